@@ -1,0 +1,1148 @@
+// C ABI (include/dsmgp_hip.h) and host orchestration of the GP-expert hot path on one MI355X.
+// The host builds, once per leaf table, flat task lists for every block step of the batched
+// left-looking Cholesky; fit!/predict then replay them as a fixed launch sequence on one stream.
+#include "../../include/dsmgp_hip.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dsmgp;
+
+namespace {
+
+std::string g_create_error;
+
+struct HyperHost {
+    int kind = -1;
+    std::vector<double> loghyp;   // [logl..., logs, logNoise]
+};
+
+struct LeafHost {
+    int n = 0, npad = 0, nb = 0, kid = 0;
+    double mean = 0.0;
+    int64_t obs_off = 0;
+    int op = DSMGP_SHARE_FULL, src = -1;
+    int64_t prefix = 0;
+    int owner = -1;          // leaf whose factor buffer this leaf uses (itself unless COPY)
+    int kb = 0;              // PREFIX: number of leading 128-blocks copied from src
+    size_t f_off = 0, dinv_off = 0, vec_off = 0, xg_off = 0;
+    // prediction
+    int nt = 0, ntpad = 0;
+    size_t vt_off = 0, xt_off = 0, pv_off = 0;
+    int64_t route_off = 0;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t count = 0;
+};
+
+struct StepLists {
+    // one phase (wave) of factorisation: per block step k the tasks for update / diag / trsm
+    std::vector<int> upd_off, diag_off, trsm_off;   // size nsteps+1
+    DevBuf<TileTask> upd, trsm;
+    DevBuf<DiagTask> diag;
+    int nsteps = 0;
+};
+
+}  // namespace
+
+struct dsmgp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profile = false;
+
+    int64_t N = 0;
+    int D = 0;
+    double* dX = nullptr;
+    double* dy = nullptr;
+
+    int L = 0;
+    std::vector<LeafHost> leaves;
+    std::vector<int64_t> obs_ptr, obs_idx;
+    int64_t* d_obs_ptr = nullptr;
+    int64_t* d_obs_idx = nullptr;
+    bool sharing_set = false;
+    bool plan_ready = false;
+
+    std::vector<HyperHost> hyper;
+    KParam* d_kp = nullptr;
+    double* d_l2 = nullptr;
+    int kp_count = 0;
+
+    double* arenaF = nullptr;
+    double* arenaDinv = nullptr;
+    double* arenaVec = nullptr;     // per leaf: yc, w, z, alpha (4 x npad)
+    double* arenaXg = nullptr;
+    int* d_info = nullptr;
+    double* d_mll = nullptr;
+    LeafDev* d_leaves = nullptr;
+    std::vector<LeafDev> h_leaves;
+    size_t bytes_needed = 0;
+
+    DevBuf<GramTask> gram;
+    StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
+    std::vector<int> fwd_off, bwd_off;
+    DevBuf<SolveTask> fwd, bwd;
+    int solve_steps = 0;
+    bool fitted = false;
+
+    // prediction
+    double* dXt = nullptr;
+    int64_t n_t = 0;
+    int64_t* d_route_ptr = nullptr;
+    int64_t* d_route_idx = nullptr;
+    std::vector<int64_t> route_ptr;
+    double* arenaVt = nullptr;
+    double* arenaXt = nullptr;
+    double* arenaPV = nullptr;      // per leaf: mu, var (2 x ntpad)
+    DevBuf<GramTask> pgram;
+    DevBuf<PredTask> ptasks;
+    std::vector<int> pupd_off, ptrsm_off;
+    DevBuf<TileTask> pupd, ptrsm;
+    int psteps = 0;
+    bool test_ready = false;
+    bool predicted = false;
+    int64_t route_total = 0;
+
+    double timings[DSMGP_N_TIMINGS] = {0};
+    double alg_flops_update = 0.0;  // algorithmic flops of the Cholesky update launches
+    int n_update_launches = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return (e_ == hipErrorOutOfMemory) ? DSMGP_E_NOMEM : DSMGP_E_HIP;                    \
+        }                                                                                        \
+    } while (0)
+
+int fail(dsmgp_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+template <class T>
+int dev_upload(dsmgp_ctx* ctx, DevBuf<T>& buf, const std::vector<T>& host) {
+    if (buf.p) {
+        HIPCHK(ctx, hipFree(buf.p));
+        buf.p = nullptr;
+    }
+    buf.count = host.size();
+    if (host.empty()) return 0;
+    HIPCHK(ctx, hipMalloc(&buf.p, host.size() * sizeof(T)));
+    HIPCHK(ctx, hipMemcpy(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <class T>
+void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_plan(dsmgp_ctx* c) {
+    dev_free(c->arenaF);
+    dev_free(c->arenaDinv);
+    dev_free(c->arenaVec);
+    dev_free(c->arenaXg);
+    dev_free(c->d_info);
+    dev_free(c->d_mll);
+    dev_free(c->d_leaves);
+    dev_free(c->gram.p);
+    for (auto& ph : c->phase) {
+        dev_free(ph.upd.p);
+        dev_free(ph.trsm.p);
+        dev_free(ph.diag.p);
+    }
+    dev_free(c->fwd.p);
+    dev_free(c->bwd.p);
+    c->plan_ready = false;
+    c->fitted = false;
+}
+
+void free_test(dsmgp_ctx* c) {
+    dev_free(c->dXt);
+    dev_free(c->d_route_ptr);
+    dev_free(c->d_route_idx);
+    dev_free(c->arenaVt);
+    dev_free(c->arenaXt);
+    dev_free(c->arenaPV);
+    dev_free(c->pgram.p);
+    dev_free(c->ptasks.p);
+    dev_free(c->pupd.p);
+    dev_free(c->ptrsm.p);
+    c->test_ready = false;
+    c->predicted = false;
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Upload the KParam table from the host hyper-parameters.
+int upload_hyper(dsmgp_ctx* c) {
+    const int nk = (int)c->hyper.size();
+    std::vector<double> l2pool;
+    std::vector<KParam> kp(nk);
+    std::vector<size_t> off(nk);
+    for (int k = 0; k < nk; ++k) {
+        const HyperHost& h = c->hyper[k];
+        off[k] = l2pool.size();
+        if (h.kind < 0) {   // id never set: no leaf may use it (check_hyper)
+            kp[k] = KParam{0, 0, 1.0, 1.0, 1.0, nullptr};
+            continue;
+        }
+        const int nl = (int)h.loghyp.size() - 2;
+        off[k] = l2pool.size();
+        for (int i = 0; i < nl; ++i) {
+            const double l = std::exp(h.loghyp[i]);
+            l2pool.push_back(l * l);
+        }
+        kp[k].kind = h.kind;
+        kp[k].nl = nl;
+        const double logs = h.loghyp[nl];
+        const double logn = h.loghyp[nl + 1];
+        kp[k].sigma2 = (h.kind == DSMGP_KIND_ISO_LINEAR) ? 1.0 : std::exp(2.0 * logs);
+        kp[k].sigma = (h.kind == DSMGP_KIND_ISO_LINEAR) ? 1.0 : std::exp(logs);
+        kp[k].noise = std::exp(2.0 * logn);
+    }
+    dev_free(c->d_l2);
+    dev_free(c->d_kp);
+    HIPCHK(c, hipMalloc(&c->d_l2, std::max<size_t>(1, l2pool.size()) * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_l2, l2pool.data(), l2pool.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < nk; ++k) kp[k].l2 = c->d_l2 + off[k];
+    HIPCHK(c, hipMalloc(&c->d_kp, std::max(1, nk) * sizeof(KParam)));
+    HIPCHK(c, hipMemcpy(c->d_kp, kp.data(), nk * sizeof(KParam), hipMemcpyHostToDevice));
+    c->kp_count = nk;
+    return 0;
+}
+
+int check_hyper(dsmgp_ctx* c) {
+    for (int l = 0; l < c->L; ++l) {
+        const int kid = c->leaves[l].kid;
+        if (kid < 0 || kid >= (int)c->hyper.size() || c->hyper[kid].kind < 0)
+            return fail(c, DSMGP_E_STATE, "leaf " + std::to_string(l) + " uses kernel id " + std::to_string(kid) +
+                                              " without hyper-parameters");
+        const HyperHost& h = c->hyper[kid];
+        const int nl = (int)h.loghyp.size() - 2;
+        if (h.kind == DSMGP_KIND_ARD_SE && nl != c->D)
+            return fail(c, DSMGP_E_ARG, "ArdSE needs one lengthscale per input dimension");
+        if (h.kind != DSMGP_KIND_ARD_SE && nl != 1) return fail(c, DSMGP_E_ARG, "Iso kernels take one lengthscale");
+    }
+    return 0;
+}
+
+// Algorithmic flops of the left-looking update of a leaf of (unpadded) size n: for every block column k,
+// 2*K flops (K = 128k) per lower-triangle element of that block column.
+double update_flops(int n) {
+    double f = 0.0;
+    for (int k = 1; k * TB < n; ++k) {
+        const int c0 = k * TB, c1 = std::min(n, c0 + TB);
+        double elems = 0.0;
+        for (int c = c0; c < c1; ++c) elems += (double)(n - c);
+        f += 2.0 * (double)c0 * elems;
+    }
+    return f;
+}
+
+// Build arenas, the LeafDev table and every task list for the current leaf table + sharing schedule.
+int build_plan(dsmgp_ctx* c) {
+    free_plan(c);
+    const int L = c->L;
+    if (L == 0) return fail(c, DSMGP_E_STATE, "no leaves set");
+    size_t fTot = 0, dTot = 0, vTot = 0, xTot = 0;
+    for (int l = 0; l < L; ++l) {
+        LeafHost& lf = c->leaves[l];
+        lf.owner = (lf.op == DSMGP_SHARE_COPY) ? lf.src : l;
+        lf.kb = (lf.op == DSMGP_SHARE_PREFIX) ? (int)(lf.prefix / TB) : 0;
+        if (lf.op == DSMGP_SHARE_PREFIX && lf.kb == 0) {
+            lf.op = DSMGP_SHARE_FULL;   // nothing worth copying
+            lf.src = -1;
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+        LeafHost& lf = c->leaves[l];
+        if (lf.owner == l) {
+            lf.f_off = fTot;
+            fTot += (size_t)lf.npad * lf.npad;
+            lf.dinv_off = dTot;
+            dTot += (size_t)lf.nb * TB * TB;
+        }
+        lf.vec_off = vTot;
+        vTot += (size_t)4 * lf.npad;
+        lf.xg_off = xTot;
+        xTot += (size_t)lf.npad * c->D;
+    }
+    for (int l = 0; l < L; ++l) {
+        LeafHost& lf = c->leaves[l];
+        if (lf.owner != l) {
+            lf.f_off = c->leaves[lf.owner].f_off;
+            lf.dinv_off = c->leaves[lf.owner].dinv_off;
+        }
+    }
+    c->bytes_needed = (fTot + dTot + vTot + xTot) * sizeof(double);
+    size_t freeB = 0, totalB = 0;
+    HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+    if (c->bytes_needed + (size_t(1) << 30) > freeB)
+        return fail(c, DSMGP_E_NOMEM, "leaf table needs " + std::to_string(c->bytes_needed >> 20) + " MiB, device has " +
+                                          std::to_string(freeB >> 20) + " MiB free");
+    HIPCHK(c, hipMalloc(&c->arenaF, std::max<size_t>(1, fTot) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->arenaDinv, std::max<size_t>(1, dTot) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->arenaVec, std::max<size_t>(1, vTot) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->arenaXg, std::max<size_t>(1, xTot) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_info, L * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_mll, L * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_leaves, L * sizeof(LeafDev)));
+
+    c->h_leaves.assign(L, LeafDev{});
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        LeafDev& d = c->h_leaves[l];
+        d.F = c->arenaF + lf.f_off;
+        d.Dinv = c->arenaDinv + lf.dinv_off;
+        d.Xg = c->arenaXg + lf.xg_off;
+        d.yc = c->arenaVec + lf.vec_off;
+        d.w = d.yc + lf.npad;
+        d.z = d.w + lf.npad;
+        d.alpha = d.z + lf.npad;
+        d.info = c->d_info + lf.owner;
+        d.mean = lf.mean;
+        d.n = lf.n;
+        d.npad = lf.npad;
+        d.nb = lf.nb;
+        d.kid = lf.kid;
+    }
+    HIPCHK(c, hipMemcpy(c->d_leaves, c->h_leaves.data(), L * sizeof(LeafDev), hipMemcpyHostToDevice));
+
+    // gather X rows and centred y of every leaf (replaces the per-leaf views + apply_subtract!,
+    // src/gaussianprocess.jl:72-74, src/treeStructure.jl:271-273)
+    {
+        int maxpad = 0;
+        for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
+        for (int l0 = 0; l0 < L; l0 += 32768) {
+            const int cnt = std::min(32768, L - l0);
+            dim3 grid((maxpad + 255) / 256, cnt);
+            gather_leaf_kernel<<<grid, 256, 0, c->stream>>>(c->d_leaves, c->d_obs_ptr, c->d_obs_idx, c->dX, c->dy,
+                                                            c->N, c->D, l0);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+
+    // Gram tasks: lower tiles of every owner
+    std::vector<GramTask> gram;
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (lf.owner != l) continue;
+        const LeafDev& d = c->h_leaves[l];
+        for (int j = 0; j < lf.nb; ++j)
+            for (int i = j; i < lf.nb; ++i) {
+                GramTask g{};
+                g.xa = d.Xg + (size_t)i * TB;
+                g.xb = d.Xg + (size_t)j * TB;
+                g.out = d.F + (size_t)i * TB + (size_t)j * TB * lf.npad;
+                g.lda = g.ldb = g.ldo = lf.npad;
+                g.na = std::max(0, std::min(TB, lf.n - i * TB));
+                g.nb = std::max(0, std::min(TB, lf.n - j * TB));
+                g.sym = 1;
+                g.diag = (i == j);
+                g.kid = lf.kid;
+                gram.push_back(g);
+            }
+    }
+    if (int rc = dev_upload(c, c->gram, gram)) return rc;
+
+    // factorisation phases
+    c->alg_flops_update = 0.0;
+    for (int ph = 0; ph < 2; ++ph) {
+        StepLists& S = c->phase[ph];
+        int nsteps = 0;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.owner != l) continue;
+            if ((lf.op == DSMGP_SHARE_PREFIX) != (ph == 1)) continue;
+            nsteps = std::max(nsteps, lf.nb);
+        }
+        S.nsteps = nsteps;
+        std::vector<TileTask> upd, trsm;
+        std::vector<DiagTask> diag;
+        S.upd_off.assign(nsteps + 1, 0);
+        S.trsm_off.assign(nsteps + 1, 0);
+        S.diag_off.assign(nsteps + 1, 0);
+        for (int k = 0; k < nsteps; ++k) {
+            S.upd_off[k] = (int)upd.size();
+            S.trsm_off[k] = (int)trsm.size();
+            S.diag_off[k] = (int)diag.size();
+            for (int l = 0; l < L; ++l) {
+                const LeafHost& lf = c->leaves[l];
+                if (lf.owner != l || lf.nb <= k) continue;
+                if ((lf.op == DSMGP_SHARE_PREFIX) != (ph == 1)) continue;
+                const LeafDev& d = c->h_leaves[l];
+                const int ld = lf.npad;
+                // a PREFIX leaf keeps the copied leading kb x kb blocks: for k < kb only rows >= kb are new
+                const int i_first = (k < lf.kb) ? lf.kb : k;
+                const bool own_diag = (k >= lf.kb);
+                for (int i = i_first; i < lf.nb; ++i) {
+                    if (k > 0) {
+                        TileTask u{};
+                        u.A = d.F + (size_t)i * TB;
+                        u.B = d.F + (size_t)k * TB;
+                        u.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
+                        u.lda = u.ldb = u.ldc = ld;
+                        upd.push_back(u);
+                    }
+                    if (i > k) {
+                        TileTask s{};
+                        s.A = d.F + (size_t)i * TB + (size_t)k * TB * ld;
+                        s.B = d.Dinv + (size_t)k * TB * TB;
+                        s.C = const_cast<double*>(s.A);
+                        s.lda = ld;
+                        s.ldb = TB;
+                        s.ldc = ld;
+                        trsm.push_back(s);
+                    }
+                }
+                if (own_diag) {
+                    DiagTask g{};
+                    g.T = d.F + (size_t)k * TB + (size_t)k * TB * ld;
+                    g.Dinv = d.Dinv + (size_t)k * TB * TB;
+                    g.info = d.info;
+                    g.ld = ld;
+                    g.nvalid = std::max(0, std::min(TB, lf.n - k * TB));
+                    g.row0 = k * TB;
+                    diag.push_back(g);
+                }
+            }
+        }
+        S.upd_off[nsteps] = (int)upd.size();
+        S.trsm_off[nsteps] = (int)trsm.size();
+        S.diag_off[nsteps] = (int)diag.size();
+        if (int rc = dev_upload(c, S.upd, upd)) return rc;
+        if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
+        if (int rc = dev_upload(c, S.diag, diag)) return rc;
+    }
+    for (int l = 0; l < L; ++l)
+        if (c->leaves[l].owner == l) c->alg_flops_update += update_flops(c->leaves[l].n);
+
+    // solve sweeps: every leaf (COPY leaves have their own right-hand side)
+    {
+        int nsteps = 0;
+        for (auto& lf : c->leaves) nsteps = std::max(nsteps, lf.nb);
+        c->solve_steps = nsteps;
+        std::vector<SolveTask> fwd, bwd;
+        c->fwd_off.assign(nsteps + 1, 0);
+        c->bwd_off.assign(nsteps + 1, 0);
+        for (int k = 0; k < nsteps; ++k) {
+            c->fwd_off[k] = (int)fwd.size();
+            for (int l = 0; l < L; ++l) {
+                const LeafHost& lf = c->leaves[l];
+                if (lf.nb <= k) continue;
+                const LeafDev& d = c->h_leaves[l];
+                for (int i = k; i < lf.nb; ++i) {
+                    SolveTask s{};
+                    s.Dk = d.Dinv + (size_t)k * TB * TB;
+                    s.vk = d.w + (size_t)k * TB;
+                    s.ldt = lf.npad;
+                    if (i == k) {
+                        s.self = 1;
+                        s.out_k = d.z + (size_t)k * TB;
+                    } else {
+                        s.T = d.F + (size_t)i * TB + (size_t)k * TB * lf.npad;
+                        s.vi = d.w + (size_t)i * TB;
+                    }
+                    fwd.push_back(s);
+                }
+            }
+        }
+        c->fwd_off[nsteps] = (int)fwd.size();
+        // backward sweep: step s handles block kb = nb-1-s of each leaf; z is consumed in place
+        for (int s_ = 0; s_ < nsteps; ++s_) {
+            c->bwd_off[s_] = (int)bwd.size();
+            for (int l = 0; l < L; ++l) {
+                const LeafHost& lf = c->leaves[l];
+                const int kb = lf.nb - 1 - s_;
+                if (kb < 0) continue;
+                const LeafDev& d = c->h_leaves[l];
+                for (int j = 0; j <= kb; ++j) {
+                    SolveTask s{};
+                    s.Dk = d.Dinv + (size_t)kb * TB * TB;
+                    s.vk = d.z + (size_t)kb * TB;
+                    s.ldt = lf.npad;
+                    if (j == kb) {
+                        s.self = 1;
+                        s.out_k = d.alpha + (size_t)kb * TB;
+                    } else {
+                        s.T = d.F + (size_t)kb * TB + (size_t)j * TB * lf.npad;
+                        s.vi = d.z + (size_t)j * TB;
+                    }
+                    bwd.push_back(s);
+                }
+            }
+        }
+        c->bwd_off[nsteps] = (int)bwd.size();
+        if (int rc = dev_upload(c, c->fwd, fwd)) return rc;
+        if (int rc = dev_upload(c, c->bwd, bwd)) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->plan_ready = true;
+    return 0;
+}
+
+struct PhaseTimer {
+    dsmgp_ctx* c;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;
+    explicit PhaseTimer(dsmgp_ctx* c_) : c(c_) {}
+    void begin(int slot) {
+        if (!c->profile) return;
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, c->stream);
+        spans.push_back({slot, {a, b}});
+    }
+    void end() {
+        if (!c->profile) return;
+        (void)hipEventRecord(spans.back().second.second, c->stream);
+    }
+    void collect() {
+        for (auto& s : spans) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, s.second.first, s.second.second);
+            c->timings[s.first] += ms * 1e-3;
+            (void)hipEventDestroy(s.second.first);
+            (void)hipEventDestroy(s.second.second);
+        }
+        spans.clear();
+    }
+};
+
+// One factorisation phase: for every block step, update -> diagonal -> panel solve.
+int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
+    for (int k = 0; k < S.nsteps; ++k) {
+        const int nu = S.upd_off[k + 1] - S.upd_off[k];
+        if (nu > 0) {
+            pt.begin(1);
+            tile_gemm_kernel<true><<<nu, 256, 0, c->stream>>>(S.upd.p + S.upd_off[k], k * TB);
+            pt.end();
+            if (count_launches) c->n_update_launches++;
+        }
+        const int nd = S.diag_off[k + 1] - S.diag_off[k];
+        if (nd > 0) {
+            pt.begin(2);
+            chol_diag_kernel<<<nd, 256, TB*(TB + 1) * sizeof(double), c->stream>>>(S.diag.p + S.diag_off[k]);
+            pt.end();
+        }
+        const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
+        if (ns > 0) {
+            pt.begin(3);
+            tile_gemm_kernel<false><<<ns, 256, 0, c->stream>>>(S.trsm.p + S.trsm_off[k], TB);
+            pt.end();
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
+    if (!out) return fail(nullptr, DSMGP_E_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, DSMGP_E_NODEVICE, "no HIP device visible: the GP-expert path has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, DSMGP_E_ARG, "device id out of range");
+    dsmgp_ctx* c = new dsmgp_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, TB * (TB + 1) * (int)sizeof(double));
+    const char* p = std::getenv("DSMGP_PROFILE");
+    c->profile = p && p[0] == '1';
+    *out = c;
+    return 0;
+}
+
+int dsmgp_destroy(dsmgp_ctx* c) {
+    if (!c) return DSMGP_E_ARG;
+    (void)hipSetDevice(c->device);
+    free_plan(c);
+    free_test(c);
+    dev_free(c->dX);
+    dev_free(c->dy);
+    dev_free(c->d_obs_ptr);
+    dev_free(c->d_obs_idx);
+    dev_free(c->d_kp);
+    dev_free(c->d_l2);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+const char* dsmgp_last_error(dsmgp_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int dsmgp_device_name(dsmgp_ctx* c, char* buf, int32_t len) {
+    if (!c || !buf || len <= 0) return DSMGP_E_ARG;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    std::snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int dsmgp_set_profile(dsmgp_ctx* c, int32_t on) {
+    if (!c) return DSMGP_E_ARG;
+    c->profile = on != 0;
+    return 0;
+}
+
+int dsmgp_set_train(dsmgp_ctx* c, const double* X, const double* y, int64_t N, int32_t D) {
+    if (!c) return DSMGP_E_ARG;
+    if (!X || !y || N <= 0 || D <= 0) return fail(c, DSMGP_E_ARG, "set_train: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    free_plan(c);
+    free_test(c);
+    dev_free(c->dX);
+    dev_free(c->dy);
+    c->N = N;
+    c->D = D;
+    HIPCHK(c, hipMalloc(&c->dX, (size_t)N * D * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->dy, (size_t)N * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->dX, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dy, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    c->L = 0;
+    c->leaves.clear();
+    return 0;
+}
+
+int dsmgp_set_leaves(dsmgp_ctx* c, int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx,
+                     const int32_t* kernel_id, const double* mean) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->dX) return fail(c, DSMGP_E_STATE, "set_leaves before set_train");
+    if (L <= 0 || !obs_ptr || !obs_idx || !kernel_id || !mean) return fail(c, DSMGP_E_ARG, "set_leaves: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    free_plan(c);
+    free_test(c);
+    if (obs_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "obs_ptr[0] must be 0");
+    c->leaves.assign(L, LeafHost{});
+    for (int l = 0; l < L; ++l) {
+        const int64_t a = obs_ptr[l], b = obs_ptr[l + 1];
+        if (b <= a) return fail(c, DSMGP_E_ARG, "leaf " + std::to_string(l) + " has no observations");
+        if (b - a > (int64_t)1 << 20) return fail(c, DSMGP_E_ARG, "leaf too large");
+        for (int64_t i = a; i < b; ++i) {
+            if (obs_idx[i] < 0 || obs_idx[i] >= c->N) return fail(c, DSMGP_E_ARG, "observation index out of range");
+            if (i > a && obs_idx[i] <= obs_idx[i - 1]) return fail(c, DSMGP_E_ARG, "obs lists must be strictly ascending");
+        }
+        if (kernel_id[l] < 0 || kernel_id[l] > 4096) return fail(c, DSMGP_E_ARG, "kernel id out of range");
+        LeafHost& lf = c->leaves[l];
+        lf.n = (int)(b - a);
+        lf.npad = round_up(lf.n, TB);
+        lf.nb = lf.npad / TB;
+        lf.kid = kernel_id[l];
+        lf.mean = mean[l];
+        lf.obs_off = a;
+    }
+    c->L = L;
+    c->obs_ptr.assign(obs_ptr, obs_ptr + L + 1);
+    c->obs_idx.assign(obs_idx, obs_idx + obs_ptr[L]);
+    dev_free(c->d_obs_ptr);
+    dev_free(c->d_obs_idx);
+    HIPCHK(c, hipMalloc(&c->d_obs_ptr, (L + 1) * sizeof(int64_t)));
+    HIPCHK(c, hipMalloc(&c->d_obs_idx, std::max<size_t>(1, c->obs_idx.size()) * sizeof(int64_t)));
+    HIPCHK(c, hipMemcpy(c->d_obs_ptr, obs_ptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_obs_idx, obs_idx, c->obs_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    c->sharing_set = false;
+    return 0;
+}
+
+int dsmgp_set_sharing(dsmgp_ctx* c, const int32_t* op, const int32_t* src, const int64_t* prefix_len) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_sharing before set_leaves");
+    const int L = c->L;
+    for (int l = 0; l < L; ++l) {
+        LeafHost& lf = c->leaves[l];
+        const int o = op ? op[l] : DSMGP_SHARE_FULL;
+        if (o == DSMGP_SHARE_FULL) {
+            lf.op = o;
+            lf.src = -1;
+            lf.prefix = 0;
+            continue;
+        }
+        if (!src || src[l] < 0 || src[l] >= L || src[l] == l) return fail(c, DSMGP_E_ARG, "sharing: bad source leaf");
+        const LeafHost& s = c->leaves[src[l]];
+        const int so = op[src[l]];
+        if (so != DSMGP_SHARE_FULL) return fail(c, DSMGP_E_ARG, "sharing: source leaf must be factorised in full");
+        if (s.kid != lf.kid) return fail(c, DSMGP_E_ARG, "sharing: kernel ids differ");
+        const int64_t* a = c->obs_idx.data() + lf.obs_off;
+        const int64_t* b = c->obs_idx.data() + s.obs_off;
+        if (o == DSMGP_SHARE_COPY) {
+            if (s.n != lf.n || std::memcmp(a, b, sizeof(int64_t) * lf.n) != 0)
+                return fail(c, DSMGP_E_ARG, "sharing: COPY needs identical observation lists");
+            lf.prefix = 0;
+        } else if (o == DSMGP_SHARE_PREFIX) {
+            if (!prefix_len || prefix_len[l] != s.n || s.n >= lf.n || std::memcmp(a, b, sizeof(int64_t) * s.n) != 0)
+                return fail(c, DSMGP_E_ARG, "sharing: PREFIX needs the source's list as a strict prefix");
+            lf.prefix = prefix_len[l];
+        } else {
+            return fail(c, DSMGP_E_ARG, "sharing: unknown op");
+        }
+        lf.op = o;
+        lf.src = src[l];
+    }
+    c->sharing_set = true;
+    free_plan(c);
+    return 0;
+}
+
+int dsmgp_set_hyper(dsmgp_ctx* c, int32_t kernel_id, int32_t kind, const double* loghyp, int32_t n) {
+    if (!c) return DSMGP_E_ARG;
+    if (kernel_id < 0 || kernel_id > 4096 || !loghyp || n < 3) return fail(c, DSMGP_E_ARG, "set_hyper: bad arguments");
+    if (kind < 0 || kind > 2) return fail(c, DSMGP_E_ARG, "set_hyper: unknown kernel kind");
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(loghyp[i])) return fail(c, DSMGP_E_ARG, "set_hyper: non-finite hyper-parameter");
+    if ((int)c->hyper.size() <= kernel_id) c->hyper.resize(kernel_id + 1);
+    c->hyper[kernel_id].kind = kind;
+    c->hyper[kernel_id].loghyp.assign(loghyp, loghyp + n);
+    c->fitted = false;
+    c->predicted = false;
+    return 0;
+}
+
+int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->L == 0) return fail(c, DSMGP_E_STATE, "fit before set_leaves");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_hyper(c)) return rc;
+    if (!c->plan_ready)
+        if (int rc = build_plan(c)) return rc;
+    if (int rc = upload_hyper(c)) return rc;
+    const int L = c->L;
+    for (int i = 0; i < 6; ++i) c->timings[i] = 0.0;
+    c->timings[11] = 0.0;
+    c->n_update_launches = 0;
+    PhaseTimer pt(c);
+    hipEvent_t t0, t1;
+    HIPCHK(c, hipEventCreate(&t0));
+    HIPCHK(c, hipEventCreate(&t1));
+    HIPCHK(c, hipEventRecord(t0, c->stream));
+
+    HIPCHK(c, hipMemsetAsync(c->d_info, 0, L * sizeof(int), c->stream));
+    // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98)
+    if (c->gram.count) {
+        pt.begin(0);
+        gram_tile_kernel<<<(int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
+        pt.end();
+    }
+    // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101)
+    if (int rc = run_phase(c, c->phase[0], pt, true)) return rc;
+    // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
+    bool any_prefix = false;
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (lf.op != DSMGP_SHARE_PREFIX) continue;
+        any_prefix = true;
+        const LeafDev& d = c->h_leaves[l];
+        const LeafDev& s = c->h_leaves[lf.src];
+        const size_t rows = (size_t)lf.kb * TB;
+        HIPCHK(c, hipMemcpy2DAsync(d.F, (size_t)d.npad * sizeof(double), s.F, (size_t)s.npad * sizeof(double),
+                                   rows * sizeof(double), rows, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d.Dinv, s.Dinv, rows * TB * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (any_prefix)
+        if (int rc = run_phase(c, c->phase[1], pt, true)) return rc;
+    // 4. alpha = L^-T (L^-1 y)                                (src/gaussianprocess.jl:105)
+    {
+        int maxpad = 0;
+        for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
+        pt.begin(4);
+        copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
+        for (int k = 0; k < c->solve_steps; ++k) {
+            const int n = c->fwd_off[k + 1] - c->fwd_off[k];
+            if (n > 0) solve_fwd_kernel<<<n, 256, 0, c->stream>>>(c->fwd.p + c->fwd_off[k]);
+        }
+        for (int s = 0; s < c->solve_steps; ++s) {
+            const int n = c->bwd_off[s + 1] - c->bwd_off[s];
+            if (n > 0) solve_bwd_kernel<<<n, 256, 0, c->stream>>>(c->bwd.p + c->bwd_off[s]);
+        }
+        pt.end();
+    }
+    // 5. log marginal likelihood                              (src/gaussianprocess.jl:163)
+    pt.begin(5);
+    mll_kernel<<<L, 256, 0, c->stream>>>(c->d_leaves, c->d_mll);
+    pt.end();
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    pt.collect();
+    c->timings[11] = ms * 1e-3;
+    if (seconds) *seconds = ms * 1e-3;
+    if (mll_out) HIPCHK(c, hipMemcpy(mll_out, c->d_mll, L * sizeof(double), hipMemcpyDeviceToHost));
+    if (info_out) {
+        // info lives per factor owner
+        std::vector<int> owner_info(L);
+        HIPCHK(c, hipMemcpy(owner_info.data(), c->d_info, L * sizeof(int), hipMemcpyDeviceToHost));
+        for (int l = 0; l < L; ++l) info_out[l] = owner_info[c->leaves[l].owner];
+    }
+    c->fitted = true;
+    c->predicted = false;
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* route_ptr, const int64_t* route_idx) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_test before set_leaves");
+    if (!Xt || n_t <= 0 || !route_ptr) return fail(c, DSMGP_E_ARG, "set_test: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->plan_ready)
+        if (int rc = build_plan(c)) return rc;
+    free_test(c);
+    const int L = c->L;
+    if (route_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "route_ptr[0] must be 0");
+    const int64_t total = route_ptr[L];
+    if (total > 0 && !route_idx) return fail(c, DSMGP_E_ARG, "route_idx is NULL");
+    for (int l = 0; l < L; ++l)
+        if (route_ptr[l + 1] < route_ptr[l]) return fail(c, DSMGP_E_ARG, "route_ptr must be non-decreasing");
+    for (int64_t i = 0; i < total; ++i)
+        if (route_idx[i] < 0 || route_idx[i] >= n_t) return fail(c, DSMGP_E_ARG, "route index out of range");
+    c->n_t = n_t;
+    c->route_total = total;
+    c->route_ptr.assign(route_ptr, route_ptr + L + 1);
+    size_t vTot = 0, xTot = 0, pTot = 0;
+    for (int l = 0; l < L; ++l) {
+        LeafHost& lf = c->leaves[l];
+        lf.nt = (int)(route_ptr[l + 1] - route_ptr[l]);
+        lf.ntpad = round_up(lf.nt, TB);
+        lf.route_off = route_ptr[l];
+        lf.vt_off = vTot;
+        vTot += (size_t)lf.ntpad * lf.npad;
+        lf.xt_off = xTot;
+        xTot += (size_t)lf.ntpad * c->D;
+        lf.pv_off = pTot;
+        pTot += (size_t)2 * lf.ntpad;
+    }
+    size_t freeB = 0, totalB = 0;
+    HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+    const size_t need = (vTot + xTot + pTot) * sizeof(double) + (size_t)n_t * c->D * sizeof(double);
+    if (need + (size_t(1) << 30) > freeB)
+        return fail(c, DSMGP_E_NOMEM, "test set needs " + std::to_string(need >> 20) + " MiB, device has " +
+                                          std::to_string(freeB >> 20) + " MiB free");
+    HIPCHK(c, hipMalloc(&c->dXt, (size_t)n_t * c->D * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->dXt, Xt, (size_t)n_t * c->D * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_route_ptr, (L + 1) * sizeof(int64_t)));
+    HIPCHK(c, hipMemcpy(c->d_route_ptr, route_ptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_route_idx, std::max<int64_t>(1, total) * sizeof(int64_t)));
+    if (total) HIPCHK(c, hipMemcpy(c->d_route_idx, route_idx, total * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->arenaVt, std::max<size_t>(1, vTot) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->arenaXt, std::max<size_t>(1, xTot) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->arenaPV, std::max<size_t>(1, pTot) * sizeof(double)));
+    int maxpad = 0;
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        LeafDev& d = c->h_leaves[l];
+        d.Vt = c->arenaVt + lf.vt_off;
+        d.Xtg = c->arenaXt + lf.xt_off;
+        d.mu = c->arenaPV + lf.pv_off;
+        d.var = d.mu + lf.ntpad;
+        d.nt = lf.nt;
+        d.ntpad = lf.ntpad;
+        maxpad = std::max(maxpad, lf.ntpad);
+    }
+    HIPCHK(c, hipMemcpy(c->d_leaves, c->h_leaves.data(), L * sizeof(LeafDev), hipMemcpyHostToDevice));
+    if (maxpad > 0) {
+        for (int l0 = 0; l0 < L; l0 += 32768) {
+            const int cnt = std::min(32768, L - l0);
+            gather_test_kernel<<<dim3((maxpad + 255) / 256, cnt), 256, 0, c->stream>>>(
+                c->d_leaves, c->d_route_ptr, c->d_route_idx, c->dXt, n_t, c->D, l0);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    // task lists
+    std::vector<GramTask> pg;
+    std::vector<PredTask> ptk;
+    int nsteps = 0;
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (lf.nt == 0) continue;
+        nsteps = std::max(nsteps, lf.nb);
+        const LeafDev& d = c->h_leaves[l];
+        for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
+            ptk.push_back(PredTask{l, ti * TB});
+            for (int j = 0; j < lf.nb; ++j) {
+                GramTask g{};
+                g.xa = d.Xtg + (size_t)ti * TB;
+                g.xb = d.Xg + (size_t)j * TB;
+                g.out = d.Vt + (size_t)ti * TB + (size_t)j * TB * lf.ntpad;
+                g.lda = lf.ntpad;
+                g.ldb = lf.npad;
+                g.ldo = lf.ntpad;
+                g.na = std::max(0, std::min(TB, lf.nt - ti * TB));
+                g.nb = std::max(0, std::min(TB, lf.n - j * TB));
+                g.sym = 0;
+                g.diag = 0;
+                g.kid = lf.kid;
+                pg.push_back(g);
+            }
+        }
+    }
+    c->psteps = nsteps;
+    std::vector<TileTask> upd, trsm;
+    c->pupd_off.assign(nsteps + 1, 0);
+    c->ptrsm_off.assign(nsteps + 1, 0);
+    for (int k = 0; k < nsteps; ++k) {
+        c->pupd_off[k] = (int)upd.size();
+        c->ptrsm_off[k] = (int)trsm.size();
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.nt == 0 || lf.nb <= k) continue;
+            const LeafDev& d = c->h_leaves[l];
+            for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
+                double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
+                if (k > 0) {
+                    TileTask u{};
+                    u.A = d.Vt + (size_t)ti * TB;
+                    u.B = d.F + (size_t)k * TB;
+                    u.C = tile;
+                    u.lda = lf.ntpad;
+                    u.ldb = lf.npad;
+                    u.ldc = lf.ntpad;
+                    upd.push_back(u);
+                }
+                TileTask s{};
+                s.A = tile;
+                s.B = d.Dinv + (size_t)k * TB * TB;
+                s.C = tile;
+                s.lda = lf.ntpad;
+                s.ldb = TB;
+                s.ldc = lf.ntpad;
+                trsm.push_back(s);
+            }
+        }
+    }
+    c->pupd_off[nsteps] = (int)upd.size();
+    c->ptrsm_off[nsteps] = (int)trsm.size();
+    if (int rc = dev_upload(c, c->pgram, pg)) return rc;
+    if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
+    if (int rc = dev_upload(c, c->pupd, upd)) return rc;
+    if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->test_ready = true;
+    return 0;
+}
+
+int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->fitted) return fail(c, DSMGP_E_STATE, "predict before fit");
+    if (!c->test_ready) return fail(c, DSMGP_E_STATE, "predict before set_test");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 6; i < 10; ++i) c->timings[i] = 0.0;
+    c->timings[12] = 0.0;
+    PhaseTimer pt(c);
+    hipEvent_t t0, t1;
+    HIPCHK(c, hipEventCreate(&t0));
+    HIPCHK(c, hipEventCreate(&t1));
+    HIPCHK(c, hipEventRecord(t0, c->stream));
+    if (c->pgram.count) {
+        // K_tn tiles and the predictive mean        (src/gaussianprocess.jl:117-118,133)
+        pt.begin(6);
+        gram_tile_kernel<<<(int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
+        pred_mu_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p);
+        pt.end();
+        // V^T = K_tn L^-T, block column by block column (src/gaussianprocess.jl:120)
+        for (int k = 0; k < c->psteps; ++k) {
+            const int nu = c->pupd_off[k + 1] - c->pupd_off[k];
+            if (nu > 0) {
+                pt.begin(7);
+                tile_gemm_kernel<true><<<nu, 256, 0, c->stream>>>(c->pupd.p + c->pupd_off[k], k * TB);
+                pt.end();
+            }
+            const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
+            if (ns > 0) {
+                pt.begin(8);
+                tile_gemm_kernel<false><<<ns, 256, 0, c->stream>>>(c->ptrsm.p + c->ptrsm_off[k], TB);
+                pt.end();
+            }
+        }
+        // diag(Ktt - V'V) + noise                   (src/gaussianprocess.jl:121-126)
+        pt.begin(9);
+        pred_var_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p, c->d_kp, c->D);
+        pt.end();
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    pt.collect();
+    c->timings[12] = ms * 1e-3;
+    if (seconds) *seconds = ms * 1e-3;
+    c->predicted = true;
+    return 0;
+}
+
+int dsmgp_predict_fetch(dsmgp_ctx* c, double* mu_out, double* var_out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->predicted) return fail(c, DSMGP_E_STATE, "predict_fetch before predict_run");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int l = 0; l < c->L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (lf.nt == 0) continue;
+        const LeafDev& d = c->h_leaves[l];
+        if (mu_out) HIPCHK(c, hipMemcpyAsync(mu_out + lf.route_off, d.mu, lf.nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (var_out) HIPCHK(c, hipMemcpyAsync(var_out + lf.route_off, d.var, lf.nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dsmgp_predict_leaves(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* route_ptr,
+                         const int64_t* route_idx, double* mu_out, double* var_out) {
+    if (int rc = dsmgp_set_test(c, Xt, n_t, route_ptr, route_idx)) return rc;
+    if (int rc = dsmgp_predict_run(c, nullptr)) return rc;
+    return dsmgp_predict_fetch(c, mu_out, var_out);
+}
+
+int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
+    if (!c) return DSMGP_E_ARG;
+    (void)grad_out;
+    (void)stride;
+    return fail(c, DSMGP_E_STATE, "gradients: not built yet");
+}
+
+// -------------------------------------------------------------------------------------------------
+int dsmgp_kernel_matrix(dsmgp_ctx* c, int32_t kernel_id, const double* x1, int64_t n1, const double* x2,
+                        int64_t n2, double* K_out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!x1 || !x2 || !K_out || n1 <= 0 || n2 <= 0 || c->D <= 0) return fail(c, DSMGP_E_ARG, "kernel_matrix: bad arguments");
+    if (kernel_id < 0 || kernel_id >= (int)c->hyper.size() || c->hyper[kernel_id].kind < 0)
+        return fail(c, DSMGP_E_STATE, "kernel_matrix: kernel id without hyper-parameters");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_hyper(c)) return rc;
+    const int D = c->D;
+    const int p1 = round_up((int)n1, TB), p2 = round_up((int)n2, TB);
+    double *dx1 = nullptr, *dx2 = nullptr, *dK = nullptr;
+    HIPCHK(c, hipMalloc(&dx1, (size_t)n1 * D * sizeof(double)));
+    HIPCHK(c, hipMalloc(&dx2, (size_t)n2 * D * sizeof(double)));
+    HIPCHK(c, hipMalloc(&dK, (size_t)p1 * p2 * sizeof(double)));
+    HIPCHK(c, hipMemcpy(dx1, x1, (size_t)n1 * D * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dx2, x2, (size_t)n2 * D * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<GramTask> g;
+    for (int j = 0; j < p2 / TB; ++j)
+        for (int i = 0; i < p1 / TB; ++i) {
+            GramTask t{};
+            t.xa = dx1 + (size_t)i * TB;
+            t.xb = dx2 + (size_t)j * TB;
+            t.out = dK + (size_t)i * TB + (size_t)j * TB * p1;
+            t.lda = (int)n1;
+            t.ldb = (int)n2;
+            t.ldo = p1;
+            t.na = (int)std::min<int64_t>(TB, n1 - (int64_t)i * TB);
+            t.nb = (int)std::min<int64_t>(TB, n2 - (int64_t)j * TB);
+            t.kid = kernel_id;
+            g.push_back(t);
+        }
+    DevBuf<GramTask> dg;
+    if (int rc = dev_upload(c, dg, g)) return rc;
+    gram_tile_kernel<<<(int)g.size(), 256, 0, c->stream>>>(dg.p, c->d_kp, D);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(K_out, (size_t)n1 * sizeof(double), dK, (size_t)p1 * sizeof(double), (size_t)n1 * sizeof(double),
+                          (size_t)n2, hipMemcpyDeviceToHost));
+    dev_free(dg.p);
+    dev_free(dx1);
+    dev_free(dx2);
+    dev_free(dK);
+    return 0;
+}
+
+int dsmgp_download_factor(dsmgp_ctx* c, int32_t leaf, double* F, double* alpha) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->fitted) return fail(c, DSMGP_E_STATE, "download_factor before fit");
+    if (leaf < 0 || leaf >= c->L) return fail(c, DSMGP_E_ARG, "leaf out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    const LeafHost& lf = c->leaves[leaf];
+    const LeafDev& d = c->h_leaves[leaf];
+    if (F) {
+        HIPCHK(c, hipMemcpy2D(F, (size_t)lf.n * sizeof(double), d.F, (size_t)lf.npad * sizeof(double),
+                              (size_t)lf.n * sizeof(double), (size_t)lf.n, hipMemcpyDeviceToHost));
+        for (int col = 1; col < lf.n; ++col)
+            for (int r = 0; r < col; ++r) F[r + (size_t)col * lf.n] = 0.0;
+    }
+    if (alpha) HIPCHK(c, hipMemcpy(alpha, d.alpha, lf.n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dsmgp_timings(dsmgp_ctx* c, double* out) {
+    if (!c || !out) return DSMGP_E_ARG;
+    for (int i = 0; i < DSMGP_N_TIMINGS; ++i) out[i] = c->timings[i];
+    return 0;
+}
+
+int dsmgp_work(dsmgp_ctx* c, double* alg_flops_update, int32_t* n_update_launches) {
+    if (!c) return DSMGP_E_ARG;
+    if (alg_flops_update) *alg_flops_update = c->alg_flops_update;
+    if (n_update_launches) *n_update_launches = c->n_update_launches;
+    return 0;
+}
+
+int dsmgp_memory(dsmgp_ctx* c, int64_t* needed, int64_t* free_bytes) {
+    if (!c) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(c, hipMemGetInfo(&f, &t));
+    if (needed) *needed = (int64_t)c->bytes_needed;
+    if (free_bytes) *free_bytes = (int64_t)f;
+    return 0;
+}
+
+int dsmgp_probe_f64_mfma(dsmgp_ctx* c, double* tflops) {
+    if (!c || !tflops) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount * 2;   // 2 x 256 threads = 2 waves per SIMD
+    const int iters = 20000;
+    double* out = nullptr;
+    HIPCHK(c, hipMalloc(&out, (size_t)blocks * 256 * sizeof(double)));
+    hipEvent_t t0, t1;
+    HIPCHK(c, hipEventCreate(&t0));
+    HIPCHK(c, hipEventCreate(&t1));
+    mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(out, 200);
+    HIPCHK(c, hipEventRecord(t0, c->stream));
+    mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(out, iters);
+    HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    dev_free(out);
+    const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 4.0 /*mfma per iter*/ * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return 0;
+}
+
+}  // extern "C"

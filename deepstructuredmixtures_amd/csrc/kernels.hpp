@@ -1,0 +1,520 @@
+// Device kernels of the GP-expert hot path for gfx950 (MI355X, wave64, f64 MFMA).
+//
+// Everything here works on 128x128 Float64 tiles of column-major matrices whose dimensions are
+// padded to multiples of 128 (padding = identity block, see gram_tile_kernel).  One leaf GP's
+// factor F (npad x npad) is produced by a LEFT-LOOKING blocked Cholesky, batched over all leaves:
+//   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel<true>,  v_mfma_f64_16x16x4_f64)
+//            F[k,k]  = chol(F[k,k]), Dinv_k = F[k,k]^-1   (chol_diag_kernel)
+//            F[i,k]  = F[i,k] Dinv_k^T       (tile_gemm_kernel<false>)
+// which is update_cholesky!/potrf! of the reference (src/gaussianprocess.jl:82-108) and, started at
+// a later column with the leading block copied, chol_continue! (src/AdvancedCholeskey.jl:152-174).
+// prediction() (src/gaussianprocess.jl:110-137) appends the test rows below the factor: V^T = K_tn L^-T
+// is the same two tile kernels run on the rows of K_tn.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsmgp {
+
+constexpr int TB = 128;    // tile edge = Cholesky block size
+constexpr int KC = 16;     // K-chunk staged through LDS per iteration
+constexpr int LDP = 144;   // LDS leading dimension (doubles): 128 + 16 keeps the f64 MFMA operand reads conflict-free
+constexpr int DCH = 8;     // input dimensions staged per pass in the Gram kernel
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------
+// kernel-function parameters (one per kernel id), derived on the host from the log-scale vector
+// [logl..., logs, logNoise]  (src/kernels.jl:68-73, src/gaussianprocess.jl:39)
+struct KParam {
+    int kind;           // DSMGP_KIND_*
+    int nl;             // number of lengthscales (1 for Iso, D for Ard)
+    double sigma2;      // exp(2 logs)  (1.0 for IsoLinear, src/kernels.jl:181)
+    double sigma;       // exp(logs)
+    double noise;       // exp(2 logNoise)
+    const double* l2;   // device: lengthscale^2 per slot
+};
+
+// ---------------------------------------------------------------------------------------------
+// Gram tiles.  out(r,c) = k(a_r, b_c); rows/cols beyond the valid counts are 0, and with `sym` the
+// tile belongs to K_nn: the global diagonal gets + noise + 1e-8 (src/gaussianprocess.jl:94-98,
+// eps = src/DeepStructuredMixtures.jl:27) and padded diagonal entries are 1 (identity padding).
+struct GramTask {
+    const double* xa;   // a-points, column-major [lda x D], already offset to the tile's first row
+    const double* xb;
+    double* out;        // tile origin
+    int lda, ldb, ldo;
+    int na, nb;         // valid rows / cols in this tile (<= 128)
+    int sym;            // 1: tile of a symmetric K_nn
+    int diag;           // 1: tile sits on the block diagonal (global row == global col possible)
+    int kid;
+};
+
+// One 256-thread workgroup per tile: thread t owns rows 4*(t&31)..+3 and columns (t>>5)+8q, q<16,
+// so every column of the tile is written as 32 threads x 32 B = 1 KiB contiguous.
+// IsoSE follows src/kernels.jl:21-27,78-83 as exp(-0.5*(z/l^2)) then * sigma^2, with z accumulated
+// from direct differences (the reference's Distances.pairwise uses |a|^2+|b|^2-2a.b; same value up to
+// rounding).  ArdSE is the additive form sigma^2 * sum_d exp(-0.5 (a_d-b_d)^2 / l_d^2)
+// (src/kernels.jl:39-49).  IsoLinear is a.b / l^2 (src/kernels.jl:189-194).
+__global__ __launch_bounds__(256) void gram_tile_kernel(const GramTask* __restrict__ tasks,
+                                                        const KParam* __restrict__ kp, int D) {
+    __shared__ double sa[DCH][TB];
+    __shared__ double sb[DCH][TB];
+    const GramTask tk = tasks[blockIdx.x];
+    const KParam p = kp[tk.kid];
+    const int t = threadIdx.x;
+    const int r0 = (t & 31) * 4;
+    const int cb = t >> 5;
+    double acc[16][4];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q][j] = 0.0;
+
+    for (int d0 = 0; d0 < D; d0 += DCH) {
+        const int dn = min(DCH, D - d0);
+        __syncthreads();
+        for (int e = t; e < dn * TB; e += 256) {
+            const int d = e / TB, r = e % TB;
+            sa[d][r] = (r < tk.na) ? tk.xa[r + (size_t)(d0 + d) * tk.lda] : 0.0;
+            sb[d][r] = (r < tk.nb) ? tk.xb[r + (size_t)(d0 + d) * tk.ldb] : 0.0;
+        }
+        __syncthreads();
+        for (int d = 0; d < dn; ++d) {
+            const double a0 = sa[d][r0], a1 = sa[d][r0 + 1], a2 = sa[d][r0 + 2], a3 = sa[d][r0 + 3];
+            const double l2d = (p.kind == 1) ? p.l2[d0 + d] : 1.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double b = sb[d][cb + 8 * q];
+                if (p.kind == 0) {
+                    double u;
+                    u = a0 - b; acc[q][0] = fma(u, u, acc[q][0]);
+                    u = a1 - b; acc[q][1] = fma(u, u, acc[q][1]);
+                    u = a2 - b; acc[q][2] = fma(u, u, acc[q][2]);
+                    u = a3 - b; acc[q][3] = fma(u, u, acc[q][3]);
+                } else if (p.kind == 1) {
+                    double u;
+                    u = a0 - b; acc[q][0] += exp(-0.5 * ((u * u) / l2d));
+                    u = a1 - b; acc[q][1] += exp(-0.5 * ((u * u) / l2d));
+                    u = a2 - b; acc[q][2] += exp(-0.5 * ((u * u) / l2d));
+                    u = a3 - b; acc[q][3] += exp(-0.5 * ((u * u) / l2d));
+                } else {
+                    acc[q][0] = fma(a0, b, acc[q][0]);
+                    acc[q][1] = fma(a1, b, acc[q][1]);
+                    acc[q][2] = fma(a2, b, acc[q][2]);
+                    acc[q][3] = fma(a3, b, acc[q][3]);
+                }
+            }
+        }
+    }
+    const double l2 = p.l2[0];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = cb + 8 * q;
+        d4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j;
+            double k;
+            if (p.kind == 0) k = p.sigma2 * exp(-0.5 * (acc[q][j] / l2));
+            else if (p.kind == 1) k = p.sigma2 * acc[q][j];
+            else k = acc[q][j] / l2;
+            const bool valid = (r < tk.na) && (c < tk.nb);
+            if (!valid) k = 0.0;
+            if (tk.sym && tk.diag && r == c) k = valid ? k + (p.noise + 1e-8) : 1.0;
+            v[j] = k;
+        }
+        *reinterpret_cast<d4*>(tk.out + r0 + (size_t)c * tk.ldo) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128x128 tile GEMM on the f64 matrix cores:  C = (UPDATE ? C : 0) -/+ A B^T,  K uniform per launch.
+//   A(r,kk) = A[r + kk*lda]   (tile rows, r < 128)      B(c,kk) = B[c + kk*ldb]   (tile columns)
+// 4 waves in a 2x2 grid, each owning a 64x64 sub-tile = 4x4 MFMA tiles of 16x16.
+// v_mfma_f64_16x16x4_f64: lane l supplies Aop[i=l&15][k=l>>4], Bop[k=l>>4][j=l&15] and receives
+// D[(l>>4)+4r][l&15], r<4.  The tile COLUMN index is put on the MFMA row (Aop <- B matrix) and the tile
+// ROW index on the MFMA column (Bop <- A matrix), so that the 16 lanes l&15 of a result register are 16
+// consecutive rows = 128 contiguous bytes of the column-major tile.
+struct TileTask {
+    const double* A;
+    const double* B;
+    double* C;
+    int lda, ldb, ldc;
+    int pad;
+};
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileTask* __restrict__ tasks, int K) {
+    __shared__ __attribute__((aligned(16))) double sA[2][KC * LDP];
+    __shared__ __attribute__((aligned(16))) double sB[2][KC * LDP];
+    const TileTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wr = w & 1, wc = w >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn) acc[cm][rn] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // staging: instruction q moves column kk = 4q + w of the chunk, rows 2*lane, 2*lane+1 (1 KiB per wave)
+    d2 ra[4], rb[4];
+    const double* gA = tk.A + 2 * lane + (size_t)w * tk.lda;
+    const double* gB = tk.B + 2 * lane + (size_t)w * tk.ldb;
+    const int sOff = w * LDP + 2 * lane;
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ra[q] = *reinterpret_cast<const d2*>(gA + (size_t)(k0 + 4 * q) * tk.lda);
+            rb[q] = *reinterpret_cast<const d2*>(gB + (size_t)(k0 + 4 * q) * tk.ldb);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<d2*>(&sA[buf][sOff + 4 * q * LDP]) = ra[q];
+            *reinterpret_cast<d2*>(&sB[buf][sOff + 4 * q * LDP]) = rb[q];
+        }
+    };
+
+    const int nch = K / KC;
+    if (nch > 0) {
+        gload(0);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nch) gload((c + 1) * KC);
+        const double* pa = &sB[buf][l4 * LDP + wc * 64 + l15];   // MFMA A operand <- tile columns
+        const double* pb = &sA[buf][l4 * LDP + wr * 64 + l15];   // MFMA B operand <- tile rows
+#pragma unroll
+        for (int k4 = 0; k4 < KC / 4; ++k4) {
+            double fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = pa[k4 * 4 * LDP + 16 * i];
+                fb[i] = pb[k4 * 4 * LDP + 16 * i];
+            }
+#pragma unroll
+            for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+                for (int rn = 0; rn < 4; ++rn)
+                    acc[cm][rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cm], fb[rn], acc[cm][rn], 0, 0, 0);
+        }
+        if (c + 1 < nch) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: register r of acc[cm][rn] is C(row = wr*64+16rn+l15, col = wc*64+16cm+l4+4r)
+#pragma unroll
+    for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* pc = tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc;
+                if (UPDATE) *pc = *pc - acc[cm][rn][r];
+                else *pc = acc[cm][rn][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal block: in-LDS Cholesky of one 128x128 tile + its triangular inverse (used by the panel
+// solves as a GEMM).  One workgroup per leaf and step.  potrf semantics of src/gaussianprocess.jl:101:
+// lower factor; info = first non-positive pivot (1-based, global index), like LAPACK.
+struct DiagTask {
+    double* T;        // diagonal tile of F
+    double* Dinv;     // 128x128 output, ld 128
+    int* info;
+    int ld;
+    int nvalid;       // valid rows in this tile
+    int row0;         // global index of the tile's first row
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restrict__ tasks) {
+    extern __shared__ __attribute__((aligned(16))) double S[];   // [128][129], S[r*129 + c]
+    __shared__ double tmp[TB];
+    __shared__ int bad;
+    constexpr int LS = TB + 1;
+    const DiagTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x;
+    if (t == 0) bad = 0;
+    for (int e = t; e < TB * TB; e += 256) {
+        const int r = e % TB, c = e / TB;
+        S[r * LS + c] = (c <= r) ? tk.T[r + (size_t)c * tk.ld] : 0.0;
+    }
+    __syncthreads();
+    // right-looking Cholesky, column by column
+    for (int j = 0; j < TB; ++j) {
+        const double d = S[j * LS + j];
+        if (t == 0 && !(d > 0.0) && bad == 0) bad = j + 1;
+        const double sd = sqrt(d);
+        __syncthreads();
+        if (t < TB) {
+            if (t == j) S[j * LS + j] = sd;
+            else if (t > j) S[t * LS + j] = S[t * LS + j] / sd;
+        }
+        __syncthreads();
+        const int m = TB - 1 - j;
+        // element (i, c), j < c <= i: row-major pairs spread over the 256 threads
+        for (int e = t; e < m * m; e += 256) {
+            const int i = j + 1 + e / m, c = j + 1 + e % m;
+            if (c <= i) S[i * LS + c] -= S[i * LS + j] * S[c * LS + j];
+        }
+        __syncthreads();
+    }
+    // write L back (strict upper of the tile zeroed)
+    for (int e = t; e < TB * TB; e += 256) {
+        const int r = e % TB, c = e / TB;
+        tk.T[r + (size_t)c * tk.ld] = S[r * LS + c];
+    }
+    if (t == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
+    __syncthreads();
+    // in-place inverse of the lower-triangular S (column sweep from the right)
+    for (int j = TB - 1; j >= 0; --j) {
+        if (t < TB) tmp[t] = (t > j) ? S[t * LS + j] : 0.0;
+        __syncthreads();
+        const double xjj = 1.0 / S[j * LS + j];
+        double v = 0.0;
+        if (t > j && t < TB) {
+            double s = 0.0;
+            for (int k = j + 1; k <= t; ++k) s = fma(S[t * LS + k], tmp[k], s);
+            v = -s * xjj;
+        }
+        __syncthreads();
+        if (t > j && t < TB) S[t * LS + j] = v;
+        if (t == j) S[j * LS + j] = xjj;
+        __syncthreads();
+    }
+    for (int e = t; e < TB * TB; e += 256) {
+        const int r = e % TB, c = e / TB;
+        tk.Dinv[r + (size_t)c * TB] = S[r * LS + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangular solves alpha = L^-T (L^-1 y) (src/gaussianprocess.jl:105) as block sweeps that reuse
+// the inverted diagonal blocks; one launch per block step, batched over leaves.
+struct SolveTask {
+    const double* T;     // off-diagonal tile (forward: L[i,k]; backward: L[k,j]); unused when self
+    const double* Dk;    // inverse of the diagonal block of this step
+    const double* vk;    // right-hand side block of this step (128)
+    double* out_k;       // self: solution block of this step
+    double* vi;          // other: block to update
+    int ldt;
+    int self;
+};
+
+__device__ inline void block_reduce_store(double partial, double* red, int t) {
+    // 256 threads: thread (r = t&127, h = t>>7) holds half sums; result for row r in red[r]
+    if (t >= TB) red[t - TB] = partial;
+    __syncthreads();
+    if (t < TB) red[t] += partial;
+    __syncthreads();
+}
+
+// forward: z_k = Dk * w_k ; w_i -= L[i,k] z_k
+__global__ __launch_bounds__(256) void solve_fwd_kernel(const SolveTask* __restrict__ tasks) {
+    __shared__ double vin[TB], z[TB], red[TB];
+    const SolveTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x, r = t & 127, h = t >> 7;
+    if (t < TB) vin[t] = tk.vk[t];
+    __syncthreads();
+    double s = 0.0;
+    for (int c = h * 64; c < h * 64 + 64; ++c)
+        if (c <= r) s = fma(tk.Dk[r + (size_t)c * TB], vin[c], s);
+    block_reduce_store(s, red, t);
+    if (t < TB) z[t] = red[t];
+    __syncthreads();
+    if (tk.self) {
+        if (t < TB) tk.out_k[t] = z[t];
+        return;
+    }
+    s = 0.0;
+    for (int c = h * 64; c < h * 64 + 64; ++c) s = fma(tk.T[r + (size_t)c * tk.ldt], z[c], s);
+    block_reduce_store(s, red, t);
+    if (t < TB) tk.vi[t] -= red[t];
+}
+
+// backward: a_k = Dk^T v_k ; v_j -= L[k,j]^T a_k
+__global__ __launch_bounds__(256) void solve_bwd_kernel(const SolveTask* __restrict__ tasks) {
+    __shared__ double vin[TB], a[TB];
+    const SolveTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < TB) vin[t] = tk.vk[t];
+    __syncthreads();
+    for (int c = w; c < TB; c += 4) {
+        double s = tk.Dk[lane + (size_t)c * TB] * vin[lane] + tk.Dk[lane + 64 + (size_t)c * TB] * vin[lane + 64];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) a[c] = s;
+    }
+    __syncthreads();
+    if (tk.self) {
+        if (t < TB) tk.out_k[t] = a[t];
+        return;
+    }
+    for (int c = w; c < TB; c += 4) {
+        double s = tk.T[lane + (size_t)c * tk.ldt] * a[lane] + tk.T[lane + 64 + (size_t)c * tk.ldt] * a[lane + 64];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) tk.vi[c] -= s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-leaf scalars and vectors
+struct LeafDev {
+    double* F;            // npad x npad factor (shared by COPY leaves)
+    double* Dinv;         // nb x 128 x 128
+    const double* Xg;     // gathered inputs, npad x D (ld = npad), zero padded
+    double* yc;           // y - mean, zero padded
+    double* w;            // work vector
+    double* z;            // L^-1 yc
+    double* alpha;        // L^-T z
+    int* info;
+    double mean;
+    int n, npad, nb, kid;
+    // prediction
+    double* Vt;           // ntpad x npad (ld = ntpad): K_tn, then K_tn L^-T
+    const double* Xtg;    // gathered test inputs, ntpad x D (ld = ntpad)
+    double* mu;           // ntpad
+    double* var;          // ntpad
+    int nt, ntpad;
+    int pad0, pad1;
+};
+
+// yc = y[obs] - mean, Xg = X[obs, :]; one workgroup per (leaf, 256-row slab)
+__global__ void gather_leaf_kernel(const LeafDev* __restrict__ leaves, const int64_t* __restrict__ obs_ptr,
+                                   const int64_t* __restrict__ obs_idx, const double* __restrict__ X,
+                                   const double* __restrict__ y, int64_t N, int D, int leaf0) {
+    const LeafDev lf = leaves[leaf0 + blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= lf.npad) return;
+    const bool valid = r < lf.n;
+    const int64_t g = valid ? obs_idx[obs_ptr[leaf0 + blockIdx.y] + r] : 0;
+    lf.yc[r] = valid ? y[g] - lf.mean : 0.0;
+    double* xg = const_cast<double*>(lf.Xg);
+    for (int d = 0; d < D; ++d) xg[r + (size_t)d * lf.npad] = valid ? X[g + (size_t)d * N] : 0.0;
+}
+
+__global__ void gather_test_kernel(const LeafDev* __restrict__ leaves, const int64_t* __restrict__ route_ptr,
+                                   const int64_t* __restrict__ route_idx, const double* __restrict__ Xt,
+                                   int64_t n_t, int D, int leaf0) {
+    const LeafDev lf = leaves[leaf0 + blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= lf.ntpad) return;
+    const bool valid = r < lf.nt;
+    const int64_t g = valid ? route_idx[route_ptr[leaf0 + blockIdx.y] + r] : 0;
+    double* xg = const_cast<double*>(lf.Xtg);
+    for (int d = 0; d < D; ++d) xg[r + (size_t)d * lf.ntpad] = valid ? Xt[g + (size_t)d * n_t] : 0.0;
+}
+
+// mll = -(y.alpha + 2 sum log L_ii + n log 2pi)/2   (src/gaussianprocess.jl:163)
+__global__ __launch_bounds__(256) void mll_kernel(const LeafDev* __restrict__ leaves, double* __restrict__ mll_out) {
+    __shared__ double red[256];
+    __shared__ double red2[256];
+    const LeafDev lf = leaves[blockIdx.x];
+    const int t = threadIdx.x;
+    double s = 0.0, ld = 0.0;
+    for (int i = t; i < lf.n; i += 256) {
+        s = fma(lf.yc[i], lf.alpha[i], s);
+        ld += log(lf.F[i + (size_t)i * lf.npad]);
+    }
+    red[t] = s;
+    red2[t] = ld;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            red[t] += red[t + o];
+            red2[t] += red2[t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double log2pi = 1.8378770664093454835606594728112;
+        mll_out[blockIdx.x] = -(red[0] + 2.0 * red2[0] + log2pi * (double)lf.n) / 2.0;
+    }
+}
+
+// w = yc (start of the forward sweep)
+__global__ void copy_vec_kernel(const LeafDev* __restrict__ leaves) {
+    const LeafDev lf = leaves[blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < lf.npad) lf.w[r] = lf.yc[r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// prediction helpers (src/gaussianprocess.jl:117-126), one workgroup per (leaf, 128-row test tile)
+struct PredTask {
+    int leaf;
+    int row0;
+};
+
+// mu = m + K_tn alpha, from the freshly assembled K_tn (before the in-place solve overwrites it)
+__global__ __launch_bounds__(256) void pred_mu_kernel(const LeafDev* __restrict__ leaves,
+                                                      const PredTask* __restrict__ tasks) {
+    __shared__ double red[TB];
+    const PredTask tk = tasks[blockIdx.x];
+    const LeafDev lf = leaves[tk.leaf];
+    const int t = threadIdx.x, r = t & 127, h = t >> 7;
+    const double* V = lf.Vt + tk.row0 + r;
+    double s = 0.0;
+    for (int c = h; c < lf.n; c += 2) s = fma(V[(size_t)c * lf.ntpad], lf.alpha[c], s);
+    block_reduce_store(s, red, t);
+    if (t < TB) lf.mu[tk.row0 + t] = lf.mean + red[t];
+}
+
+// var = k(x*,x*) + noise - sum_c V(t,c)^2
+__global__ __launch_bounds__(256) void pred_var_kernel(const LeafDev* __restrict__ leaves,
+                                                       const PredTask* __restrict__ tasks,
+                                                       const KParam* __restrict__ kp, int D) {
+    __shared__ double red[TB];
+    const PredTask tk = tasks[blockIdx.x];
+    const LeafDev lf = leaves[tk.leaf];
+    const KParam p = kp[lf.kid];
+    const int t = threadIdx.x, r = t & 127, h = t >> 7;
+    const double* V = lf.Vt + tk.row0 + r;
+    double s = 0.0;
+    for (int c = h; c < lf.n; c += 2) {
+        const double v = V[(size_t)c * lf.ntpad];
+        s = fma(v, v, s);
+    }
+    block_reduce_store(s, red, t);
+    if (t < TB) {
+        double kss;
+        if (p.kind == 0) kss = p.sigma2;
+        else if (p.kind == 1) kss = p.sigma2 * (double)D;
+        else {
+            double q = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double x = lf.Xtg[tk.row0 + t + (size_t)d * lf.ntpad];
+                q = fma(x, x, q);
+            }
+            kss = q / p.l2[0];
+        }
+        lf.var[tk.row0 + t] = (kss - red[t]) + p.noise;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f64 MFMA issue-rate probe: register-only chains, 4 independent accumulators per wave
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, int iters) {
+    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+
+}  // namespace dsmgp

@@ -1,0 +1,107 @@
+"""Leaf sharding across ranks (one process per GPU) and the only exchange step of the path.
+
+Leaves are independent units (`src/fit.jl:88-119` touches one leaf and at most its "main" leaf), so
+each rank factorises and predicts its own leaves; what is exchanged is small: per-leaf log-marginals
+after fit and per-(leaf, routed test row) predictive moments after predict, by an all-gather
+(RCCL over xGMI when the process group is `nccl`, gloo on CPU in the tests).  The sum/product
+aggregation then runs redundantly on every rank.
+"""
+import numpy as np
+
+
+def _pg():
+    try:
+        import torch.distributed as td
+    except Exception:
+        return None
+    return td if td.is_available() and td.is_initialized() else None
+
+
+class Shard:
+    """Owner rank of every leaf + gather helpers."""
+
+    def __init__(self, owner, rank, world):
+        self.owner = np.asarray(owner, dtype=np.int64)
+        self.rank = int(rank)
+        self.world = int(world)
+        self.local = np.flatnonzero(self.owner == self.rank)
+
+    @staticmethod
+    def single(L):
+        return Shard(np.zeros(L, dtype=np.int64), 0, 1)
+
+    @staticmethod
+    def lpt(nobs, op, src, rank, world, n_test=None):
+        """Longest-processing-time greedy on cost n^3/3 + n^2 * n_t,leaf; COPY/PREFIX leaves follow
+        their source so shared factors stay on one GPU."""
+        nobs = np.asarray(nobs, dtype=np.float64)
+        L = nobs.size
+        nt = np.zeros(L) if n_test is None else np.asarray(n_test, dtype=np.float64)
+        cost = nobs ** 3 / 3.0 + nobs ** 2 * nt
+        group = np.arange(L)
+        for j in range(L):
+            if op[j] != 0 and src[j] >= 0:
+                group[j] = src[j]
+        for j in range(L):          # resolve one level of chaining
+            group[j] = group[group[j]]
+        gcost = np.zeros(L)
+        for j in range(L):
+            gcost[group[j]] += cost[j] if op[j] == 0 else 2.0 * nobs[j] ** 2
+        roots = [g for g in range(L) if group[g] == g]
+        roots.sort(key=lambda g: (-gcost[g], g))
+        load = np.zeros(world)
+        owner_of_root = {}
+        for g in roots:
+            r = int(np.argmin(load))
+            owner_of_root[g] = r
+            load[r] += gcost[g]
+        owner = np.array([owner_of_root[group[j]] for j in range(L)], dtype=np.int64)
+        return Shard(owner, rank, world)
+
+    # ---- exchange -------------------------------------------------------------------------------
+    def _all_gather_padded(self, local, maxlen):
+        """All-gather of one padded float64 vector per rank -> list of numpy arrays."""
+        import torch
+        td = _pg()
+        if td is None:
+            raise RuntimeError("sharded model needs an initialised torch.distributed process group")
+        backend = td.get_backend()
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        buf = torch.zeros(maxlen, dtype=torch.float64, device=dev)
+        buf[: local.size] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64)).to(dev)
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        td.all_gather(out, buf)
+        return [o.cpu().numpy() for o in out]
+
+    def gather_leaf_values(self, local_vals):
+        """local_vals[i] belongs to leaf self.local[i]; returns the value of every leaf."""
+        L = self.owner.size
+        local_vals = np.asarray(local_vals, dtype=np.float64)
+        if self.world == 1:
+            return local_vals.copy()
+        counts = np.bincount(self.owner, minlength=self.world)
+        parts = self._all_gather_padded(local_vals, int(counts.max()))
+        out = np.empty(L)
+        for r in range(self.world):
+            idx = np.flatnonzero(self.owner == r)
+            out[idx] = parts[r][: idx.size]
+        return out
+
+    def gather_ragged(self, local_flat, counts):
+        """local_flat = concatenation over this rank's leaves (in leaf order) of counts[leaf] values;
+        returns the concatenation over ALL leaves in leaf order."""
+        counts = np.asarray(counts, dtype=np.int64)
+        local_flat = np.asarray(local_flat, dtype=np.float64)
+        if self.world == 1:
+            return local_flat.copy()
+        per_rank = np.array([counts[self.owner == r].sum() for r in range(self.world)])
+        parts = self._all_gather_padded(local_flat, int(per_rank.max()))
+        ptr = np.concatenate([[0], np.cumsum(counts)])
+        out = np.empty(int(ptr[-1]))
+        for r in range(self.world):
+            pos = 0
+            for g in np.flatnonzero(self.owner == r):
+                c = int(counts[g])
+                out[ptr[g]:ptr[g] + c] = parts[r][pos:pos + c]
+                pos += c
+        return out

@@ -1,0 +1,229 @@
+"""ctypes binding of the C ABI in include/dsmgp_hip.h (the same symbols Julia would `ccall`).
+
+The GP-expert path has no CPU fallback: `Context()` raises when the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
+
+N_TIMINGS = 13
+TIMING_NAMES = ("gram", "chol_update", "chol_diag", "chol_trsm", "solve", "mll", "predict_gram",
+                "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_ctx = C.c_void_p
+
+# every symbol include/dsmgp_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "dsmgp_create": (C.c_int, [C.c_int32, C.POINTER(_ctx)]),
+    "dsmgp_destroy": (C.c_int, [_ctx]),
+    "dsmgp_last_error": (C.c_char_p, [_ctx]),
+    "dsmgp_device_name": (C.c_int, [_ctx, C.c_char_p, C.c_int32]),
+    "dsmgp_set_train": (C.c_int, [_ctx, _dp, _dp, C.c_int64, C.c_int32]),
+    "dsmgp_set_leaves": (C.c_int, [_ctx, C.c_int32, _lp, _lp, _ip, _dp]),
+    "dsmgp_set_sharing": (C.c_int, [_ctx, _ip, _ip, _lp]),
+    "dsmgp_set_hyper": (C.c_int, [_ctx, C.c_int32, C.c_int32, _dp, C.c_int32]),
+    "dsmgp_fit": (C.c_int, [_ctx, _dp, _ip, _dp]),
+    "dsmgp_set_test": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp]),
+    "dsmgp_predict_run": (C.c_int, [_ctx, _dp]),
+    "dsmgp_predict_fetch": (C.c_int, [_ctx, _dp, _dp]),
+    "dsmgp_predict_leaves": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp, _dp, _dp]),
+    "dsmgp_gradients": (C.c_int, [_ctx, _dp, C.c_int32]),
+    "dsmgp_kernel_matrix": (C.c_int, [_ctx, C.c_int32, _dp, C.c_int64, _dp, C.c_int64, _dp]),
+    "dsmgp_download_factor": (C.c_int, [_ctx, C.c_int32, _dp, _dp]),
+    "dsmgp_set_profile": (C.c_int, [_ctx, C.c_int32]),
+    "dsmgp_timings": (C.c_int, [_ctx, _dp]),
+    "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
+    "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
+    "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
+}
+
+_lib = None
+
+
+class DsmgpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dsmgp error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """dlopen libdsmgp_hip.so and attach prototypes; raises if the extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with deepstructuredmixtures_amd/csrc/build.sh "
+                           "(there is no CPU fallback for the GP-expert path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _f64_fortran(a):
+    a = np.asfortranarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(_lp)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+class Context:
+    """One GPU context (dsmgp_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = _ctx()
+        rc = self.lib.dsmgp_create(int(device), C.byref(self.h))
+        if rc != 0:
+            msg = self.lib.dsmgp_last_error(None).decode()
+            self.h = None
+            raise DsmgpError(rc, msg)
+        self.L = 0
+        self.D = 0
+        self.route_total = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DsmgpError(rc, self.lib.dsmgp_last_error(self.h).decode())
+
+    def close(self):
+        if self.h is not None:
+            self.lib.dsmgp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._chk(self.lib.dsmgp_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def set_train(self, X, y):
+        X, px = _f64_fortran(X)
+        y, py = _f64(y)
+        assert X.ndim == 2 and y.shape == (X.shape[0],)
+        self._chk(self.lib.dsmgp_set_train(self.h, px, py, X.shape[0], X.shape[1]))
+        self.D = X.shape[1]
+
+    def set_leaves(self, obs_ptr, obs_idx, kernel_id, mean):
+        obs_ptr, p0 = _i64(obs_ptr)
+        obs_idx, p1 = _i64(obs_idx)
+        kernel_id, p2 = _i32(kernel_id)
+        mean, p3 = _f64(mean)
+        L = len(obs_ptr) - 1
+        self._chk(self.lib.dsmgp_set_leaves(self.h, L, p0, p1, p2, p3))
+        self.L = L
+
+    def set_sharing(self, op, src, plen):
+        if op is None:
+            self._chk(self.lib.dsmgp_set_sharing(self.h, None, None, None))
+            return
+        op, p0 = _i32(op)
+        src, p1 = _i32(src)
+        plen, p2 = _i64(plen)
+        self._chk(self.lib.dsmgp_set_sharing(self.h, p0, p1, p2))
+
+    def set_hyper(self, kernel_id, kind, loghyp):
+        v, p = _f64(loghyp)
+        self._chk(self.lib.dsmgp_set_hyper(self.h, int(kernel_id), int(kind), p, len(v)))
+
+    def fit(self):
+        """Returns (mll[L], info[L], device_seconds)."""
+        mll = np.empty(self.L)
+        info = np.empty(self.L, dtype=np.int32)
+        sec = C.c_double(0.0)
+        self._chk(self.lib.dsmgp_fit(self.h, mll.ctypes.data_as(_dp), info.ctypes.data_as(_ip), C.byref(sec)))
+        return mll, info, sec.value
+
+    def set_test(self, Xt, route_ptr, route_idx):
+        Xt, px = _f64_fortran(Xt)
+        route_ptr, p0 = _i64(route_ptr)
+        route_idx, p1 = _i64(route_idx)
+        self._chk(self.lib.dsmgp_set_test(self.h, px, Xt.shape[0], p0, p1))
+        self.route_total = int(route_ptr[-1])
+
+    def predict_run(self):
+        sec = C.c_double(0.0)
+        self._chk(self.lib.dsmgp_predict_run(self.h, C.byref(sec)))
+        return sec.value
+
+    def predict_fetch(self):
+        mu = np.empty(self.route_total)
+        var = np.empty(self.route_total)
+        self._chk(self.lib.dsmgp_predict_fetch(self.h, mu.ctypes.data_as(_dp), var.ctypes.data_as(_dp)))
+        return mu, var
+
+    def predict_leaves(self, Xt, route_ptr, route_idx):
+        self.set_test(Xt, route_ptr, route_idx)
+        self.predict_run()
+        return self.predict_fetch()
+
+    def gradients(self, stride):
+        g = np.zeros((self.L, stride))
+        self._chk(self.lib.dsmgp_gradients(self.h, g.ctypes.data_as(_dp), int(stride)))
+        return g
+
+    def kernel_matrix(self, kernel_id, x1, x2):
+        x1, p1 = _f64_fortran(x1)
+        x2, p2 = _f64_fortran(x2)
+        K = np.empty((x1.shape[0], x2.shape[0]), order="F")
+        self._chk(self.lib.dsmgp_kernel_matrix(self.h, int(kernel_id), p1, x1.shape[0], p2, x2.shape[0],
+                                               K.ctypes.data_as(_dp)))
+        return K
+
+    def download_factor(self, leaf, n):
+        F = np.empty((n, n), order="F")
+        alpha = np.empty(n)
+        self._chk(self.lib.dsmgp_download_factor(self.h, int(leaf), F.ctypes.data_as(_dp), alpha.ctypes.data_as(_dp)))
+        return F, alpha
+
+    def set_profile(self, on):
+        self._chk(self.lib.dsmgp_set_profile(self.h, 1 if on else 0))
+
+    def timings(self):
+        t = np.zeros(N_TIMINGS)
+        self._chk(self.lib.dsmgp_timings(self.h, t.ctypes.data_as(_dp)))
+        return dict(zip(TIMING_NAMES, t.tolist()))
+
+    def work(self):
+        f = C.c_double(0.0)
+        n = C.c_int32(0)
+        self._chk(self.lib.dsmgp_work(self.h, C.byref(f), C.byref(n)))
+        return f.value, n.value
+
+    def memory(self):
+        a = C.c_int64(0)
+        b = C.c_int64(0)
+        self._chk(self.lib.dsmgp_memory(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def probe_f64_mfma(self):
+        t = C.c_double(0.0)
+        self._chk(self.lib.dsmgp_probe_f64_mfma(self.h, C.byref(t)))
+        return t.value

@@ -1,0 +1,530 @@
+"""Host-side mirror of the reference's model API over the HIP GP-expert path.
+
+Names and argument meaning follow the Julia package (`!` dropped): buildDSMGP / buildPoE / buildBCM
+(`src/treeStructure.jl:328-403`), fit / fit_naive (`src/fit.jl:67-122,294-304`), predict
+(`src/common.jl:294-307`), update / infer / mll (`src/common.jl:323-355`, `src/optimize.jl:18-25`),
+setparams / getparams (`src/optimize.jl:185-198`), train (`src/optimisers.jl:4-87`).
+
+All per-leaf numerics (Gram, Cholesky, alpha, mll, predictive moments, gradients) are computed by
+libdsmgp_hip.so through `hipabi.Context`; this module only holds the tree logic the reference keeps in
+scalar Julia code (routing, log-domain mixture aggregation, weights), plus leaf sharding across ranks.
+"""
+import numpy as np
+
+from . import hipabi
+from .kernels import IsoSE, ConstMean, KIND_ISO_SE, KIND_ARD_SE, KIND_ISO_LINEAR
+from .tree import (DSMGPConfig, build_tree, get_leaves, get_overlap, share_schedule, route, route_all,
+                   get_child, ordered_nodes, SHARE_COPY, SHARE_FULL, SHARE_PREFIX)
+from . import dist as _dist
+
+EPS = 1e-8  # `const ϵ` of src/DeepStructuredMixtures.jl:27
+
+
+def _logsumexp(a, axis=None):
+    """StatsFuns.logsumexp / `lse` (`src/common.jl:309-313`): max-shifted."""
+    a = np.asarray(a, dtype=np.float64)
+    if axis is None:
+        m = np.max(a)
+        m = m if np.isfinite(m) else 0.0
+        return float(np.log(np.sum(np.exp(a - m))) + m)
+    m = np.max(a, axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0)
+    return np.squeeze(np.log(np.sum(np.exp(a - m), axis=axis, keepdims=True)) + m, axis=axis)
+
+
+class Model:
+    """Common state of DSMGP / PoE / gPoE / rBCM (`src/DeepStructuredMixtures.jl:108-130`)."""
+    family = "dsmgp"
+
+    def __init__(self, root, x, y, overlap, ctx=None, device=0, shard=None):
+        self.root = root
+        self.x = np.asfortranarray(x, dtype=np.float64)
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+        self.D = overlap  # leaf-overlap matrix (the reference calls this field D)
+        self.leaves = get_leaves(root)
+        self.L = len(self.leaves)
+        self.shard = shard if shard is not None else _dist.Shard.single(self.L)
+        self._ctx = ctx
+        self._device = device
+        self.leaf_mll = np.full(self.L, np.nan)
+        self.leaf_info = np.zeros(self.L, dtype=np.int32)
+        self.last_fit_seconds = 0.0
+        self.last_predict_seconds = 0.0
+        self._uploaded = False
+        self._schedule = None
+        self._test_key = None
+
+    @property
+    def ctx(self):
+        """GPU context, created on first use; raises if the HIP library or a GPU is missing."""
+        if self._ctx is None:
+            self._ctx = hipabi.Context(self._device)
+        return self._ctx
+
+    # ---- kernel ids -> shared hyper-parameters --------------------------------------------------
+    def kernel_table(self):
+        """One (kernel, logNoise) per kernel id, taken from the first leaf carrying that id: the
+        reference sets every leaf of an id to the same vector (`src/optimize.jl:188-198`)."""
+        tab = {}
+        for lf in self.leaves:
+            tab.setdefault(lf.kernelid, lf)
+        return [tab[k] for k in sorted(tab)]
+
+    def _push_hyper(self):
+        for lf in self.kernel_table():
+            hyp = np.concatenate([lf.kernel.loghyp(), [lf.logNoise]])
+            self.ctx.set_hyper(lf.kernelid, lf.kernel.kind, hyp)
+
+    # ---- leaf table ------------------------------------------------------------------------------
+    def _upload(self, tau):
+        loc = self.shard.local
+        key = ("sched", None if tau is None else float(tau))
+        if self._uploaded and self._schedule == key:
+            return
+        if not self._uploaded:
+            self.ctx.set_train(self.x, self.y)
+        lv = [self.leaves[i] for i in loc]
+        ptr = np.zeros(len(lv) + 1, dtype=np.int64)
+        for i, lf in enumerate(lv):
+            ptr[i + 1] = ptr[i] + lf.nobs
+        idx = np.concatenate([lf.obs for lf in lv]) if lv else np.zeros(0, np.int64)
+        self.ctx.set_leaves(ptr, idx, [lf.kernelid for lf in lv], [lf.mean.m for lf in lv])
+        if self.D is not None and tau is not None:
+            op, src, plen = share_schedule(self.leaves, self.D, tau)
+            g2l = {g: i for i, g in enumerate(loc)}
+            lop = np.zeros(len(lv), dtype=np.int32)
+            lsrc = np.full(len(lv), -1, dtype=np.int32)
+            lpl = np.zeros(len(lv), dtype=np.int64)
+            for i, g in enumerate(loc):
+                if op[g] != SHARE_FULL and int(src[g]) in g2l:   # source must live on the same rank
+                    lop[i], lsrc[i], lpl[i] = op[g], g2l[int(src[g])], plen[g]
+            self.share_op = op
+            self.ctx.set_sharing(lop, lsrc, lpl)
+        else:
+            self.ctx.set_sharing(None, None, None)
+        self._uploaded = True
+        self._schedule = key
+        self._test_key = None
+
+
+class DSMGP(Model):
+    family = "dsmgp"
+
+
+class PoE(Model):
+    family = "poe"
+
+
+class gPoE(Model):
+    family = "gpoe"
+
+
+class rBCM(Model):
+    family = "rbcm"
+
+
+# ------------------------------------------------------------------------------------ builders
+
+def build(x, y, K, V, eps, M, D, kernel, meanFun, logNoise, useSum, *, seed=7, device=0, ctx=None,
+          cls=DSMGP, tau=0.05, fit_now=True, shard_world=None):
+    """`src/treeStructure.jl:405-437`. NOTE the reference swaps its positional K/V into the config:
+    config.K (splits per split node) = V argument, config.V (children per sum node) = K argument."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    config = DSMGPConfig(meanFun, kernel, logNoise, M, V, K, D, eps, useSum)
+    root = build_tree(x, np.asarray(y, dtype=np.float64), config, seed=seed)
+    L = len(get_leaves(root))
+    overlap = get_overlap(root, L)
+    model = cls(root, x, y, overlap, ctx=ctx, device=device)
+    if shard_world is not None:
+        rank, world = shard_world
+        op, src, _ = share_schedule(model.leaves, overlap, tau)
+        model.shard = _dist.Shard.lpt([lf.nobs for lf in model.leaves], op, src, rank, world)
+    if fit_now:
+        fit(model, tau=tau)
+    return model
+
+
+def buildDSMGP(x, y, K, V, *, eps=0.5, M=30, D=2, kernel=None, meanFun=None, logNoise=1.0, sum=True, **kw):
+    """buildDSMGP(x, y, K, V): K children under each sum node, V splits per split node
+    (`src/treeStructure.jl:309-339`; README.md:51 calls it as buildDSMGP(x, y, 3, 4))."""
+    kernel = IsoSE(1.0, 1.0) if kernel is None else kernel
+    return build(x, y, K, V, eps, M, D, kernel, meanFun, logNoise, sum, cls=DSMGP, **kw)
+
+
+def buildPoE(x, y, V, *, eps=0.0, M=30, D=2, kernel=None, meanFun, logNoise=1.0, generalized=False, **kw):
+    """`src/treeStructure.jl:341-371` (meanFun is a required keyword there too)."""
+    kernel = IsoSE(1.0, 1.0) if kernel is None else kernel
+    return build(x, y, 1, V, eps, M, D, kernel, meanFun, logNoise, False, cls=gPoE if generalized else PoE, **kw)
+
+
+def buildBCM(x, y, V, *, eps=0.0, M=30, D=2, kernel=None, meanFun=None, logNoise=1.0, robust=False, **kw):
+    """`src/treeStructure.jl:373-403`: always the robust BCM."""
+    kernel = IsoSE(1.0, 1.0) if kernel is None else kernel
+    return build(x, y, 1, V, eps, M, D, kernel, meanFun, logNoise, False, cls=rBCM, **kw)
+
+
+class GaussianProcess:
+    """Single exact GP (`src/gaussianprocess.jl:14-80`) as a one-leaf table on the device."""
+
+    def __init__(self, x, y, *, mean=None, kernel=None, logNoise=np.log(7.0), run_cholesky=False, device=0, ctx=None):
+        from .tree import GPNode
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        y = np.asarray(y, dtype=np.float64)
+        mean = ConstMean(float(np.mean(y))) if mean is None else mean
+        kernel = IsoSE(0.0, 0.0) if kernel is None else kernel
+        N, D = x.shape
+        leaf = GPNode(np.arange(N), np.full(D, -np.inf), np.full(D, np.inf), kernel, 0, mean, logNoise)
+        leaf.leaf = 0
+        self.node = leaf
+        self.model = Model(leaf, x, y, None, ctx=ctx, device=device)
+        self.N, self.D = N, D
+        if run_cholesky:
+            update_cholesky(self)
+
+    @property
+    def kernel(self):
+        return self.node.kernel
+
+    @property
+    def logNoise(self):
+        return self.node.logNoise
+
+
+def update_cholesky(gp):
+    """`update_cholesky!(gp)` (`src/gaussianprocess.jl:82-108`)."""
+    fit_naive(gp.model)
+    return gp
+
+
+def prediction(gp, xtest):
+    """`prediction(gp, xtest)` -> (mu, diag of Sigma) (`src/gaussianprocess.jl:110-137`; only the
+    diagonal of Sigma is ever consumed, `src/common.jl:136,147`)."""
+    xt = np.asarray(xtest, dtype=np.float64)
+    if xt.ndim == 1:
+        xt = xt.reshape(-1, 1)
+    n = xt.shape[0]
+    mu, var = gp.model.ctx.predict_leaves(xt, np.array([0, n]), np.arange(n))
+    return mu, var
+
+
+# ------------------------------------------------------------------------------------ fit
+
+def _fit(model, tau):
+    model._upload(tau)
+    model._push_hyper()
+    mll_loc, info_loc, sec = model.ctx.fit()
+    model.leaf_mll = model.shard.gather_leaf_values(mll_loc)
+    model.leaf_info = model.shard.gather_leaf_values(info_loc.astype(np.float64)).astype(np.int32)
+    model.last_fit_seconds = sec
+    bad = np.flatnonzero(model.leaf_info != 0)
+    if bad.size:
+        raise np.linalg.LinAlgError(f"leaf {int(bad[0])}: leading minor of order {int(model.leaf_info[bad[0]])} "
+                                    "is not positive definite")
+    return sec
+
+
+def fit(model, tau=0.05):
+    """`fit!(model; τ)`: shared-Cholesky fit (copy + prefix sharing). Returns seconds."""
+    target = model.model if isinstance(model, GaussianProcess) else model
+    return _fit(target, tau)
+
+
+def fit_naive(model):
+    """`fit_naive!`: one full factorisation per leaf (`src/fit.jl:294-304`)."""
+    target = model.model if isinstance(model, GaussianProcess) else model
+    return _fit(target, None)
+
+
+# ------------------------------------------------------------------------------------ mll / weights
+
+def mll(model):
+    """Tree log marginal likelihood (`src/optimize.jl:18-25`)."""
+    if isinstance(model, GaussianProcess):
+        return float(model.model.leaf_mll[0])
+
+    def rec(node):
+        if node.kind == "gp":
+            return float(model.leaf_mll[node.leaf])
+        if node.kind == "split":
+            return sum(rec(c) for c in node.children)
+        K = len(node.children)
+        return float(_logsumexp(np.array([-np.log(K) + rec(c) for c in node.children])))
+
+    return rec(model.root)
+
+
+def mll_table(model):
+    """`mll!(spn, L)`: value per node id (`src/optimize.jl:27-39`)."""
+    tab = {}
+
+    def rec(node):
+        if node.kind == "gp":
+            v = float(model.leaf_mll[node.leaf])
+        elif node.kind == "split":
+            v = sum(rec(c) for c in node.children)
+        else:
+            K = len(node.children)
+            v = float(_logsumexp(np.array([-np.log(K) + rec(c) for c in node.children])))
+        tab[node.id] = v
+        return v
+
+    rec(model.root)
+    return tab
+
+
+def update(model):
+    """`update!(model)`: posterior sum-node weights (`src/common.jl:323-334`). Returns the root value."""
+
+    def rec(node):
+        if node.kind == "gp":
+            return float(model.leaf_mll[node.leaf])
+        if node.kind == "split":
+            return sum(rec(c) for c in node.children)
+        K = len(node.children)
+        lw = np.array([-np.log(K) + rec(c) for c in node.children])
+        z = float(_logsumexp(lw))
+        node.logweights = lw - z
+        return z
+
+    return rec(model.root)
+
+
+def infer(model):
+    """`infer!(model)` (`src/common.jl:336-355`): only sums over GPs keep posterior weights."""
+
+    def rec(node):
+        if node.kind == "gp":
+            return float(model.leaf_mll[node.leaf])
+        if node.kind == "split":
+            return sum(rec(c) for c in node.children)
+        K = len(node.children)
+        lw = np.array([-np.log(K) + rec(c) for c in node.children])
+        z = float(_logsumexp(lw))
+        node.logweights = (lw - z) if node.of_gps else np.full(K, -np.log(K))
+        return z
+
+    return rec(model.root)
+
+
+def reset_weights(model):
+    """`reset_weights!` (`src/common.jl:357-363`)."""
+    for n in ordered_nodes(model.root):
+        if n.kind == "sum":
+            n.logweights = np.full(len(n.children), -np.log(len(n.children)))
+
+
+# ------------------------------------------------------------------------------------ parameters
+
+def getparams(model):
+    """Concatenated log-scale hyper-vector per kernel id: [logl..., logs, logNoise]."""
+    return np.concatenate([np.concatenate([lf.kernel.loghyp(), [lf.logNoise]]) for lf in model.kernel_table()])
+
+
+def setparams(model, hyp):
+    """`setparams!(spn, hyp)` (`src/optimize.jl:188-198`, `src/gaussianprocess.jl:153-161`)."""
+    hyp = np.asarray(hyp, dtype=np.float64)
+    tab = model.kernel_table()
+    c = 0
+    chunks = {}
+    for lf in tab:
+        n = lf.kernel.nparams() + 1
+        chunks[lf.kernelid] = hyp[c:c + n]
+        c += n
+    if c != hyp.size:
+        raise ValueError(f"hyper-vector has {hyp.size} entries, model needs {c}")
+    for lf in model.leaves:
+        h = chunks[lf.kernelid]
+        lf.logNoise = float(h[-1])
+        lf.kernel.set_loghyp(h[:-1])
+
+
+# ------------------------------------------------------------------------------------ predict
+
+def _leaf_moments(model, xt, ptr, idx):
+    """(mu, var) per (leaf, routed row) for ALL leaves, computed on the owning ranks."""
+    loc = model.shard.local
+    lptr = np.zeros(len(loc) + 1, dtype=np.int64)
+    parts = []
+    for i, g in enumerate(loc):
+        seg = idx[ptr[g]:ptr[g + 1]]
+        parts.append(seg)
+        lptr[i + 1] = lptr[i] + seg.size
+    lidx = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+    key = (xt.shape, hash(xt.tobytes()) if xt.size < 1 << 16 else id(xt), int(lptr[-1]))
+    if model._test_key != key:
+        model.ctx.set_test(xt, lptr, lidx)
+        model._test_key = key
+    model.last_predict_seconds = model.ctx.predict_run()
+    mu_l, var_l = model.ctx.predict_fetch()
+    counts = np.diff(ptr)
+    mu = model.shard.gather_ragged(mu_l, counts)
+    var = model.shard.gather_ragged(var_l, counts)
+    return mu, var
+
+
+def predict(model, xtest):
+    """`predict(model, x)` -> (mu, var) of length n_t (`src/common.jl:294-307`)."""
+    if isinstance(model, GaussianProcess):
+        mu, var = prediction(model, xtest)
+        var = np.where(var <= 0, EPS, var)
+        return mu, var
+    xt = np.asfortranarray(xtest, dtype=np.float64)
+    if xt.ndim == 1:
+        xt = xt.reshape(-1, 1)
+    n_t = xt.shape[0]
+    if model.family == "dsmgp":
+        ptr, idx = route(model.root, xt)
+    else:
+        ptr, idx = route_all(model.root, n_t)
+    mu, var = _leaf_moments(model, xt, ptr, idx)
+    if model.family == "dsmgp":
+        return _aggregate_dsmgp(model, xt, ptr, mu, var)
+    return _aggregate_poe(model, xt, ptr, mu, var)
+
+
+def _aggregate_dsmgp(model, xt, ptr, mu, var):
+    """Sum/product aggregation of the leaf moments exactly as `_minpredict` + `_predict`
+    (`src/common.jl:134-196,275-302`) do it, from ONE set of leaf predictions."""
+    n_t = xt.shape[0]
+    all_rows = np.arange(n_t, dtype=np.int64)
+
+    def leaf_vals(node):
+        a, b = ptr[node.leaf], ptr[node.leaf + 1]
+        return mu[a:b], var[a:b]
+
+    def minpred(node, rows):
+        if node.kind == "gp":
+            return leaf_vals(node)[0]
+        if node.kind == "split":
+            out = np.zeros(rows.size)
+            ch = get_child(node, xt[rows])
+            for k, c in enumerate(node.children):
+                sel = ch == k
+                out[sel] = minpred(c, rows[sel])
+            return out
+        out = np.full(rows.size, np.inf)
+        for c in node.children:
+            out = np.minimum(out, minpred(c, rows))
+        return out
+
+    def pred(node, rows, mmin):
+        if node.kind == "gp":
+            m, s2 = leaf_vals(node)
+            s2 = np.where(s2 <= 0, EPS, s2)  # src/common.jl:137
+            if not np.all(m >= mmin):
+                raise AssertionError("leaf mean below the shift (src/common.jl:138)")
+            with np.errstate(divide="ignore"):
+                return np.log(m - mmin), np.log(m * m), np.log(s2)
+        if node.kind == "split":
+            lm = np.zeros(rows.size)
+            lm2 = np.zeros(rows.size)
+            ls = np.zeros(rows.size)
+            ch = get_child(node, xt[rows])
+            for k, c in enumerate(node.children):
+                sel = ch == k
+                a, b, d = pred(c, rows[sel], mmin[sel])
+                lm[sel], lm2[sel], ls[sel] = a, b, d
+            return lm, lm2, ls
+        K = len(node.children)
+        lm = np.zeros((rows.size, K))
+        lm2 = np.zeros((rows.size, K))
+        ls = np.zeros((rows.size, K))
+        for k, c in enumerate(node.children):
+            a, b, d = pred(c, rows, mmin)
+            lm[:, k] = a + node.logweights[k]
+            lm2[:, k] = b + node.logweights[k]
+            ls[:, k] = d + node.logweights[k]
+        return _logsumexp(lm, axis=1), _logsumexp(lm2, axis=1), _logsumexp(ls, axis=1)
+
+    def predict_node(node, rows):
+        if node.kind == "gp":                    # src/common.jl:175-179
+            m, s2 = leaf_vals(node)
+            return m, np.where(s2 <= 0, EPS, s2)
+        if node.kind == "split":                 # src/common.jl:243-254
+            m = np.zeros(rows.size)
+            v = np.zeros(rows.size)
+            ch = get_child(node, xt[rows])
+            for k, c in enumerate(node.children):
+                sel = ch == k
+                m[sel], v[sel] = predict_node(c, rows[sel])
+            return m, v
+        mmin = minpred(node, rows)               # src/common.jl:294-302
+        lm, lm2, ls = pred(node, rows, mmin - 1.0)
+        m = np.exp(lm) + mmin - 1.0
+        return m, np.exp(ls) + (np.exp(lm2) - m * m)
+
+    return predict_node(model.root, all_rows)
+
+
+def _prior_diag(lf, xt):
+    k = lf.kernel
+    if k.kind == KIND_ISO_SE:
+        return np.full(xt.shape[0], np.exp(2 * k.logs))
+    if k.kind == KIND_ARD_SE:
+        return np.full(xt.shape[0], np.exp(2 * k.logs) * xt.shape[1])
+    return np.sum(xt * xt, axis=1) / np.exp(k.logl) ** 2
+
+
+def _aggregate_poe(model, xt, ptr, mu, var):
+    """PoE / gPoE / rBCM combination rules (`src/common.jl:145-149,198-273`)."""
+    n_t = xt.shape[0]
+
+    def poe(node):
+        if node.kind == "gp":
+            a, b = ptr[node.leaf], ptr[node.leaf + 1]
+            return mu[a:b], 1.0 / var[a:b]
+        m = np.zeros(n_t)
+        t = np.zeros(n_t)
+        for c in node.children:
+            m_, t_ = poe(c)
+            t += t_
+            m += t_ * m_
+        return m / t, t
+
+    root = model.root
+    if root.kind == "gp":
+        m, t = poe(root)
+        return m, 1.0 / t
+    if model.family == "poe":
+        m, t = poe(root)
+        return m, 1.0 / t
+    if model.family == "gpoe":
+        beta = 1.0 / len(root.children)
+        m = np.zeros(n_t)
+        t = np.zeros(n_t)
+        for c in root.children:
+            m_, t_ = poe(c)
+            t += beta * t_
+            m += beta * t_ * m_
+        return m / t, 1.0 / t
+    lf0 = get_leaves(root)[0]
+    s = _prior_diag(lf0, xt) + np.exp(2 * lf0.logNoise)
+    Cc = 1.0 / s
+    m = np.zeros(n_t)
+    for c in root.children:
+        m_, t_ = poe(c)
+        s_ = 1.0 / t_
+        beta = 0.5 * (np.log(s) - np.log(s_))
+        Cc = Cc + (beta * t_) - (beta / s)
+        m = m + m_ * (beta * t_)
+    return m / Cc, 1.0 / Cc
+
+
+# ------------------------------------------------------------------------------------ scores
+
+def mse(y_true, y_pred):
+    return float(np.mean((np.asarray(y_true) - np.asarray(y_pred)) ** 2))
+
+
+def mae(y_true, y_pred):
+    return float(np.mean(np.abs(np.asarray(y_true) - np.asarray(y_pred))))
+
+
+def nlpd(y_true, mu, var):
+    """`src/scorefunctions.jl:16`."""
+    y_true, mu, var = map(np.asarray, (y_true, mu, var))
+    return float(np.mean(0.5 * np.log(2 * np.pi * var) + 0.5 * (y_true - mu) ** 2 / var))

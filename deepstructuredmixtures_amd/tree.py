@@ -1,0 +1,350 @@
+"""Host-side sum-product tree: node types, random builder, leaf-overlap matrix, test-point routing.
+
+This is the caller side of the hot path: its output -- the leaf table
+(`obs` CSR, kernel ids, per-leaf means), the sharing schedule and the test-row routes -- is
+what crosses the C ABI.  Behaviour follows the reference's builder
+(`src/treeStructure.jl:4-307,405-437`), overlap (`src/fit.jl:12-39`), scheduler decisions
+(`src/fit.jl:71-122,208-292`) and routing (`src/common.jl:101-122`); indices are 0-based here.
+Random draws come from `datagen.Stream` (Julia's RNG stream cannot be reproduced).
+"""
+import itertools
+import numpy as np
+
+from .datagen import Stream
+from .kernels import ConstMean, KernelFunction
+
+_ids = itertools.count(1)
+
+
+def _gensym(tag):
+    return f"{tag}#{next(_ids)}"
+
+
+class GPNode:
+    """Leaf expert (`src/DeepStructuredMixtures.jl:61-71`). `leaf` = position in getLeaves order."""
+    kind = "gp"
+
+    def __init__(self, obs, lb, ub, kernel, kernelid, mean, logNoise):
+        self.id = _gensym("GP")
+        self.obs = np.asarray(obs, dtype=np.int64)  # ascending original row indices, 0-based
+        self.nobs = int(self.obs.size)
+        self.lb = lb
+        self.ub = ub
+        self.kernel = kernel
+        self.kernelid = int(kernelid)  # 0-based
+        self.mean = mean
+        self.logNoise = float(logNoise)
+        self.dnoise = 0.0
+        self.leaf = -1
+        self.children = []
+
+
+class GPSplitNode:
+    """Product node over axis-aligned regions (`src/DeepStructuredMixtures.jl:52-59`)."""
+    kind = "split"
+
+    def __init__(self, lowerBound, upperBound, split):
+        self.id = _gensym("split")
+        self.children = []
+        self.lowerBound = lowerBound
+        self.upperBound = upperBound
+        self.split = split  # list of (dim, threshold); the last threshold is upperBound[dim]
+
+
+class GPSumNode:
+    """Mixture node (`src/DeepStructuredMixtures.jl:40-45`); `of_gps` marks GPSumNode{GPNode}."""
+    kind = "sum"
+
+    def __init__(self, of_gps=False):
+        self.id = _gensym("sum")
+        self.children = []
+        self.logweights = np.zeros(0)
+        self.of_gps = of_gps
+
+    def add(self, child, logw):
+        self.children.append(child)
+        self.logweights = np.append(self.logweights, logw)
+
+
+class DSMGPConfig:
+    """`src/DeepStructuredMixtures.jl:91-101`; K = splits per split node, V = children per sum node."""
+
+    def __init__(self, meanFun, kernels, observationNoise, minData, K, V, depth, bnoise, sumRoot):
+        self.meanFun = meanFun
+        self.kernels = kernels
+        self.observationNoise = float(observationNoise)
+        self.minData = int(minData)
+        self.K = int(K)
+        self.V = int(V)
+        self.depth = int(depth)
+        self.bnoise = float(bnoise)
+        self.sumRoot = bool(sumRoot)
+
+
+def get_leaves(node):
+    """Leaves in depth-first child order (`src/fit.jl:9-10`)."""
+    if node.kind == "gp":
+        return [node]
+    out = []
+    for c in node.children:
+        out.extend(get_leaves(c))
+    return out
+
+
+def ordered_nodes(node):
+    out = []
+    for c in node.children:
+        out.extend(ordered_nodes(c))
+    out.append(node)
+    return out
+
+
+# ----------------------------------------------------------------------------- builder
+
+def _get_splits(xd, lower, upper, minData, eps, K, rng, depth=1):
+    """Cut positions on one dimension (`src/treeStructure.jl:23-129`).
+
+    `xd` is the column of the current region; `lower`/`upper` the bounds on that dimension.
+    K_ starts at depth^2, so K=4 gives 3 cuts and K=8 gives 7.
+    """
+    K_ = depth * depth
+    s = []
+    l = max(lower, float(xd.min()))
+    u = min(upper, float(xd.max()))
+    v = u - l
+    sel = xd[(xd > l) & (xd <= u)]
+    if sel.size > 2 * minData:
+        m = float(np.median(sel))
+        z1 = z2 = 0
+        c = 0
+        s_new = m
+        while z1 == 0 or z2 == 0:
+            a = rng.beta22() * v + l
+            s_new = float(eps * a + (1.0 - eps) * m)
+            z1 = int(np.count_nonzero(sel <= s_new))
+            z2 = sel.size - z1
+            c += 1
+            if c > 100:
+                return s
+        first_low = rng.randint(1, 2) == 1
+        order = ("low", "high") if first_low else ("high", "low")
+        for pos, side in enumerate(order):
+            z = z1 if side == "low" else z2
+            if z > minData and K_ < K:
+                if side == "low":
+                    s.extend(_get_splits(xd, lower, s_new, minData, eps, K, rng, depth + 1))
+                else:
+                    s.extend(_get_splits(xd, s_new, upper, minData, eps, K, rng, depth + 1))
+                if pos == 0:
+                    K_ += 1
+        s.append(s_new)
+    return s
+
+
+def _build_gp(X, y, lb, ub, config, observations):
+    """`src/treeStructure.jl:245-307`."""
+    ym = float(np.mean(y)) if y.size else 0.0
+    mfun = ConstMean(ym) if config.meanFun is None else config.meanFun
+    if isinstance(config.kernels, (list, tuple)):
+        w = config._rng.dirichlet1(len(config.kernels))
+        node = GPSumNode(of_gps=True)
+        for v, kern in enumerate(config.kernels):
+            node.add(GPNode(observations, lb, ub, kern.copy(), v, mfun, config.observationNoise), np.log(w[v]))
+        return node
+    return GPNode(observations, lb, ub, config.kernels.copy(), 0, mfun, config.observationNoise)
+
+
+def _build_split(X, y, lowerBound, upperBound, config, depth, observations, d=0):
+    """`src/treeStructure.jl:131-210`. Region membership is (lb, ub] on dimension d."""
+    rng = config._rng
+    xd = X[:, d]
+    s = sorted(_get_splits(xd, lowerBound[d], upperBound[d], config.minData, config.bnoise, config.K, rng))
+    if not s:
+        idx = np.flatnonzero((xd > lowerBound[d]) & (xd <= upperBound[d]))
+        return _build_gp(X[idx], y[idx], lowerBound.copy(), upperBound.copy(), config, observations[idx])
+    split = [(d, si) for si in s] + [(d, float(upperBound[d]))]
+    node = GPSplitNode(lowerBound, upperBound, split)
+    lb = lowerBound.copy()
+    ub = upperBound.copy()
+    for (_, si) in split:
+        lb_ = lb.copy()
+        ub_ = ub.copy()
+        ub_[d] = si
+        idx = np.flatnonzero((xd > lb_[d]) & (xd <= ub_[d]))
+        if depth < config.depth and idx.size > config.minData:
+            if config.sumRoot:
+                child = _build_sum(X[idx], y[idx], lb_, ub_, config, depth, observations[idx])
+            else:
+                child = _build_split(X[idx], y[idx], lb_, ub_, config, depth, observations[idx])
+        else:
+            child = _build_gp(X[idx], y[idx], lb_, ub_, config, observations[idx])
+        node.children.append(child)
+        lb[d] = si
+    return node
+
+
+def _build_sum(X, y, lowerBound, upperBound, config, depth, observations):
+    """`src/treeStructure.jl:212-243`: V children, each split on a dimension drawn ~ data range."""
+    V = config.V
+    node = GPSumNode()
+    phi = X.max(axis=0) - X.min(axis=0)
+    phi = phi / phi.sum() if phi.sum() > 0 else np.full(X.shape[1], 1.0 / X.shape[1])
+    for _ in range(V):
+        d = config._rng.categorical(phi)
+        node.add(_build_split(X, y, lowerBound, upperBound, config, depth + 1, observations, d=d), -np.log(V))
+    return node
+
+
+def build_tree(X, y, config, seed=7):
+    """`src/treeStructure.jl:4-21`."""
+    N, D = X.shape
+    assert N == y.shape[0] and np.all(np.isfinite(X))
+    config._rng = Stream(seed)
+    lb = np.full(D, -np.inf)
+    ub = np.full(D, np.inf)
+    obs = np.arange(N, dtype=np.int64)
+    if config.sumRoot:
+        root = _build_sum(X, y, lb, ub, config, 0, obs)
+    else:
+        root = _build_split(X, y, lb, ub, config, 0, obs)
+    for i, leaf in enumerate(get_leaves(root)):
+        leaf.leaf = i
+    return root
+
+
+# ----------------------------------------------------------------------------- overlap + schedule
+
+def get_overlap(root, L):
+    """Leaf-overlap matrix (`src/fit.jl:12-39`): D[n,m] = 1 - |n \\ m| / |n| for leaves under
+    different children of a common sum node, forced to 1 when kernel ids differ."""
+    Dm = np.zeros((L, L))
+
+    def rec(node):
+        if node.kind == "gp":
+            return [node]
+        if node.kind == "split":
+            out = []
+            for c in node.children:
+                out.extend(rec(c))
+            return out
+        r = [rec(c) for c in node.children]
+        for i in range(len(r)):
+            for j in range(i + 1, len(r)):
+                for nn in r[i]:
+                    for mm in r[j]:
+                        if nn.kernelid == mm.kernelid:
+                            common = np.intersect1d(nn.obs, mm.obs, assume_unique=True).size
+                            dn = nn.nobs - common
+                            dm = mm.nobs - common
+                        else:
+                            dn = dm = 0
+                        Dm[nn.leaf, mm.leaf] = 1.0 - dn / nn.nobs
+                        Dm[mm.leaf, nn.leaf] = 1.0 - dm / mm.nobs
+        out = []
+        for x in r:
+            out.extend(x)
+        return out
+
+    rec(root)
+    return Dm
+
+
+SHARE_FULL, SHARE_COPY, SHARE_PREFIX = 0, 1, 2
+
+
+def share_schedule(leaves, Dm, tau=0.05):
+    """Per-leaf factorisation decision of the shared-Cholesky `fit!` (`src/fit.jl:71-122`).
+
+    Returns (op, src, plen): op[j] in {FULL, COPY, PREFIX}; for COPY the factor of leaf src[j] is
+    reused as is (`src/fit.jl:132-143`); for PREFIX the leading plen[j] x plen[j] block is leaf
+    src[j]'s factor and the factorisation continues from column plen[j]
+    (`src/fit.jl:208-292` -> `src/AdvancedCholeskey.jl:152-174`).  The row-deletion (low-rank)
+    branches (`src/fit.jl:174-201,256-275` with a non-empty `toupdate`) are numerically defective
+    in the reference and map to FULL.  tau=0 disables sharing except COPY, as in the
+    reference (`src/fit.jl:256`: 0 < 0 is false).
+    """
+    L = len(leaves)
+    op = np.zeros(L, dtype=np.int32)
+    src = np.full(L, -1, dtype=np.int32)
+    plen = np.zeros(L, dtype=np.int64)
+    if L == 0:
+        return op, src, plen
+    main = np.empty(L, dtype=np.int64)
+    counts = np.zeros(L, dtype=np.int64)
+    for j in range(L):
+        i = int(np.argmax(Dm[:, j] * Dm[j, :]))
+        main[j] = i
+        counts[i] += 1
+    order = sorted(range(L), key=lambda j: counts[j])  # stable, like Julia's sort! on objects
+    processed = np.zeros(L, dtype=bool)
+    for j in order:
+        if processed[j]:
+            continue
+        i = int(main[j])
+        if not processed[i]:
+            processed[i] = True  # main leaf: full factorisation (`src/fit.jl:97-100`)
+        processed[j] = True
+        if i == j:
+            continue
+        lj, li = leaves[j], leaves[i]
+        if li.kernelid != lj.kernelid or lj.obs[0] < li.obs[0]:
+            continue
+        ione = Dm[i, j] == 1.0
+        jone = Dm[j, i] == 1.0
+        if ione and jone:
+            if op[i] == SHARE_FULL:
+                op[j], src[j] = SHARE_COPY, i
+            elif op[i] == SHARE_COPY:
+                op[j], src[j] = SHARE_COPY, src[i]
+        elif ione and not jone and tau > 0.0:
+            p = li.nobs
+            if lj.obs[0] == li.obs[0] and lj.nobs > p and np.array_equal(lj.obs[:p], li.obs) \
+                    and op[i] == SHARE_FULL:
+                op[j], src[j], plen[j] = SHARE_PREFIX, i, p
+    return op, src, plen
+
+
+# ----------------------------------------------------------------------------- routing
+
+def get_child(node, x):
+    """Child index per row (`src/common.jl:101-122`): first k with s_{k-1} < x[d] <= s_k."""
+    d = node.split[0][0]
+    th = np.array([s for (_, s) in node.split])
+    idx = np.searchsorted(th, x[:, d], side="left")
+    if np.any(idx >= len(th)):
+        raise ValueError("test point outside the region of a split node (reference loops forever here)")
+    return idx
+
+
+def route(root, xt):
+    """Which test rows each leaf is asked to predict: CSR (route_ptr, route_idx) in leaf order.
+
+    Sum nodes forward every row to every child, split nodes to exactly one child
+    (`src/common.jl:181-196,275-292`)."""
+    leaves = get_leaves(root)
+    rows = [None] * len(leaves)
+
+    def rec(node, idx):
+        if node.kind == "gp":
+            rows[node.leaf] = idx
+        elif node.kind == "sum":
+            for c in node.children:
+                rec(c, idx)
+        else:
+            ch = get_child(node, xt[idx])
+            for k, c in enumerate(node.children):
+                rec(c, idx[ch == k])
+
+    rec(root, np.arange(xt.shape[0], dtype=np.int64))
+    ptr = np.zeros(len(leaves) + 1, dtype=np.int64)
+    for i, r in enumerate(rows):
+        ptr[i + 1] = ptr[i] + (0 if r is None else r.size)
+    flat = np.concatenate([r for r in rows if r is not None]) if len(leaves) else np.zeros(0, np.int64)
+    return ptr, flat.astype(np.int64)
+
+
+def route_all(root, n_t):
+    """PoE-family routing: every expert predicts every test row (`src/common.jl:198-208`)."""
+    L = len(get_leaves(root))
+    ptr = np.arange(L + 1, dtype=np.int64) * n_t
+    return ptr, np.tile(np.arange(n_t, dtype=np.int64), L)

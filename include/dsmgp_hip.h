@@ -1,0 +1,126 @@
+/*
+ * dsmgp_hip.h -- C ABI of the MI355X (gfx950) GP-expert hot path of DeepStructuredMixtures.
+ *
+ * The reference (Julia) has no FFI of its own: the boundary is the set of Julia methods whose
+ * bodies are the hot path.  Each entry point below names the reference
+ * code it replaces; INTEGRATION.md shows the `ccall` glue a maintainer would add.
+ *
+ * Conventions
+ *   - all matrices are column-major Float64 (Julia `Matrix{Float64}`), indices 0-based, sizes int64/int32
+ *   - every function returns 0 on success, a negative DSMGP_E_* code on failure; the message is
+ *     available from dsmgp_last_error(); nothing throws or longjmps across the ABI
+ *   - the caller owns every host pointer; the library never keeps a host pointer after return
+ *   - a context is bound to ONE GPU and must not be used from two threads at once (the reference
+ *     `fit!` loop is serial, src/fit.jl:88); multi-GPU = one context per process/GPU, leaves sharded
+ *     by the caller
+ *   - hyper-parameters are on the reference's log scale: [logl..., logs, logNoise] with
+ *     lengthscale exp(logl), signal variance exp(2 logs), noise variance exp(2 logNoise)
+ *     (src/kernels.jl:68-73, src/gaussianprocess.jl:39,153-161)
+ */
+#ifndef DSMGP_HIP_H
+#define DSMGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsmgp_ctx dsmgp_ctx;
+
+/* kernel kinds (src/kernels.jl:59,109,174) */
+#define DSMGP_KIND_ISO_SE     0
+#define DSMGP_KIND_ARD_SE     1   /* additive form, src/kernels.jl:39-49 */
+#define DSMGP_KIND_ISO_LINEAR 2
+
+/* per-leaf sharing decisions of the shared-Cholesky fit! (src/fit.jl:107-117) */
+#define DSMGP_SHARE_FULL   0      /* update_cholesky!               src/gaussianprocess.jl:82-108 */
+#define DSMGP_SHARE_COPY   1      /* identical observation sets     src/fit.jl:132-143 */
+#define DSMGP_SHARE_PREFIX 2      /* chol_continue! from column p   src/fit.jl:276-278, src/AdvancedCholeskey.jl:152-174 */
+
+/* error codes */
+#define DSMGP_OK            0
+#define DSMGP_E_ARG        -1
+#define DSMGP_E_STATE      -2
+#define DSMGP_E_HIP        -3
+#define DSMGP_E_NOMEM      -4
+#define DSMGP_E_NODEVICE   -5
+
+/* number of doubles dsmgp_timings() fills: gram, chol_update, chol_diag, chol_trsm, solve, mll,
+ * predict_gram, predict_update, predict_trsm, predict_var, gradients, total_fit, total_predict */
+#define DSMGP_N_TIMINGS 13
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int dsmgp_create(int32_t device_id, dsmgp_ctx** out);
+int dsmgp_destroy(dsmgp_ctx* ctx);
+const char* dsmgp_last_error(dsmgp_ctx* ctx);     /* ctx may be NULL: error of the failed create */
+int dsmgp_device_name(dsmgp_ctx* ctx, char* buf, int32_t len);
+
+/* ---- data: replaces the GaussianProcess constructor's host copies
+ *      (src/gaussianprocess.jl:50-80: x, mean-subtracted y; the distance tensor P is never stored) */
+int dsmgp_set_train(dsmgp_ctx* ctx, const double* X /* N x D */, const double* y /* N */,
+                    int64_t N, int32_t D);
+
+/* leaf table = output of buildTree (src/treeStructure.jl:245-307): obs lists in CSR form
+ * (ascending 0-based row indices), kernel id (0-based), ConstMean value per leaf (src/means.jl:7-14) */
+int dsmgp_set_leaves(dsmgp_ctx* ctx, int32_t L, const int64_t* obs_ptr /* L+1 */,
+                     const int64_t* obs_idx, const int32_t* kernel_id, const double* mean /* L */);
+
+/* sharing schedule decided by the caller exactly as src/fit.jl:78-117 does; NULL op = all FULL.
+ * The library validates COPY/PREFIX claims against the obs lists and returns DSMGP_E_ARG on a lie. */
+int dsmgp_set_sharing(dsmgp_ctx* ctx, const int32_t* op /* L */, const int32_t* src /* L */,
+                      const int64_t* prefix_len /* L */);
+
+/* replaces setparams!(gp, hyper) (src/gaussianprocess.jl:153-161, src/optimize.jl:188-198) for all
+ * leaves of one kernel id; n = (#lengthscales) + 2 */
+int dsmgp_set_hyper(dsmgp_ctx* ctx, int32_t kernel_id, int32_t kind, const double* loghyp, int32_t n);
+
+/* ---- fit!: Gram assembly + Cholesky + alpha for every leaf
+ *      replaces fit!/fit_naive!/update_cholesky! (src/fit.jl:71-122,294-304; src/gaussianprocess.jl:82-108)
+ *      and mll(gp) (src/gaussianprocess.jl:163).
+ *      mll_out[l]  = -(y.alpha + logdet + n log 2pi)/2
+ *      info_out[l] = 0, or k>0 if the leading minor of order k is not positive definite (LAPACK potrf)
+ *      seconds     = device time of the call (hipEvents), like the @elapsed value fit! returns */
+int dsmgp_fit(dsmgp_ctx* ctx, double* mll_out /* L */, int32_t* info_out /* L */, double* seconds);
+
+/* ---- prediction(gp, xtest) for every (leaf, routed test row): src/gaussianprocess.jl:110-137
+ *      mu  = m + Knt' alpha ; var = k(x*,x*) - |L^-1 k_n*|^2 + exp(2 logNoise)   (diag only; no clamp,
+ *      the caller applies src/common.jl:137).  route_ptr/route_idx: per leaf, which rows of Xt.
+ *      Outputs are aligned with route_idx. */
+int dsmgp_set_test(dsmgp_ctx* ctx, const double* Xt /* n_t x D */, int64_t n_t,
+                   const int64_t* route_ptr /* L+1 */, const int64_t* route_idx);
+int dsmgp_predict_run(dsmgp_ctx* ctx, double* seconds);   /* device work only, inputs resident */
+int dsmgp_predict_fetch(dsmgp_ctx* ctx, double* mu_out, double* var_out);
+int dsmgp_predict_leaves(dsmgp_ctx* ctx, const double* Xt, int64_t n_t, const int64_t* route_ptr,
+                         const int64_t* route_idx, double* mu_out, double* var_out);
+
+/* ---- updategradients!(gp) + grad vector of src/gaussianprocess.jl:165-178,185-217 per leaf.
+ *      grad_out[l*stride + j], j over [dl..., ds, dnoise] (reference order, src/gaussianprocess.jl:212-214),
+ *      reproducing the reference's scaling and ArdSE dl == 0. */
+int dsmgp_gradients(dsmgp_ctx* ctx, double* grad_out, int32_t stride);
+
+/* ---- inspection ------------------------------------------------------------------------------- */
+/* kernelmatrix(kernel, x1, x2) (src/kernels.jl:15-18) through the same device code as the fit path */
+int dsmgp_kernel_matrix(dsmgp_ctx* ctx, int32_t kernel_id, const double* x1, int64_t n1,
+                        const double* x2, int64_t n2, double* K_out /* n1 x n2 */);
+/* gp.cK.factors (lower triangle = L, strict upper = 0) and gp.alpha of one leaf; either may be NULL */
+int dsmgp_download_factor(dsmgp_ctx* ctx, int32_t leaf, double* F /* n x n */, double* alpha /* n */);
+/* per-launch hipEvent timing of every kernel category (adds event records between launches);
+ * also switched on by the environment variable DSMGP_PROFILE=1 at dsmgp_create */
+int dsmgp_set_profile(dsmgp_ctx* ctx, int32_t on);
+int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the last fit/predict */);
+/* work of the dominant kernel (the f64-MFMA Cholesky update) in the last fit: algorithmic flops over
+ * all its launches (2*K per lower-triangle element of every block column, unpadded sizes) and the
+ * number of launches */
+int dsmgp_work(dsmgp_ctx* ctx, double* alg_flops_update, int32_t* n_update_launches);
+/* bytes of device memory the current leaf table needs / the device has free */
+int dsmgp_memory(dsmgp_ctx* ctx, int64_t* needed, int64_t* free_bytes);
+
+/* f64 MFMA issue-rate probe used for the roofline peak (bench.py): returns TFLOP/s of a register-only
+ * v_mfma_f64_16x16x4_f64 loop over the whole chip */
+int dsmgp_probe_f64_mfma(dsmgp_ctx* ctx, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,288 @@
+"""GPU suite: the HIP path, called through the C ABI (libdsmgp_hip.so), against the CPU oracle,
+the committed golden vectors and size-independent properties.  Float64 throughout; tolerances are
+stated per test (north star: predictive mean/variance within 1e-8 relative)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import deepstructuredmixtures_amd as dsm
+from deepstructuredmixtures_amd import hipabi, tree as ptree
+from deepstructuredmixtures_amd.datagen import uniform, normal, regression_data
+from oracle import gp as ogp, spn as ospn
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8   # north-star tolerance on predictive moments and log-marginals
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hipabi.Context(0)
+    yield c
+    c.close()
+
+
+def _cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "gp_small.npz"))
+    cases = {}
+    for key in z.files:
+        name, field = key.split("/")
+        cases.setdefault(name, {})[field] = z[key]
+    return cases
+
+
+def _single(ctx, X, y, mean, kind, loghyp, logNoise):
+    n = X.shape[0]
+    ctx.set_train(X, y)
+    ctx.set_leaves([0, n], np.arange(n), [0], [mean])
+    ctx.set_hyper(0, kind, np.concatenate([loghyp, [logNoise]]))
+    return ctx.fit()
+
+
+def test_native_library_is_loaded_and_sees_an_mi355x(ctx):
+    assert os.path.exists(hipabi.LIB_PATH)
+    name = ctx.device_name()
+    assert "gfx950" in name, name
+
+
+def test_mfma_f64_layout_exact_integers(ctx):
+    """A = I / asymmetric-B style check of the f64 MFMA operand and result maps: with small integer
+    data the blocked factorisation must reproduce an integer Cholesky factor EXACTLY."""
+    n = 256
+    rng = np.random.default_rng(5)
+    Lt = np.tril(rng.integers(-3, 4, size=(n, n)).astype(np.float64), -1) + np.diag(rng.integers(1, 5, size=n).astype(float))
+    A = Lt @ Lt.T          # exact in float64, asymmetric structure per tile
+    # feed A through the IsoLinear kernel: K = X X^T / l^2 with X = Lt, l = 1, noise chosen to cancel eps
+    X = Lt.copy()
+    noise_var = 4.0
+    ctx.set_train(X, np.zeros(n))
+    ctx.set_leaves([0, n], np.arange(n), [0], [0.0])
+    ctx.set_hyper(0, 2, [0.0, 0.0, 0.5 * np.log(noise_var)])
+    mll, info, _ = ctx.fit()
+    assert info[0] == 0
+    F, _ = ctx.download_factor(0, n)
+    ref = np.linalg.cholesky(A + (noise_var + 1e-8) * np.eye(n))
+    assert np.max(np.abs(F - ref)) < 1e-11 * np.max(np.abs(ref))
+    # rows/cols swapped inside a tile would give errors of order 1, not 1e-11
+
+
+def test_kernel_matrix_against_oracle(ctx):
+    D = 5
+    x1 = uniform(50, 0, 300 * D).reshape((300, D), order="F")
+    x2 = uniform(51, 0, 131 * D).reshape((131, D), order="F")
+    ctx.set_train(x1, np.zeros(300))
+    for kind, h in ((0, [np.log(0.4), 0.2]), (1, list(np.log([0.3, 0.5, 0.7, 0.9, 1.1])) + [-0.1]), (2, [np.log(1.7), 0.0])):
+        ctx.set_hyper(0, kind, h + [0.0])
+        K = ctx.kernel_matrix(0, x1, x2)
+        Ko = ogp.kernelmatrix(ogp.make_kernel(kind, h), x1, x2, exact=True)
+        assert np.max(np.abs(K - Ko)) <= 1e-13 * max(1.0, np.max(np.abs(Ko))), kind
+        Kw = ogp.kernelmatrix(ogp.make_kernel(kind, h), x1, x2, exact=False)   # reference's GEMM-trick distances
+        assert np.max(np.abs(K - Kw)) <= 1e-12 * max(1.0, np.max(np.abs(Ko))), kind
+
+
+def test_golden_single_gps(ctx, golden_dir):
+    """mpmath-pinned golden vectors: alpha, mll, predictive mean / variance, factor."""
+    for name, c in _cases(golden_dir).items():
+        n = c["X"].shape[0]
+        mll, info, _ = _single(ctx, c["X"], c["y"], float(c["mean"]), int(c["kind"]), c["loghyp"], float(c["logNoise"]))
+        assert info[0] == 0
+        assert abs(mll[0] - float(c["mll"])) <= RTOL * max(1.0, abs(float(c["mll"]))), name
+        F, alpha = ctx.download_factor(0, n)
+        assert np.max(np.abs(F - c["L"])) <= 1e-11 * np.max(np.abs(c["L"])), name
+        assert np.allclose(alpha, c["alpha"], rtol=1e-8, atol=1e-10), name
+        nt = c["Xt"].shape[0]
+        mu, var = ctx.predict_leaves(c["Xt"], [0, nt], np.arange(nt))
+        assert np.allclose(mu, c["mu"], rtol=RTOL, atol=1e-11), name
+        assert np.allclose(var, c["var"], rtol=RTOL, atol=1e-11), name
+
+
+def test_analytic_closed_forms(ctx, golden_dir):
+    a = json.load(open(os.path.join(golden_dir, "analytic.json")))
+    for name in ("n1", "n2"):
+        c = a[name]
+        X = np.atleast_1d(np.array(c["x"], dtype=float)).reshape(-1, 1)
+        y = np.atleast_1d(np.array(c["y"], dtype=float))
+        mll, info, _ = _single(ctx, X, y, c["mean"], 0, np.array([c["logl"], c["logs"]]), c["logNoise"])
+        assert abs(mll[0] - c["mll"]) < 1e-12 * max(1, abs(c["mll"]))
+        mu, var = ctx.predict_leaves(np.array([[c["xt"]]]), [0, 1], [0])
+        assert abs(mu[0] - c["mu"]) < 1e-13 and abs(var[0] - c["var"]) < 1e-13
+
+
+@pytest.mark.parametrize("n,D,kind", [(127, 1, 0), (128, 2, 0), (129, 3, 0), (700, 4, 0), (1000, 8, 1), (515, 3, 2),
+                                       (2500, 8, 0)])
+def test_single_gp_vs_oracle(ctx, n, D, kind):
+    """Config-2 shape at oracle-sized n, ragged sizes around the 128 tile edge, every kernel kind."""
+    X = uniform(60 + n, 0, n * D).reshape((n, D), order="F")
+    y = np.sin(4 * X[:, 0]) + 0.1 * normal(61 + n, 0, n)
+    Xt = uniform(62 + n, 0, 150 * D).reshape((150, D), order="F")
+    h = {0: [np.log(0.3), 0.0], 1: list(np.log(np.linspace(0.3, 0.8, D))) + [0.1], 2: [np.log(0.9), 0.0]}[kind]
+    logNoise = np.log(0.1)
+    mean = float(np.mean(y))
+    mll, info, _ = _single(ctx, X, y, mean, kind, np.array(h), logNoise)
+    g = ogp.GaussianProcess(X, y, mean, ogp.make_kernel(kind, h), logNoise, exact_dist=True).update_cholesky()
+    assert info[0] == 0 and g.info == 0
+    assert abs(mll[0] - g.mll()) <= RTOL * max(1.0, abs(g.mll()))
+    F, alpha = ctx.download_factor(0, n)
+    assert np.max(np.abs(F - g.L())) <= 1e-9 * np.max(np.abs(g.L()))
+    assert np.max(np.abs(alpha - g.alpha)) <= 1e-7 * np.max(np.abs(g.alpha))
+    mu, var = ctx.predict_leaves(Xt, [0, 150], np.arange(150))
+    mo, vo = g.prediction(Xt)
+    assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9)
+    assert np.allclose(var, vo, rtol=RTOL, atol=1e-10)
+
+
+def test_not_positive_definite_is_reported(ctx):
+    """LAPACK-style info: a rank-1 linear-kernel Gram of size 1e16 leaves only rounding noise (+-1) in the
+    Schur complement, far above noise + eps, so some pivot goes non-positive -- in LAPACK and here."""
+    import scipy.linalg as sla
+    n = 140
+    X = np.linspace(1.0, 2.0, n).reshape(-1, 1) * 1e8
+    ctx.set_train(X, np.zeros(n))
+    ctx.set_leaves([0, n], np.arange(n), [0], [0.0])
+    ctx.set_hyper(0, 2, [0.0, 0.0, -30.0])
+    _, info, _ = ctx.fit()
+    K = X @ X.T + (np.exp(-60.0) + 1e-8) * np.eye(n)
+    _, linfo = sla.lapack.dpotrf(K, lower=1)
+    assert linfo > 0 and 1 < info[0] <= n
+
+
+def test_error_paths(ctx):
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.set_leaves([0, 3], [2, 1, 0], [0], [0.0])               # not ascending
+    X = uniform(1, 0, 40).reshape((20, 2), order="F")
+    ctx.set_train(X, np.zeros(20))
+    ctx.set_leaves([0, 10, 20], np.arange(20), [0, 1], [0.0, 0.0])
+    ctx.set_hyper(0, 0, [0.0, 0.0, 0.0])
+    with pytest.raises(hipabi.DsmgpError) as e:
+        ctx.fit()                                                    # kernel id 1 has no hyper-parameters
+    assert "kernel id 1" in str(e.value)
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.set_sharing([0, 1], [-1, 0], [0, 0])                     # COPY claim with different obs lists
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.set_hyper(0, 1, [0.0, 0.0, 0.0])                         # ArdSE needs D lengthscales
+        ctx.set_hyper(1, 0, [0.0, 0.0, 0.0])
+        ctx.fit()
+
+
+def _oracle_model(m, X, y, tau=0.05):
+    gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+    census = ospn.fit(m.root, gps, ospn.get_overlap(m.root, m.L), tau)
+    return gps, census
+
+
+def test_config1_readme_example(golden_dir):
+    """BASELINE config 1 (README 1-D sinusoid, N=100, IsoSE(1,1), K=4, V=3, M=10): every sharing branch
+    fires here (copy, prefix continue); compared with the committed oracle fixture."""
+    z = np.load(os.path.join(golden_dir, "config1.npz"))
+    X, y, xt = z["x"].reshape(-1, 1), z["y"], z["xt"]
+    m = dsm.buildDSMGP(X, y, 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(float(np.mean(X))), seed=11)
+    assert np.count_nonzero(m.share_op == ptree.SHARE_COPY) == z["census"][1] > 0
+    assert np.count_nonzero(m.share_op == ptree.SHARE_PREFIX) == z["census"][2] > 0
+    assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=RTOL, atol=1e-9)
+    zroot = dsm.update(m)
+    assert abs(zroot - float(z["root_mll"])) <= RTOL * abs(float(z["root_mll"]))
+    mu, var = dsm.predict(m, xt)
+    assert np.allclose(mu, z["mu"], rtol=RTOL, atol=1e-10)
+    assert np.allclose(var, z["var"], rtol=RTOL, atol=1e-10)
+    # fit_naive! (no sharing) gives the same model
+    dsm.fit_naive(m)
+    assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=RTOL, atol=1e-9)
+
+
+def test_prefix_continue_equals_full_factorisation(ctx):
+    """chol_continue! property (src/AdvancedCholeskey.jl:121-135's intent): continuing from a copied
+    leading block == factorising from scratch, at sizes that cross several 128-blocks."""
+    N, D = 900, 2
+    X = uniform(70, 0, N * D).reshape((N, D), order="F")
+    y = np.cos(3 * X[:, 0]) + 0.05 * normal(71, 0, N)
+    p = 400                                     # 3 whole blocks copied, block 3 recomputed
+    obs_ptr = [0, p, p + N]
+    obs_idx = np.concatenate([np.arange(p), np.arange(N)])
+    ctx.set_train(X, y)
+    ctx.set_leaves(obs_ptr, obs_idx, [0, 0], [0.1, 0.2])
+    ctx.set_hyper(0, 0, [np.log(0.3), 0.0, np.log(0.1)])
+    ctx.set_sharing([0, 2], [-1, 0], [0, p])
+    mll_s, info, _ = ctx.fit()
+    F_s, a_s = ctx.download_factor(1, N)
+    ctx.set_sharing(None, None, None)
+    mll_f, info2, _ = ctx.fit()
+    F_f, a_f = ctx.download_factor(1, N)
+    assert info[1] == 0 and info2[1] == 0
+    assert np.max(np.abs(F_s - F_f)) <= 1e-12 * np.max(np.abs(F_f))
+    assert np.allclose(mll_s, mll_f, rtol=1e-12)
+    assert np.allclose(a_s, a_f, rtol=1e-9, atol=1e-11)
+    g = ogp.GaussianProcess(X, y, 0.2, ogp.IsoSE(np.log(0.3), 0.0), np.log(0.1), True).update_cholesky()
+    assert abs(mll_s[1] - g.mll()) <= RTOL * abs(g.mll())
+
+
+@pytest.mark.parametrize("family", ["dsmgp", "poe", "gpoe", "rbcm", "kernel_vector", "ardse"])
+def test_models_vs_oracle(family):
+    """Whole models at oracle size: leaf log-marginals, update!, predict for every model family."""
+    N, D = 3000, 3
+    X, y, Xt = regression_data(N, D, n_test=200, seed=900)
+    kern = dsm.IsoSE(np.log(0.3), 0.0)
+    kw = dict(logNoise=np.log(0.1), seed=4)
+    if family == "dsmgp":
+        m = dsm.buildDSMGP(X, y, 3, 4, M=60, kernel=kern, **kw)
+    elif family == "kernel_vector":
+        m = dsm.buildDSMGP(X, y, 2, 4, M=60, kernel=[kern, dsm.IsoLinear(np.log(1.5))], **kw)
+    elif family == "ardse":
+        m = dsm.buildDSMGP(X, y, 2, 4, M=60, kernel=dsm.ArdSE(np.log([0.3, 0.4, 0.5]), 0.0), **kw)
+    elif family == "poe":
+        m = dsm.buildPoE(X, y, 8, M=100, kernel=kern, meanFun=dsm.ConstMean(float(np.mean(y))), **kw)
+    elif family == "gpoe":
+        m = dsm.buildPoE(X, y, 8, M=100, kernel=kern, meanFun=dsm.ConstMean(float(np.mean(y))), generalized=True, **kw)
+    else:
+        m = dsm.buildBCM(X, y, 8, M=100, kernel=kern, **kw)
+    gps, _ = _oracle_model(m, X, y)
+    lo = np.array([g.mll() for g in gps])
+    assert np.allclose(m.leaf_mll, lo, rtol=RTOL, atol=1e-8)
+    if m.family == "dsmgp":
+        z = dsm.update(m)
+        zo = ospn.update(m.root, gps)
+        assert abs(z - zo) <= RTOL * max(1.0, abs(zo))
+        mo, vo = ospn.predict(m.root, gps, Xt)
+    elif m.family == "poe":
+        mo, vo = ospn.predict_poe(m.root, gps, Xt)
+    elif m.family == "gpoe":
+        mo, vo = ospn.predict_gpoe(m.root, gps, Xt)
+    else:
+        mo, vo = ospn.predict_rbcm(m.root, gps, Xt)
+    mu, var = dsm.predict(m, Xt)
+    assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9), float(np.max(np.abs(mu - mo)))
+    assert np.allclose(var, vo, rtol=RTOL, atol=1e-10), float(np.max(np.abs(var - vo) / vo))
+
+
+def test_full_size_properties_single_large_gp(ctx):
+    """Config 2 (single exact GP N=4096, D=4, IsoSE) -- too large to compare entry by entry quickly,
+    checked through size-independent properties: L L^T = K, K alpha = y, mll consistency,
+    predictions at training points, refit idempotence."""
+    N, D = 4096, 4
+    X, y, Xt = regression_data(N, D, n_test=256, seed=20202)
+    h = np.array([np.log(0.3), 0.0])
+    ln = np.log(0.1)
+    mean = float(np.mean(y))
+    mll, info, sec = _single(ctx, X, y, mean, 0, h, ln)
+    assert info[0] == 0
+    F, alpha = ctx.download_factor(0, N)
+    K = ogp.kernelmatrix(ogp.IsoSE(*h), X, None, exact=True)
+    K[np.diag_indices(N)] += np.exp(2 * ln) + 1e-8
+    assert np.max(np.abs(F @ F.T - K)) <= 1e-12 * N
+    yc = y - mean
+    assert np.max(np.abs(K @ alpha - yc)) <= 1e-8 * np.max(np.abs(yc))
+    mll_host = -(yc @ alpha + 2 * np.sum(np.log(np.diag(F))) + N * np.log(2 * np.pi)) / 2
+    assert abs(mll[0] - mll_host) <= 1e-10 * abs(mll_host)
+    # predicting at training inputs: mu = y - noise*alpha  (K_f alpha = yc - (noise+eps) alpha)
+    idx = np.arange(0, N, 16)
+    mu, var = ctx.predict_leaves(X[idx], [0, idx.size], np.arange(idx.size))
+    assert np.allclose(mu, y[idx] - (np.exp(2 * ln) + 1e-8) * alpha[idx], rtol=1e-9, atol=1e-10)
+    assert np.all(var > np.exp(2 * ln)) and np.all(var < 1.0 + np.exp(2 * ln) + 1e-12)
+    mll2, _, _ = ctx.fit()
+    assert mll2[0] == mll[0]                                         # deterministic, idempotent
+    g_mu, g_var = ctx.predict_leaves(Xt, [0, 256], np.arange(256))
+    go = ogp.GaussianProcess(X, y, mean, ogp.IsoSE(*h), ln, True).update_cholesky()
+    mo, vo = go.prediction(Xt)
+    assert abs(mll[0] - go.mll()) <= RTOL * abs(go.mll())
+    assert np.allclose(g_mu, mo, rtol=RTOL, atol=1e-9) and np.allclose(g_var, vo, rtol=RTOL, atol=1e-10)

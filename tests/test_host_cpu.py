@@ -1,0 +1,241 @@
+"""CPU suite, part 2: the product's HOST logic (tree builder, overlap, sharing schedule, routing,
+aggregation, sharding) checked against the oracle's literal restatement of the reference recursions,
+plus the C-ABI library's exported symbols.  No GPU: per-leaf numerics come from tests/oracle_context.py."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import deepstructuredmixtures_amd as dsm
+from deepstructuredmixtures_amd import tree as ptree, hipabi, dist as pdist
+from deepstructuredmixtures_amd.datagen import uniform, normal, splitmix64, Stream, regression_data
+from oracle import spn as ospn
+from oracle_context import OracleContext
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _small_problem(N=400, D=2, seed=21):
+    X = uniform(seed, 0, N * D).reshape((N, D), order="F")
+    y = np.sin(5 * X[:, 0]) + 0.5 * X[:, -1] + 0.1 * normal(seed + 1, 0, N)
+    return X, y
+
+
+def test_datagen_is_counter_based_and_reproducible():
+    a = splitmix64(1234567, 0, 4)
+    # SplitMix64 reference sequence for seed 1234567 (public test vector of the algorithm)
+    assert [int(v) for v in a] == [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431]
+    assert np.array_equal(splitmix64(5, 10, 6), splitmix64(5, 0, 16)[10:])
+    u = uniform(3, 0, 1000)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.05
+    z = normal(4, 0, 20001)
+    assert z.size == 20001 and abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+    X, y, Xt = regression_data(1000, 4, seed=20200)
+    assert X.flags.f_contiguous and X.shape == (1000, 4) and Xt.shape == (100, 4) and y.shape == (1000,)
+    s = Stream(9)
+    b = [s.beta22() for _ in range(2000)]
+    assert abs(np.mean(b) - 0.5) < 0.02 and abs(np.var(b) - 0.05) < 0.01   # Beta(2,2): var = 1/20
+
+
+def test_tree_structure_follows_the_reference_builder():
+    X, y = _small_problem(2000, 3)
+    m = dsm.buildDSMGP(X, y, 3, 4, M=30, kernel=dsm.IsoSE(0.0, 0.0), fit_now=False, seed=5)
+    root = m.root
+    assert root.kind == "sum" and len(root.children) == 3            # K = 3 sum children
+    assert np.allclose(root.logweights, -np.log(3))
+    for sp in root.children:
+        assert sp.kind == "split" and len(sp.children) == 4          # V = 4 -> 3 cuts (depth^2 rule)
+        assert sp.split[-1][1] == np.inf
+        ths = [s for _, s in sp.split]
+        assert ths == sorted(ths)
+        # children partition the data on (lb, ub] of the split dimension
+        tot = sum(sum(lf.nobs for lf in ptree.get_leaves(c)) // 3 for c in sp.children if c.kind == "sum")
+        assert tot == 2000
+        for c in sp.children:
+            assert c.kind == "sum"                                    # depth 1 < 2 and > M points
+            for sp2 in c.children:
+                for g in sp2.children:
+                    assert g.kind == "gp"                             # depth 2 reached
+    assert m.L == 3 * 4 * 3 * 4
+    for lf in m.leaves:
+        assert np.all(np.diff(lf.obs) > 0) and lf.nobs > 0            # ascending original indices
+        assert abs(lf.mean.m - y[lf.obs].mean()) < 1e-14              # ConstMean(mean(y_leaf))
+    # K=8 splits -> 7 cuts; PoE recursion always on dimension 0 until <= 2M points
+    p = dsm.buildPoE(X, y, 8, M=50, meanFun=dsm.ConstMean(0.0), fit_now=False, seed=5)
+    assert p.root.kind == "split" and len(p.root.children) == 8
+    assert all(s[0] == 0 for s in p.root.split)
+    assert max(lf.nobs for lf in p.leaves) <= 2 * 50 + 1
+    assert sum(lf.nobs for lf in p.leaves) == 2000
+    # kernel vectors -> one GP per kernel under a sum-of-GPs with Dirichlet weights
+    kv = dsm.buildDSMGP(X, y, 1, 4, M=200, D=1, kernel=[dsm.IsoSE(0.0, 0.0), dsm.IsoLinear(0.0)], fit_now=False)
+    sums = [n for n in ptree.ordered_nodes(kv.root) if n.kind == "sum" and n.of_gps]
+    assert sums and all(len(s.children) == 2 and abs(np.exp(s.logweights).sum() - 1) < 1e-12 for s in sums)
+    assert {lf.kernelid for lf in kv.leaves} == {0, 1}
+
+
+def test_overlap_schedule_and_routing_match_the_oracle(golden_dir):
+    z = np.load(os.path.join(golden_dir, "config1.npz"))
+    x, y = z["x"], z["y"]
+    m = dsm.buildDSMGP(x.reshape(-1, 1), y, 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0),
+                       meanFun=dsm.ConstMean(float(np.mean(x))), seed=11, fit_now=False)
+    # the committed leaf table pins the builder (RNG stream + cut rules)
+    assert np.array_equal(np.concatenate([lf.obs for lf in m.leaves]), z["obs_idx"])
+    D_or = ospn.get_overlap(m.root, m.L)
+    assert np.array_equal(m.D, D_or)
+    op, src, plen = ptree.share_schedule(m.leaves, m.D, 0.05)
+    full, copy, prefix, lowrank = z["census"]
+    assert np.count_nonzero(op == ptree.SHARE_COPY) == copy
+    assert np.count_nonzero(op == ptree.SHARE_PREFIX) == prefix
+    for j in np.flatnonzero(op == ptree.SHARE_COPY):
+        assert np.array_equal(m.leaves[j].obs, m.leaves[src[j]].obs) and op[src[j]] == ptree.SHARE_FULL
+    for j in np.flatnonzero(op == ptree.SHARE_PREFIX):
+        s = m.leaves[src[j]]
+        assert plen[j] == s.nobs and np.array_equal(m.leaves[j].obs[: s.nobs], s.obs)
+    op0, _, _ = ptree.share_schedule(m.leaves, m.D, 0.0)
+    assert np.count_nonzero(op0 == ptree.SHARE_PREFIX) == 0          # τ = 0 disables the branch (fit.jl:256)
+    # routing == getchild loops of the reference
+    xt = z["xt"]
+    for n in ptree.ordered_nodes(m.root):
+        if n.kind == "split":
+            d = n.split[0][0]
+            pts = xt[(xt[:, d] > n.lowerBound[d]) & (xt[:, d] <= n.upperBound[d])]
+            if pts.size:
+                assert np.array_equal(ptree.get_child(n, pts), ospn.getchild(n, pts))
+    ptr, idx = ptree.route(m.root, xt)
+    assert ptr[-1] == xt.shape[0] * 9                                 # V^depth = 3^2 leaves per point
+
+
+@pytest.mark.parametrize("fixture", ["config1", "tree_small"])
+def test_host_aggregation_matches_reference_recursion(golden_dir, fixture):
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    if fixture == "config1":
+        X, y, xt = z["x"].reshape(-1, 1), z["y"], z["xt"]
+        m = dsm.buildDSMGP(X, y, 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(float(np.mean(X))),
+                           seed=11, fit_now=False, ctx=OracleContext())
+    else:
+        X, y, xt = z["X"], z["y"], z["Xt"]
+        m = dsm.buildDSMGP(X, y, 2, 4, M=20, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=3,
+                           fit_now=False, ctx=OracleContext())
+    dsm.fit(m)
+    assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=1e-10, atol=1e-9)
+    root_z = dsm.update(m)
+    assert abs(root_z - float(z["root_mll"])) < 1e-9 * max(1, abs(float(z["root_mll"])))
+    assert abs(dsm.mll(m) - root_z) < 1e-9 * max(1, abs(root_z))
+    mu, var = dsm.predict(m, xt)
+    assert np.allclose(mu, z["mu"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(var, z["var"], rtol=1e-8, atol=1e-10)
+    tab = dsm.mll_table(m)
+    assert abs(tab[m.root.id] - dsm.mll(m)) < 1e-12
+    # infer! resets non-GP sums to uniform (src/common.jl:347-353)
+    dsm.infer(m)
+    assert np.allclose(m.root.logweights, -np.log(len(m.root.children)))
+
+
+def test_poe_family_host_rules():
+    X, y = _small_problem(300, 2, seed=33)
+    xt = uniform(35, 0, 40).reshape((20, 2), order="F")
+    for builder, ofun, kw in ((dsm.buildPoE, ospn.predict_poe, dict(meanFun=dsm.ConstMean(0.2))),
+                              (dsm.buildPoE, ospn.predict_gpoe, dict(meanFun=dsm.ConstMean(0.2), generalized=True)),
+                              (dsm.buildBCM, ospn.predict_rbcm, dict())):
+        m = builder(X, y, 4, M=30, kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.2), ctx=OracleContext(),
+                    seed=2, **kw)
+        gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+        ospn.fit_naive(m.root, gps)
+        mu, var = dsm.predict(m, xt)
+        mo, vo = ofun(m.root, gps, xt)
+        assert np.allclose(mu, mo, rtol=1e-10, atol=1e-12) and np.allclose(var, vo, rtol=1e-10, atol=1e-13)
+
+
+def test_setparams_layout():
+    X, y = _small_problem(300, 2)
+    m = dsm.buildDSMGP(X, y, 1, 4, M=100, D=1, kernel=[dsm.IsoSE(0.1, 0.2), dsm.IsoLinear(0.3)], logNoise=0.4, fit_now=False)
+    assert np.allclose(dsm.getparams(m), [0.1, 0.2, 0.4, 0.3, 0.0, 0.4])
+    dsm.setparams(m, [1, 2, 3, 4, 5, 6])
+    for lf in m.leaves:
+        if lf.kernelid == 0:
+            assert (lf.kernel.logl, lf.kernel.logs, lf.logNoise) == (1.0, 2.0, 3.0)
+        else:
+            assert (lf.kernel.logl, lf.logNoise) == (4.0, 6.0)       # IsoLinear ignores its variance slot
+    with pytest.raises(ValueError):
+        dsm.setparams(m, [1, 2, 3])
+    a = dsm.buildDSMGP(X, y, 1, 4, M=100, D=1, kernel=dsm.ArdSE([0.1, 0.2], 0.3), logNoise=0.5, fit_now=False)
+    assert np.allclose(dsm.getparams(a), [0.1, 0.2, 0.3, 0.5])
+
+
+def test_lpt_sharding_balances_and_colocates():
+    nobs = np.array([100, 90, 80, 10, 10, 10, 10, 100])
+    op = np.array([0, 0, 0, 0, 0, 0, 0, 1])
+    src = np.array([-1, -1, -1, -1, -1, -1, -1, 0])
+    shards = [pdist.Shard.lpt(nobs, op, src, r, 2) for r in range(2)]
+    assert np.array_equal(shards[0].owner, shards[1].owner)
+    assert shards[0].owner[7] == shards[0].owner[0]                   # COPY leaf follows its source
+    loads = [np.sum(nobs[shards[0].owner == r].astype(float) ** 3) for r in range(2)]
+    assert sorted(np.concatenate([s.local for s in shards]).tolist()) == list(range(8))
+    s1 = pdist.Shard.single(5)
+    assert np.array_equal(s1.gather_leaf_values(np.arange(5.0)), np.arange(5.0))
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as td
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import deepstructuredmixtures_amd as dsm
+from oracle_context import OracleContext
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+td.init_process_group("gloo", rank=rank, world_size=world)
+z = np.load(os.path.join({root!r}, "tests", "golden", "tree_small.npz"))
+m = dsm.buildDSMGP(z["X"], z["y"], 2, 4, M=20, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=3,
+                   fit_now=False, ctx=OracleContext(), shard_world=(rank, world))
+assert 0 < len(m.shard.local) < m.L
+dsm.fit(m)
+assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=1e-10, atol=1e-9)
+dsm.update(m)
+mu, var = dsm.predict(m, z["Xt"])
+assert np.allclose(mu, z["mu"], rtol=1e-9, atol=1e-10) and np.allclose(var, z["var"], rtol=1e-8, atol=1e-10)
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok", len(m.shard.local))
+"""
+
+
+def test_two_rank_gloo_sharding_reproduces_the_single_process_result(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert " ok " in o
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """Loads libdsmgp_hip.so (no compute) and checks it exports exactly what include/dsmgp_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "dsmgp_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(dsmgp_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(hipabi.SIGNATURES), declared ^ set(hipabi.SIGNATURES)
+    if not os.path.exists(hipabi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(hipabi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_product_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hipabi.DsmgpError) as e:
+        hipabi.Context(0)
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+    # and nothing in the product imports the oracle
+    for fn in os.listdir(os.path.join(ROOT, "deepstructuredmixtures_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "deepstructuredmixtures_amd", fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src
