@@ -1,0 +1,197 @@
+"""Headline benchmark: fit! + predict wall-clock of a DSMGP (BASELINE.json metric) on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3], fits one GPU): buildDSMGP K=4 splits, V=3 sum children, M=200,
+N=100k, D=8, IsoSE, tree depth 2 (reference default) -> 144 leaf GPs, n ~ 1.5k-14k; n_t = N/10 test rows.
+One step = fit! (Gram assembly + batched Cholesky + alpha + per-leaf mll) + update! + predict
+(K_tn assembly, triangular solves, predictive moments, sum/product aggregation), inputs resident in HBM.
+With N > 1 the SAME model is sharded leaf-wise over the ranks (strong scaling); the only exchange is
+an all-gather of per-leaf log-marginals and per-(leaf, test row) moments (RCCL over xGMI).
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X public spec, fp64 matrix = fp64 vector; the in-container guide lists no fp64 figure
+
+CONFIGS = {
+    # name: (N, D, K_sum_children, V_splits, M, depth, kernel)
+    "dsmgp_n100k_d8": dict(N=100_000, D=8, K=3, V=4, M=200, depth=2),
+    "dsmgp_n20k_d8": dict(N=20_000, D=8, K=3, V=4, M=200, depth=2),
+    "dsmgp_n100k_d8_depth3": dict(N=100_000, D=8, K=3, V=4, M=200, depth=3),
+}
+
+
+def build_model(cfg, rank, world, device):
+    import deepstructuredmixtures_amd as dsm
+    from deepstructuredmixtures_amd import dist as pdist, tree as ptree
+    c = CONFIGS[cfg]
+    X, y, Xt = dsm.regression_data(c["N"], c["D"], seed=20204)
+    model = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=dsm.IsoSE(np.log(0.3), 0.0),
+                           logNoise=np.log(0.1), seed=20204, fit_now=False, device=device)
+    ptr, idx = ptree.route(model.root, Xt)
+    if world > 1:
+        op, src, _ = ptree.share_schedule(model.leaves, model.D, 0.05)
+        model.shard = pdist.Shard.lpt([lf.nobs for lf in model.leaves], op, src, rank, world, n_test=np.diff(ptr))
+    return model, X, y, Xt, ptr, idx
+
+
+def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
+    """Oracle ("port" of the reference's per-leaf arithmetic, LAPACK via SciPy) on a bounded sample of
+    the same workload: whole leaves, lean form (one potrf per leaf, diag-only variance), timed on the
+    host cores and scaled to the full leaf table by the cost model n^3/3 + n^2 (n_t + 2)."""
+    from oracle import gp as ogp
+    nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)
+    nt = np.diff(ptr).astype(np.float64)
+    cost = nobs ** 3 / 3 + nobs ** 2 * (nt + 2)
+    order = np.argsort(nobs)
+    # sample spread over the size range: every q-th leaf by size, grown until the time budget is used
+    sample, spent, done_cost = [], 0.0, 0.0
+    for q in (16, 8, 4, 2):
+        for j in order[q // 2::q]:
+            if j in sample:
+                continue
+            lf = model.leaves[j]
+            t0 = time.perf_counter()
+            g = ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(0, lf.kernel.loghyp()),
+                                    lf.logNoise, exact_dist=False).update_cholesky()
+            g.mll()
+            rows = idx[ptr[j]:ptr[j + 1]]
+            if rows.size:
+                g.prediction(Xt[rows])
+            spent += time.perf_counter() - t0
+            done_cost += cost[j]
+            sample.append(int(j))
+            if spent > budget_s:
+                break
+        if spent > budget_s:
+            break
+    est = spent * cost.sum() / done_cost
+    try:
+        import threadpoolctl
+        threads = max([p["num_threads"] for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": est, "unit": "s", "cores": int(threads), "kind": "port",
+            "sample": f"{len(sample)} of {model.L} leaves (n={int(nobs[sample].min())}..{int(nobs[sample].max())}) "
+                      f"timed {spent:.1f} s with the NumPy/LAPACK oracle, one potrf per leaf + alpha + diag-only predict; "
+                      f"scaled by (n^3/3 + n^2(n_t+2)) to all leaves"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="dsmgp_n100k_d8", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    td = None
+    if world > 1:
+        import torch.distributed as td
+        torch.cuda.set_device(local_rank)
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import deepstructuredmixtures_amd as dsm
+    model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank)
+    ctx = model.ctx
+    ctx.set_profile(not args.no_profile)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if td is not None:
+            td.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        dsm.fit(model)
+        dsm.update(model)
+        return dsm.predict(model, Xt)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    upd_s, upd_launches, fit_s, pred_s = 0.0, 0, 0.0, 0.0
+    cats = {}
+    for _ in range(args.steps):
+        mu, var = step()
+        tm = ctx.timings()
+        for k, v in tm.items():
+            cats[k] = cats.get(k, 0.0) + v
+        fl, nl = ctx.work()
+        upd_launches += nl
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if td is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    per_step = elapsed / args.steps
+    assert np.all(np.isfinite(mu)) and np.all(var > 0)
+
+    # roofline of the dominant kernel (f64-MFMA Cholesky update) on this rank
+    alg_flops, _ = ctx.work()
+    roof = None
+    if not args.no_profile and cats.get("chol_update", 0.0) > 0:
+        avg_launch = cats["chol_update"] / max(1, upd_launches)
+        flops_per_launch = alg_flops * args.steps / max(1, upd_launches)
+        achieved = flops_per_launch / avg_launch / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": None, "kernel": "tile_gemm_kernel<true> (chol_update)",
+                "avg_launch_ms": avg_launch * 1e3, "launches_per_step": upd_launches // args.steps,
+                "alg_flops_per_step": alg_flops}
+    nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)
+    chol_flops_total = float(np.sum(nobs ** 3) / 3)
+
+    if rank == 0:
+        c = CONFIGS[args.config]
+        out = {
+            "metric": "fit!+predict wall-clock, DSMGP N=%dk D=%d" % (c["N"] // 1000, c["D"]),
+            "value": per_step, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"buildDSMGP K=4 splits V=3 sum children M={c['M']} N={c['N']} D={c['D']} IsoSE "
+                                   f"depth {c['depth']}: {model.L} leaf GPs n={int(nobs.min())}..{int(nobs.max())}, "
+                                   f"n_t={Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; "
+                                   f"fit! (Gram+Cholesky+alpha+mll) + update! + predict",
+                       "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and (mu, var)"},
+            "leaf_cholesky_tflops": chol_flops_total / (cats.get("total_fit", per_step * args.steps) / args.steps) / 1e12 / 1.0
+            if world == 1 else None,
+            "device_seconds_per_step": {k: v / args.steps for k, v in cats.items() if v > 0},
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, X, y, Xt, ptr, idx)
+            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / per_step
+        try:
+            out["f64_mfma_probe_tflops"] = ctx.probe_f64_mfma()
+        except Exception:
+            pass
+        print(json.dumps(out))
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
