@@ -541,7 +541,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int nd = S.diag_off[k + 1] - S.diag_off[k];
         if (nd > 0) {
             pt.begin(2);
-            chol_diag_kernel<<<nd, 256, TB*(TB + 1) * sizeof(double), c->stream>>>(S.diag.p + S.diag_off[k]);
+            chol_diag_kernel<<<nd, 256, (TB * DLD + 256) * sizeof(double), c->stream>>>(S.diag.p + S.diag_off[k]);
             pt.end();
         }
         const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
@@ -574,7 +574,7 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, TB * (TB + 1) * (int)sizeof(double));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (TB * DLD + 256) * (int)sizeof(double));
     const char* p = std::getenv("DSMGP_PROFILE");
     c->profile = p && p[0] == '1';
     *out = c;

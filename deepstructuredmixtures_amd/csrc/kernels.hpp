@@ -239,65 +239,154 @@ struct DiagTask {
     int pad;
 };
 
+// LDS image: column-major, leading dimension DLD = 144 rows (128 + one spare block row), 128 columns.
+//   factor blocks  S(I,K), I >= K : rows 16I.., cols 16K..
+//   inverse blocks B(I,K), K <  I : stored in the unused upper triangle at rows 16K.., cols 16I..
+//                  B(I,I)         : spare block row 128..143, cols 16I..
+// Blocked right-looking Cholesky on 16x16 sub-blocks.  Per block step J:
+//   P0  wave 0: potrf + inverse of the 16x16 diagonal block, one column per lane, all in registers,
+//       cross-lane traffic by v_readlane broadcasts (no LDS, no barrier inside)
+//   P1  all waves: panel S(I,J) = S(I,J) Linv^T (I > J) and B(J,K) = Linv B(J,K) (K < J)        [MFMA]
+//   P2  all waves: trailing S(I,K) -= S(I,J) S(K,J)^T (I >= K > J), B(I,K) -= S(I,J) B(J,K)     [MFMA]
+// B accumulates L^-1 by forward substitution on the identity, interleaved with the factorisation.
+constexpr int DLD = 144;
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
+// acc[r] (+)= sum_{k<16} Aop(a,k) Bop(b,k) with a = (lane>>4)+4r, b = lane&15;
+// Aop(a,k) at pa[a*saa + k*sak], Bop(b,k) at pb[b + k*sbk]
+__device__ __forceinline__ d4 blk_mma(const double* pa, int saa, int sak, const double* pb, int sbk, d4 acc, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int kk = 4 * s + l4;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[l15 * saa + kk * sak], pb[l15 + kk * sbk], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restrict__ tasks) {
-    extern __shared__ __attribute__((aligned(16))) double S[];   // [128][129], S[r*129 + c]
-    __shared__ double tmp[TB];
-    __shared__ int bad;
-    constexpr int LS = TB + 1;
+    extern __shared__ __attribute__((aligned(16))) double S[];   // [128 cols][DLD rows] + Winv[256]
+    double* Winv = S + TB * DLD;                                  // Linv of the current step, col-major ld 16
     const DiagTask tk = tasks[blockIdx.x];
-    const int t = threadIdx.x;
-    if (t == 0) bad = 0;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    auto offS = [](int I, int K) { return (K * 16) * DLD + I * 16; };
+    auto offB = [](int I, int K) { return (I == K) ? (I * 16) * DLD + TB : (I * 16) * DLD + K * 16; };
+
     for (int e = t; e < TB * TB; e += 256) {
         const int r = e % TB, c = e / TB;
-        S[r * LS + c] = (c <= r) ? tk.T[r + (size_t)c * tk.ld] : 0.0;
+        S[c * DLD + r] = ((r >> 4) >= (c >> 4)) ? tk.T[r + (size_t)c * tk.ld] : 0.0;
     }
+    for (int e = t; e < TB * 16; e += 256) S[(e >> 4) * DLD + TB + (e & 15)] = 0.0;
     __syncthreads();
-    // right-looking Cholesky, column by column
-    for (int j = 0; j < TB; ++j) {
-        const double d = S[j * LS + j];
-        if (t == 0 && !(d > 0.0) && bad == 0) bad = j + 1;
-        const double sd = sqrt(d);
-        __syncthreads();
-        if (t < TB) {
-            if (t == j) S[j * LS + j] = sd;
-            else if (t > j) S[t * LS + j] = S[t * LS + j] / sd;
+
+    int bad = 0;
+    for (int J = 0; J < 8; ++J) {
+        // ---- P0: 16x16 diagonal block on wave 0 (lanes 16..63 mirror lanes 0..15, only 0..15 store)
+        if (w == 0) {
+            const int c = l15;
+            double a[16], x[16];
+            const double* src = S + offS(J, J) + c * DLD;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = src[r];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double d = readlane_f64(a[j], j);
+                if (!(d > 0.0) && bad == 0) bad = J * 16 + j + 1;
+                const double sd = sqrt(d);
+                const double inv = 1.0 / sd;
+                const double lc = a[j] * inv;
+#pragma unroll
+                for (int r = j + 1; r < 16; ++r) {
+                    const double lr = readlane_f64(a[r], j) * inv;
+                    if (c > j) a[r] = fma(-lr, lc, a[r]);
+                }
+                if (c == j) {
+                    a[j] = sd;
+#pragma unroll
+                    for (int r = j + 1; r < 16; ++r) a[r] *= inv;
+                }
+            }
+            // x = column c of the inverse of the lower-triangular block
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double rinv = 1.0 / readlane_f64(a[i], i);
+                double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) s = fma(-readlane_f64(a[i], k), x[k], s);
+                x[i] = (i >= c) ? s * rinv : 0.0;
+            }
+            if (lane < 16) {
+                double* dS = S + offS(J, J) + c * DLD;
+                double* dB = S + offB(J, J) + c * DLD;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dS[r] = (r >= c) ? a[r] : 0.0;
+                    dB[r] = x[r];
+                    Winv[c * 16 + r] = x[r];
+                }
+            }
         }
         __syncthreads();
-        const int m = TB - 1 - j;
-        // element (i, c), j < c <= i: row-major pairs spread over the 256 threads
-        for (int e = t; e < m * m; e += 256) {
-            const int i = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= i) S[i * LS + c] -= S[i * LS + j] * S[c * LS + j];
+        // ---- P1: panel solve and the inverse's row J
+        for (int task = w; task < 7; task += 4) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            double* dst;
+            if (task < 7 - J) {                       // S(I,J) <- S(I,J) Linv^T
+                const int I = J + 1 + task;
+                dst = S + offS(I, J);
+                acc = blk_mma(Winv, 1, 16, dst, DLD, acc, lane);
+            } else {                                  // B(J,K) <- Linv B(J,K)
+                const int K = task - (7 - J);
+                dst = S + offB(J, K);
+                acc = blk_mma(dst, DLD, 1, Winv, 16, acc, lane);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] = acc[r];
+        }
+        __syncthreads();
+        // ---- P2: trailing update of the factor and of the inverse
+        const int m = 7 - J;
+        const int ntrail = m * (m + 1) / 2;
+        const int ninv = m * (J + 1);
+        for (int task = w; task < ntrail + ninv; task += 4) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            double* dst;
+            if (task < ntrail) {                      // S(I,K) -= S(I,J) S(K,J)^T, I >= K > J
+                int q = task, Kk = 0;
+                while (q >= m - Kk) { q -= m - Kk; ++Kk; }
+                const int K = J + 1 + Kk, I = K + q;
+                dst = S + offS(I, K);
+                acc = blk_mma(S + offS(K, J), 1, DLD, S + offS(I, J), DLD, acc, lane);
+            } else {                                  // B(I,K) -= S(I,J) B(J,K), I > J, K <= J
+                const int q = task - ntrail;
+                const int I = J + 1 + q / (J + 1), K = q % (J + 1);
+                dst = S + offB(I, K);
+                acc = blk_mma(S + offB(J, K), DLD, 1, S + offS(I, J), DLD, acc, lane);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] -= acc[r];
         }
         __syncthreads();
     }
-    // write L back (strict upper of the tile zeroed)
+    // ---- write L back to the tile (upper blocks and upper parts of diagonal blocks are zero) and L^-1 to Dinv
     for (int e = t; e < TB * TB; e += 256) {
         const int r = e % TB, c = e / TB;
-        tk.T[r + (size_t)c * tk.ld] = S[r * LS + c];
-    }
-    if (t == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
-    __syncthreads();
-    // in-place inverse of the lower-triangular S (column sweep from the right)
-    for (int j = TB - 1; j >= 0; --j) {
-        if (t < TB) tmp[t] = (t > j) ? S[t * LS + j] : 0.0;
-        __syncthreads();
-        const double xjj = 1.0 / S[j * LS + j];
-        double v = 0.0;
-        if (t > j && t < TB) {
-            double s = 0.0;
-            for (int k = j + 1; k <= t; ++k) s = fma(S[t * LS + k], tmp[k], s);
-            v = -s * xjj;
+        const int R = r >> 4, Cb = c >> 4;
+        double l = 0.0, xinv = 0.0;
+        if (R >= Cb) {
+            l = S[c * DLD + r];
+            xinv = (R == Cb) ? S[(R * 16 + (c & 15)) * DLD + TB + (r & 15)] : S[(R * 16 + (c & 15)) * DLD + Cb * 16 + (r & 15)];
         }
-        __syncthreads();
-        if (t > j && t < TB) S[t * LS + j] = v;
-        if (t == j) S[j * LS + j] = xjj;
-        __syncthreads();
+        tk.T[r + (size_t)c * tk.ld] = l;
+        tk.Dinv[r + (size_t)c * TB] = xinv;
     }
-    for (int e = t; e < TB * TB; e += 256) {
-        const int r = e % TB, c = e / TB;
-        tk.Dinv[r + (size_t)c * TB] = S[r * LS + c];
-    }
+    if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
 }
 
 // ---------------------------------------------------------------------------------------------
