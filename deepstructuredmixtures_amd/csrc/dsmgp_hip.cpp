@@ -45,11 +45,81 @@ struct DevBuf {
 };
 
 struct StepLists {
-    // one phase (wave) of factorisation: per block step k the tasks for update / diag / trsm
-    std::vector<int> upd_off, diag_off, trsm_off;   // size nsteps+1
+    // one phase (wave) of factorisation: per block step k the tasks for update / split-K reduce / diag / trsm
+    std::vector<int> upd_off, red_off, diag_off, trsm_off;   // size nsteps+1
     DevBuf<TileTask> upd, trsm;
+    DevBuf<ReduceTask> red;
     DevBuf<DiagTask> diag;
     int nsteps = 0;
+};
+
+// Collects the update tiles of one block step and splits their K range over several workgroups when
+// the step has too few tiles to fill the chip (tail of the factorisation, prediction sweeps).
+// Cost model in units of one K column on one CU: a workgroup costs (K/S + C0), rounds = ceil(T*S / CUs).
+struct UpdateSplitter {
+    int ncu = 256;
+    std::vector<TileTask> upd;
+    std::vector<ReduceTask> red;
+    std::vector<int64_t> upd_slab, red_slab;   // slab index of a task's output / first slab, -1 = none
+    size_t max_slabs = 0;
+
+    static int choose_split(int T, int K, int ncu) {
+        if (T <= 0 || K < 512) return 1;
+        const double C0 = 96.0, CRED = 64.0;
+        const int chunks = K / KC;
+        auto cost = [&](int S) {
+            const double depth = (double)((chunks + S - 1) / S) * KC;
+            const double rounds = std::ceil((double)T * S / ncu);
+            return rounds * (depth + C0) + (S > 1 ? CRED : 0.0);
+        };
+        int best = 1;
+        double bc = cost(1);
+        for (int S = 2; S <= 64 && S * 256 <= K && (long)T * S <= 4096; ++S) {
+            const double c = cost(S);
+            if (c < 0.93 * bc) {
+                bc = c;
+                best = S;
+            }
+        }
+        return best;
+    }
+    // tiles: tasks with k0 = 0, k1 = K, update = 1
+    void add_step(const std::vector<TileTask>& tiles, int K) {
+        const int S = choose_split((int)tiles.size(), K, ncu);
+        if (S == 1) {
+            for (auto& t : tiles) {
+                upd.push_back(t);
+                upd_slab.push_back(-1);
+            }
+            return;
+        }
+        const int chunks = K / KC;
+        size_t slab = 0;
+        for (auto& t : tiles) {
+            ReduceTask r{};
+            r.C = t.C;
+            r.ldc = t.ldc;
+            r.nsplit = S;
+            red.push_back(r);
+            red_slab.push_back((int64_t)slab);
+            for (int s = 0; s < S; ++s) {
+                TileTask p = t;
+                p.k0 = (int)((long)chunks * s / S) * KC;
+                p.k1 = (int)((long)chunks * (s + 1) / S) * KC;
+                p.update = 0;
+                p.C = nullptr;
+                p.ldc = TB;
+                upd.push_back(p);
+                upd_slab.push_back((int64_t)slab++);
+            }
+        }
+        max_slabs = std::max(max_slabs, slab);
+    }
+    void bind(double* workspace) {
+        for (size_t i = 0; i < upd.size(); ++i)
+            if (upd_slab[i] >= 0) upd[i].C = workspace + (size_t)upd_slab[i] * TB * TB;
+        for (size_t i = 0; i < red.size(); ++i) red[i].slabs = workspace + (size_t)red_slab[i] * TB * TB;
+    }
 };
 
 }  // namespace
@@ -90,6 +160,11 @@ struct dsmgp_ctx {
 
     DevBuf<GramTask> gram;
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
+    double* slabF = nullptr;        // split-K workspace of the factorisation
+    double* slabP = nullptr;        // ... of the prediction sweep
+    int ncu = 256;
+    int stagger = 0;                // s_sleep(16) units the odd-slot partner wave is delayed by (tile_gemm_kernel)
+    int tile_variant = 2;           // 1: two-buffer kernel, 2: software-pipelined ring kernel
     std::vector<int> fwd_off, bwd_off;
     DevBuf<SolveTask> fwd, bwd;
     int solve_steps = 0;
@@ -106,8 +181,9 @@ struct dsmgp_ctx {
     double* arenaPV = nullptr;      // per leaf: mu, var (2 x ntpad)
     DevBuf<GramTask> pgram;
     DevBuf<PredTask> ptasks;
-    std::vector<int> pupd_off, ptrsm_off;
+    std::vector<int> pupd_off, pred_off, ptrsm_off;
     DevBuf<TileTask> pupd, ptrsm;
+    DevBuf<ReduceTask> pred;
     int psteps = 0;
     bool test_ready = false;
     bool predicted = false;
@@ -166,8 +242,10 @@ void free_plan(dsmgp_ctx* c) {
     for (auto& ph : c->phase) {
         dev_free(ph.upd.p);
         dev_free(ph.trsm.p);
+        dev_free(ph.red.p);
         dev_free(ph.diag.p);
     }
+    dev_free(c->slabF);
     dev_free(c->fwd.p);
     dev_free(c->bwd.p);
     c->plan_ready = false;
@@ -185,6 +263,8 @@ void free_test(dsmgp_ctx* c) {
     dev_free(c->ptasks.p);
     dev_free(c->pupd.p);
     dev_free(c->ptrsm.p);
+    dev_free(c->pred.p);
+    dev_free(c->slabP);
     c->test_ready = false;
     c->predicted = false;
 }
@@ -365,8 +445,11 @@ int build_plan(dsmgp_ctx* c) {
 
     // factorisation phases
     c->alg_flops_update = 0.0;
+    UpdateSplitter split[2];
     for (int ph = 0; ph < 2; ++ph) {
         StepLists& S = c->phase[ph];
+        UpdateSplitter& U = split[ph];
+        U.ncu = c->ncu;
         int nsteps = 0;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
@@ -375,15 +458,18 @@ int build_plan(dsmgp_ctx* c) {
             nsteps = std::max(nsteps, lf.nb);
         }
         S.nsteps = nsteps;
-        std::vector<TileTask> upd, trsm;
+        std::vector<TileTask> trsm;
         std::vector<DiagTask> diag;
         S.upd_off.assign(nsteps + 1, 0);
+        S.red_off.assign(nsteps + 1, 0);
         S.trsm_off.assign(nsteps + 1, 0);
         S.diag_off.assign(nsteps + 1, 0);
         for (int k = 0; k < nsteps; ++k) {
-            S.upd_off[k] = (int)upd.size();
+            S.upd_off[k] = (int)U.upd.size();
+            S.red_off[k] = (int)U.red.size();
             S.trsm_off[k] = (int)trsm.size();
             S.diag_off[k] = (int)diag.size();
+            std::vector<TileTask> tiles;
             for (int l = 0; l < L; ++l) {
                 const LeafHost& lf = c->leaves[l];
                 if (lf.owner != l || lf.nb <= k) continue;
@@ -400,7 +486,10 @@ int build_plan(dsmgp_ctx* c) {
                         u.B = d.F + (size_t)k * TB;
                         u.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
                         u.lda = u.ldb = u.ldc = ld;
-                        upd.push_back(u);
+                        u.k0 = 0;
+                        u.k1 = k * TB;
+                        u.update = 1;
+                        tiles.push_back(u);
                     }
                     if (i > k) {
                         TileTask s{};
@@ -410,6 +499,9 @@ int build_plan(dsmgp_ctx* c) {
                         s.lda = ld;
                         s.ldb = TB;
                         s.ldc = ld;
+                        s.k0 = 0;
+                        s.k1 = TB;
+                        s.update = 0;
                         trsm.push_back(s);
                     }
                 }
@@ -424,13 +516,23 @@ int build_plan(dsmgp_ctx* c) {
                     diag.push_back(g);
                 }
             }
+            U.add_step(tiles, k * TB);
         }
-        S.upd_off[nsteps] = (int)upd.size();
+        S.upd_off[nsteps] = (int)U.upd.size();
+        S.red_off[nsteps] = (int)U.red.size();
         S.trsm_off[nsteps] = (int)trsm.size();
         S.diag_off[nsteps] = (int)diag.size();
-        if (int rc = dev_upload(c, S.upd, upd)) return rc;
         if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
+    }
+    {
+        const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
+        if (slabs) HIPCHK(c, hipMalloc(&c->slabF, slabs * TB * TB * sizeof(double)));
+        for (int ph = 0; ph < 2; ++ph) {
+            split[ph].bind(c->slabF);
+            if (int rc = dev_upload(c, c->phase[ph].upd, split[ph].upd)) return rc;
+            if (int rc = dev_upload(c, c->phase[ph].red, split[ph].red)) return rc;
+        }
     }
     for (int l = 0; l < L; ++l)
         if (c->leaves[l].owner == l) c->alg_flops_update += update_flops(c->leaves[l].n);
@@ -499,6 +601,11 @@ int build_plan(dsmgp_ctx* c) {
     return 0;
 }
 
+void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int stagger) {
+    if (c->tile_variant == 2) tile_gemm_kernel_v2<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    else tile_gemm_kernel_t<false><<<n, 256, 0, c->stream>>>(tasks, stagger, nullptr);
+}
+
 struct PhaseTimer {
     dsmgp_ctx* c;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -528,13 +635,15 @@ struct PhaseTimer {
     }
 };
 
-// One factorisation phase: for every block step, update -> diagonal -> panel solve.
+// One factorisation phase: for every block step, update (-> split-K reduce) -> diagonal -> panel solve.
 int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
     for (int k = 0; k < S.nsteps; ++k) {
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
         if (nu > 0) {
             pt.begin(1);
-            tile_gemm_kernel<true><<<nu, 256, 0, c->stream>>>(S.upd.p + S.upd_off[k], k * TB);
+            launch_tiles(c, S.upd.p + S.upd_off[k], nu, c->stagger);
+            const int nr = S.red_off[k + 1] - S.red_off[k];
+            if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
             pt.end();
             if (count_launches) c->n_update_launches++;
         }
@@ -547,7 +656,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
         if (ns > 0) {
             pt.begin(3);
-            tile_gemm_kernel<false><<<ns, 256, 0, c->stream>>>(S.trsm.p + S.trsm_off[k], TB);
+            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns, 0);
             pt.end();
         }
     }
@@ -575,6 +684,13 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (TB * DLD + 256) * (int)sizeof(double));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+            c->ncu = prop.multiProcessorCount;
+    }
+    if (const char* s = std::getenv("DSMGP_STAGGER")) c->stagger = std::atoi(s);
+    if (const char* s = std::getenv("DSMGP_TILE_V")) c->tile_variant = std::atoi(s);
     const char* p = std::getenv("DSMGP_PROFILE");
     c->profile = p && p[0] == '1';
     *out = c;
@@ -747,7 +863,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98)
     if (c->gram.count) {
         pt.begin(0);
-        gram_tile_kernel<<<(int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
+        gram_tile_kernel<<<2 * (int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
         pt.end();
     }
     // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101)
@@ -907,12 +1023,17 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         }
     }
     c->psteps = nsteps;
-    std::vector<TileTask> upd, trsm;
+    UpdateSplitter U;
+    U.ncu = c->ncu;
+    std::vector<TileTask> trsm;
     c->pupd_off.assign(nsteps + 1, 0);
+    c->pred_off.assign(nsteps + 1, 0);
     c->ptrsm_off.assign(nsteps + 1, 0);
     for (int k = 0; k < nsteps; ++k) {
-        c->pupd_off[k] = (int)upd.size();
+        c->pupd_off[k] = (int)U.upd.size();
+        c->pred_off[k] = (int)U.red.size();
         c->ptrsm_off[k] = (int)trsm.size();
+        std::vector<TileTask> tiles;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
             if (lf.nt == 0 || lf.nb <= k) continue;
@@ -927,7 +1048,10 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                     u.lda = lf.ntpad;
                     u.ldb = lf.npad;
                     u.ldc = lf.ntpad;
-                    upd.push_back(u);
+                    u.k0 = 0;
+                    u.k1 = k * TB;
+                    u.update = 1;
+                    tiles.push_back(u);
                 }
                 TileTask s{};
                 s.A = tile;
@@ -936,16 +1060,24 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                 s.lda = lf.ntpad;
                 s.ldb = TB;
                 s.ldc = lf.ntpad;
+                s.k0 = 0;
+                s.k1 = TB;
+                s.update = 0;
                 trsm.push_back(s);
             }
         }
+        U.add_step(tiles, k * TB);
     }
-    c->pupd_off[nsteps] = (int)upd.size();
+    c->pupd_off[nsteps] = (int)U.upd.size();
+    c->pred_off[nsteps] = (int)U.red.size();
     c->ptrsm_off[nsteps] = (int)trsm.size();
+    if (U.max_slabs) HIPCHK(c, hipMalloc(&c->slabP, U.max_slabs * TB * TB * sizeof(double)));
+    U.bind(c->slabP);
+    if (int rc = dev_upload(c, c->pupd, U.upd)) return rc;
+    if (int rc = dev_upload(c, c->pred, U.red)) return rc;
+    if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
     if (int rc = dev_upload(c, c->pgram, pg)) return rc;
     if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
-    if (int rc = dev_upload(c, c->pupd, upd)) return rc;
-    if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->test_ready = true;
     return 0;
@@ -966,7 +1098,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     if (c->pgram.count) {
         // K_tn tiles and the predictive mean        (src/gaussianprocess.jl:117-118,133)
         pt.begin(6);
-        gram_tile_kernel<<<(int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
+        gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
         pred_mu_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p);
         pt.end();
         // V^T = K_tn L^-T, block column by block column (src/gaussianprocess.jl:120)
@@ -974,13 +1106,15 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
             const int nu = c->pupd_off[k + 1] - c->pupd_off[k];
             if (nu > 0) {
                 pt.begin(7);
-                tile_gemm_kernel<true><<<nu, 256, 0, c->stream>>>(c->pupd.p + c->pupd_off[k], k * TB);
+                launch_tiles(c, c->pupd.p + c->pupd_off[k], nu, c->stagger);
+                const int nr = c->pred_off[k + 1] - c->pred_off[k];
+                if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->pred.p + c->pred_off[k]);
                 pt.end();
             }
             const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
             if (ns > 0) {
                 pt.begin(8);
-                tile_gemm_kernel<false><<<ns, 256, 0, c->stream>>>(c->ptrsm.p + c->ptrsm_off[k], TB);
+                launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns, 0);
                 pt.end();
             }
         }
@@ -1066,7 +1200,7 @@ int dsmgp_kernel_matrix(dsmgp_ctx* c, int32_t kernel_id, const double* x1, int64
         }
     DevBuf<GramTask> dg;
     if (int rc = dev_upload(c, dg, g)) return rc;
-    gram_tile_kernel<<<(int)g.size(), 256, 0, c->stream>>>(dg.p, c->d_kp, D);
+    gram_tile_kernel<<<2 * (int)g.size(), 256, 0, c->stream>>>(dg.p, c->d_kp, D);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(K_out, (size_t)n1 * sizeof(double), dK, (size_t)p1 * sizeof(double), (size_t)n1 * sizeof(double),
@@ -1119,29 +1253,130 @@ int dsmgp_memory(dsmgp_ctx* c, int64_t* needed, int64_t* free_bytes) {
 }
 
 int dsmgp_probe_f64_mfma(dsmgp_ctx* c, double* tflops) {
-    if (!c || !tflops) return DSMGP_E_ARG;
+    double d[4];
+    if (!tflops) return DSMGP_E_ARG;
+    if (int rc = dsmgp_probe_f64_mfma_detail(c, 8, d)) return rc;
+    *tflops = d[0];
+    return 0;
+}
+
+// out[0] = TFLOP/s over the chip, out[1] = shader cycles per MFMA issued by one wave (median wave),
+// out[2] = shader clock in GHz held during the loop, out[3] = waves per SIMD used
+int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* c, int32_t blocks_per_cu, double* out) {
+    if (!c || !out || blocks_per_cu < 1 || blocks_per_cu > 8) return DSMGP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    hipDeviceProp_t prop;
-    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-    const int blocks = prop.multiProcessorCount * 2;   // 2 x 256 threads = 2 waves per SIMD
-    const int iters = 20000;
-    double* out = nullptr;
-    HIPCHK(c, hipMalloc(&out, (size_t)blocks * 256 * sizeof(double)));
+    const int blocks = c->ncu * blocks_per_cu;
+    const int iters = 6000 / blocks_per_cu;
+    const int nwaves = blocks * 4;
+    double* sink = nullptr;
+    unsigned long long* stamps = nullptr;
+    HIPCHK(c, hipMalloc(&sink, (size_t)blocks * 256 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&stamps, (size_t)nwaves * 2 * sizeof(unsigned long long)));
     hipEvent_t t0, t1;
     HIPCHK(c, hipEventCreate(&t0));
     HIPCHK(c, hipEventCreate(&t1));
-    mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(out, 200);
+    for (int rep = 0; rep < 3; ++rep) mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(sink, stamps, iters);
     HIPCHK(c, hipEventRecord(t0, c->stream));
-    mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(out, iters);
+    mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(sink, stamps, iters);
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
-    dev_free(out);
-    const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 4.0 /*mfma per iter*/ * 2048.0;
-    *tflops = flops / (ms * 1e-3) / 1e12;
+    std::vector<unsigned long long> hs((size_t)nwaves * 2);
+    HIPCHK(c, hipMemcpy(hs.data(), stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    dev_free(sink);
+    dev_free(stamps);
+    std::vector<double> cyc(nwaves), clk(nwaves);
+    for (int i = 0; i < nwaves; ++i) {
+        cyc[i] = (double)hs[2 * i] / ((double)iters * 16.0);
+        clk[i] = hs[2 * i + 1] ? (double)hs[2 * i] / ((double)hs[2 * i + 1] * 10.0) : 0.0;   // cycles per ns
+    }
+    std::sort(cyc.begin(), cyc.end());
+    std::sort(clk.begin(), clk.end());
+    const double flops = (double)blocks * 4.0 * (double)iters * 16.0 * 2048.0;
+    out[0] = flops / (ms * 1e-3) / 1e12;
+    out[1] = cyc[nwaves / 2];
+    out[2] = clk[nwaves / 2];   // cycles per 10 ns tick / 10 = GHz
+    out[3] = blocks_per_cu;
+    return 0;
+}
+
+// Diagnostic: steady-state rate of tile_gemm_kernel on a uniform batch (no factorisation around it).
+// mode 0: every tile has its own A panel, groups of `group` tiles share a B panel (the access pattern of
+// one block step); mode 1: all tiles read the same A and B panels (operands stay in L2).
+int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,
+                     double* seconds_per_launch) {
+    if (!c || ntiles <= 0 || K <= 0 || K % KC || !seconds_per_launch || group <= 0) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t panel = (size_t)TB * K;
+    const int nA = mode == 1 ? 1 : ntiles;
+    const int nB = mode == 1 ? 1 : (ntiles + group - 1) / group;
+    double *A = nullptr, *B = nullptr, *C = nullptr;
+    HIPCHK(c, hipMalloc(&A, nA * panel * sizeof(double)));
+    HIPCHK(c, hipMalloc(&B, nB * panel * sizeof(double)));
+    HIPCHK(c, hipMalloc(&C, (size_t)ntiles * TB * TB * sizeof(double)));
+    HIPCHK(c, hipMemset(A, 0, nA * panel * sizeof(double)));
+    HIPCHK(c, hipMemset(B, 0, nB * panel * sizeof(double)));
+    HIPCHK(c, hipMemset(C, 0, (size_t)ntiles * TB * TB * sizeof(double)));
+    {   // non-trivial operand values (random-ish, bounded)
+        std::vector<double> hv(panel);
+        for (size_t i = 0; i < panel; ++i) hv[i] = 1e-3 * (double)((i * 2654435761u) % 2001) - 1.0;
+        for (int i = 0; i < nA; ++i) HIPCHK(c, hipMemcpy(A + i * panel, hv.data(), panel * sizeof(double), hipMemcpyHostToDevice));
+        for (int i = 0; i < nB; ++i) HIPCHK(c, hipMemcpy(B + i * panel, hv.data(), panel * sizeof(double), hipMemcpyHostToDevice));
+    }
+    std::vector<TileTask> tasks(ntiles);
+    for (int i = 0; i < ntiles; ++i) {
+        TileTask t{};
+        t.A = A + (mode == 1 ? 0 : (size_t)i * panel);
+        t.B = B + (mode == 1 ? 0 : (size_t)(i / group) * panel);
+        t.C = C + (size_t)i * TB * TB;
+        t.lda = t.ldb = TB;
+        t.ldc = TB;
+        t.k0 = 0;
+        t.k1 = K;
+        t.update = 1;
+        tasks[i] = t;
+    }
+    DevBuf<TileTask> dt;
+    if (int rc = dev_upload(c, dt, tasks)) return rc;
+    hipEvent_t t0, t1;
+    HIPCHK(c, hipEventCreate(&t0));
+    HIPCHK(c, hipEventCreate(&t1));
+    launch_tiles(c, dt.p, ntiles, c->stagger);
+    HIPCHK(c, hipEventRecord(t0, c->stream));
+    for (int r = 0; r < reps; ++r) launch_tiles(c, dt.p, ntiles, c->stagger);
+    HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    *seconds_per_launch = ms * 1e-3 / reps;
+    if (std::getenv("DSMGP_STAMPS")) {
+        unsigned long long* st = nullptr;
+        HIPCHK(c, hipMalloc(&st, (size_t)ntiles * 16 * sizeof(unsigned long long)));
+        if (c->tile_variant == 2) tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
+        else tile_gemm_kernel_t<true><<<ntiles, 256, 0, c->stream>>>(dt.p, c->stagger, st);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<unsigned long long> hs((size_t)ntiles * 16);
+        HIPCHK(c, hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        dev_free(st);
+        double tot = 0, mf = 0, bd = 0, nchs = 0;
+        for (size_t i = 0; i < (size_t)ntiles * 4; ++i) {
+            tot += (double)hs[4 * i];
+            mf += (double)hs[4 * i + 1];
+            bd += (double)hs[4 * i + 2];
+            nchs += (double)hs[4 * i + 3];
+        }
+        std::fprintf(stderr, "  stamps: cycles/chunk total %.0f  mfma-span %.0f  boundary %.0f (per wave, mean)\n",
+                     tot / nchs, mf / nchs, bd / nchs);
+    }
+    dev_free(dt.p);
+    dev_free(A);
+    dev_free(B);
+    dev_free(C);
     return 0;
 }
 

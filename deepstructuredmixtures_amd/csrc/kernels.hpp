@@ -3,9 +3,9 @@
 // Everything here works on 128x128 Float64 tiles of column-major matrices whose dimensions are
 // padded to multiples of 128 (padding = identity block, see gram_tile_kernel).  One leaf GP's
 // factor F (npad x npad) is produced by a LEFT-LOOKING blocked Cholesky, batched over all leaves:
-//   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel<true>,  v_mfma_f64_16x16x4_f64)
+//   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel_t, update tasks, v_mfma_f64_16x16x4_f64)
 //            F[k,k]  = chol(F[k,k]), Dinv_k = F[k,k]^-1   (chol_diag_kernel)
-//            F[i,k]  = F[i,k] Dinv_k^T       (tile_gemm_kernel<false>)
+//            F[i,k]  = F[i,k] Dinv_k^T       (tile_gemm_kernel_t, solve tasks)
 // which is update_cholesky!/potrf! of the reference (src/gaussianprocess.jl:82-108) and, started at
 // a later column with the leading block copied, chol_continue! (src/AdvancedCholeskey.jl:152-174).
 // prediction() (src/gaussianprocess.jl:110-137) appends the test rows below the factor: V^T = K_tn L^-T
@@ -23,6 +23,12 @@ constexpr int DCH = 8;     // input dimensions staged per pass in the Gram kerne
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+// pointers read from task structs are generic to the compiler; the matrices live in global memory, and
+// saying so turns flat_load/flat_store into global_load/global_store with counted vmcnt waits
+typedef const d2 __attribute__((address_space(1)))* gd2_cptr;
+typedef double __attribute__((address_space(1)))* gf64_ptr;
+#define AS_GLOBAL_D2(p) (reinterpret_cast<gd2_cptr>(reinterpret_cast<uintptr_t>(p)))
+#define AS_GLOBAL_F64(p) (reinterpret_cast<gf64_ptr>(reinterpret_cast<uintptr_t>(p)))
 
 // ---------------------------------------------------------------------------------------------
 // kernel-function parameters (one per kernel id), derived on the host from the log-scale vector
@@ -51,24 +57,23 @@ struct GramTask {
     int kid;
 };
 
-// One 256-thread workgroup per tile: thread t owns rows 4*(t&31)..+3 and columns (t>>5)+8q, q<16,
-// so every column of the tile is written as 32 threads x 32 B = 1 KiB contiguous.
+// One 256-thread workgroup per 128x64 half tile (blockIdx = 2*task + half): thread t owns rows
+// 4*(t&31)..+3 and columns 64*half + (t>>5) + 8q, q<8, so every column is written as 32 threads x 32 B =
+// 1 KiB contiguous, and the 32 accumulators keep the kernel at 4 waves per SIMD.
 // IsoSE follows src/kernels.jl:21-27,78-83 as exp(-0.5*(z/l^2)) then * sigma^2, with z accumulated
 // from direct differences (the reference's Distances.pairwise uses |a|^2+|b|^2-2a.b; same value up to
 // rounding).  ArdSE is the additive form sigma^2 * sum_d exp(-0.5 (a_d-b_d)^2 / l_d^2)
 // (src/kernels.jl:39-49).  IsoLinear is a.b / l^2 (src/kernels.jl:189-194).
-__global__ __launch_bounds__(256) void gram_tile_kernel(const GramTask* __restrict__ tasks,
-                                                        const KParam* __restrict__ kp, int D) {
-    __shared__ double sa[DCH][TB];
-    __shared__ double sb[DCH][TB];
-    const GramTask tk = tasks[blockIdx.x];
-    const KParam p = kp[tk.kid];
+template <int KIND>
+__device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam& p, int D, int half,
+                                               double (*sa)[TB], double (*sb)[TB / 2]) {
     const int t = threadIdx.x;
     const int r0 = (t & 31) * 4;
     const int cb = t >> 5;
-    double acc[16][4];
+    const int c0 = 64 * half;
+    double acc[8][4];
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[q][j] = 0.0;
 
@@ -78,22 +83,25 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const GramTask* __restri
         for (int e = t; e < dn * TB; e += 256) {
             const int d = e / TB, r = e % TB;
             sa[d][r] = (r < tk.na) ? tk.xa[r + (size_t)(d0 + d) * tk.lda] : 0.0;
-            sb[d][r] = (r < tk.nb) ? tk.xb[r + (size_t)(d0 + d) * tk.ldb] : 0.0;
+        }
+        for (int e = t; e < dn * (TB / 2); e += 256) {
+            const int d = e / (TB / 2), r = e % (TB / 2);
+            sb[d][r] = (c0 + r < tk.nb) ? tk.xb[c0 + r + (size_t)(d0 + d) * tk.ldb] : 0.0;
         }
         __syncthreads();
         for (int d = 0; d < dn; ++d) {
             const double a0 = sa[d][r0], a1 = sa[d][r0 + 1], a2 = sa[d][r0 + 2], a3 = sa[d][r0 + 3];
-            const double l2d = (p.kind == 1) ? p.l2[d0 + d] : 1.0;
+            const double l2d = (KIND == 1) ? p.l2[d0 + d] : 1.0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 const double b = sb[d][cb + 8 * q];
-                if (p.kind == 0) {
+                if (KIND == 0) {
                     double u;
                     u = a0 - b; acc[q][0] = fma(u, u, acc[q][0]);
                     u = a1 - b; acc[q][1] = fma(u, u, acc[q][1]);
                     u = a2 - b; acc[q][2] = fma(u, u, acc[q][2]);
                     u = a3 - b; acc[q][3] = fma(u, u, acc[q][3]);
-                } else if (p.kind == 1) {
+                } else if (KIND == 1) {
                     double u;
                     u = a0 - b; acc[q][0] += exp(-0.5 * ((u * u) / l2d));
                     u = a1 - b; acc[q][1] += exp(-0.5 * ((u * u) / l2d));
@@ -110,43 +118,69 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const GramTask* __restri
     }
     const double l2 = p.l2[0];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = cb + 8 * q;
+    for (int q = 0; q < 8; ++q) {
+        const int c = c0 + cb + 8 * q;
         d4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = r0 + j;
-            double k;
-            if (p.kind == 0) k = p.sigma2 * exp(-0.5 * (acc[q][j] / l2));
-            else if (p.kind == 1) k = p.sigma2 * acc[q][j];
-            else k = acc[q][j] / l2;
+            double kv;
+            if (KIND == 0) kv = p.sigma2 * exp(-0.5 * (acc[q][j] / l2));
+            else if (KIND == 1) kv = p.sigma2 * acc[q][j];
+            else kv = acc[q][j] / l2;
             const bool valid = (r < tk.na) && (c < tk.nb);
-            if (!valid) k = 0.0;
-            if (tk.sym && tk.diag && r == c) k = valid ? k + (p.noise + 1e-8) : 1.0;
-            v[j] = k;
+            if (!valid) kv = 0.0;
+            if (tk.sym && tk.diag && r == c) kv = valid ? kv + (p.noise + 1e-8) : 1.0;
+            v[j] = kv;
         }
         *reinterpret_cast<d4*>(tk.out + r0 + (size_t)c * tk.ldo) = v;
     }
 }
 
+__global__ __launch_bounds__(256) void gram_tile_kernel(const GramTask* __restrict__ tasks,
+                                                        const KParam* __restrict__ kp, int D) {
+    __shared__ double sa[DCH][TB];
+    __shared__ double sb[DCH][TB / 2];
+    const GramTask tk = tasks[blockIdx.x >> 1];
+    const KParam p = kp[tk.kid];
+    const int half = blockIdx.x & 1;
+    if (p.kind == 0) gram_half_tile<0>(tk, p, D, half, sa, sb);
+    else if (p.kind == 1) gram_half_tile<1>(tk, p, D, half, sa, sb);
+    else gram_half_tile<2>(tk, p, D, half, sa, sb);
+}
+
 // ---------------------------------------------------------------------------------------------
-// 128x128 tile GEMM on the f64 matrix cores:  C = (UPDATE ? C : 0) -/+ A B^T,  K uniform per launch.
+// 128x128 tile GEMM on the f64 matrix cores:  C = (update ? C : 0) -/+ sum_{kk in [k0,k1)} A(:,kk) B(:,kk)^T
 //   A(r,kk) = A[r + kk*lda]   (tile rows, r < 128)      B(c,kk) = B[c + kk*ldb]   (tile columns)
 // 4 waves in a 2x2 grid, each owning a 64x64 sub-tile = 4x4 MFMA tiles of 16x16.
 // v_mfma_f64_16x16x4_f64: lane l supplies Aop[i=l&15][k=l>>4], Bop[k=l>>4][j=l&15] and receives
 // D[(l>>4)+4r][l&15], r<4.  The tile COLUMN index is put on the MFMA row (Aop <- B matrix) and the tile
 // ROW index on the MFMA column (Bop <- A matrix), so that the 16 lanes l&15 of a result register are 16
 // consecutive rows = 128 contiguous bytes of the column-major tile.
+// One task = one tile and one K range.  Three uses:
+//   update : F[i,k] -= F[i,0:K] F[k,0:K]^T                       (update = 1, whole K range)
+//   partial: slab    = F[i,Ka:Kb] F[k,Ka:Kb]^T                    (update = 0; split-K, summed by tile_reduce_kernel)
+//   solve  : F[i,k]  = F[i,k] Dinv_k^T                            (update = 0, K = 128)
 struct TileTask {
     const double* A;
     const double* B;
     double* C;
     int lda, ldb, ldc;
-    int pad;
+    int k0, k1;      // K range, multiples of KC
+    int update;
 };
 
-template <bool UPDATE>
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileTask* __restrict__ tasks, int K) {
+// STAMP = true is a diagnostic build (tools/bench_tile.py): wave 0 of every workgroup accumulates shader
+// cycles spent in the MFMA stream of each chunk and at the chunk boundary; never used by fit!/predict.
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_t(const TileTask* __restrict__ tasks, int stagger,
+                                                             unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) double sA[2][KC * LDP];
     __shared__ __attribute__((aligned(16))) double sB[2][KC * LDP];
     const TileTask tk = tasks[blockIdx.x];
@@ -164,15 +198,15 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileTask* __res
 
     // staging: instruction q moves column kk = 4q + w of the chunk, rows 2*lane, 2*lane+1 (1 KiB per wave)
     d2 ra[4], rb[4];
-    const double* gA = tk.A + 2 * lane + (size_t)w * tk.lda;
-    const double* gB = tk.B + 2 * lane + (size_t)w * tk.ldb;
+    const double* gA = tk.A + 2 * lane + (size_t)(tk.k0 + w) * tk.lda;
+    const double* gB = tk.B + 2 * lane + (size_t)(tk.k0 + w) * tk.ldb;
     const int sOff = w * LDP + 2 * lane;
 
-    auto gload = [&](int k0) {
+    auto gload = [&](int kk) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ra[q] = *reinterpret_cast<const d2*>(gA + (size_t)(k0 + 4 * q) * tk.lda);
-            rb[q] = *reinterpret_cast<const d2*>(gB + (size_t)(k0 + 4 * q) * tk.ldb);
+            ra[q] = *AS_GLOBAL_D2(gA + (size_t)(kk + 4 * q) * tk.lda);
+            rb[q] = *AS_GLOBAL_D2(gB + (size_t)(kk + 4 * q) * tk.ldb);
         }
     };
     auto swrite = [&](int buf) {
@@ -183,14 +217,30 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileTask* __res
         }
     };
 
-    const int nch = K / KC;
+    const int nch = (tk.k1 - tk.k0) / KC;
     if (nch > 0) {
         gload(0);
         swrite(0);
     }
+    // Two workgroups share a CU (two waves per SIMD) and run the same program: left alone they reach the
+    // chunk-boundary barrier together and the matrix pipe idles.  Delay the wave in the odd hardware slot
+    // by about half a chunk once, so one partner is in its MFMA stream while the other crosses the barrier.
+    if (stagger > 0 && nch > 8) {
+        const int wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // HW_ID.WAVE_ID
+        if (wave_slot & 1) {
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     __syncthreads();
+    unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0;
+    if (STAMP) tin = stamp_now();
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            ta = stamp_now();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (c + 1 < nch) gload((c + 1) * KC);
         const double* pa = &sB[buf][l4 * LDP + wc * 64 + l15];   // MFMA A operand <- tile columns
         const double* pb = &sA[buf][l4 * LDP + wr * 64 + l15];   // MFMA B operand <- tile rows
@@ -208,8 +258,27 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileTask* __res
                 for (int rn = 0; rn < 4; ++rn)
                     acc[cm][rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cm], fb[rn], acc[cm][rn], 0, 0, 0);
         }
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            tb = stamp_now();
+            __builtin_amdgcn_sched_barrier(0);
+            tmf += tb - ta;
+        }
         if (c + 1 < nch) swrite(buf ^ 1);
         __syncthreads();
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            tbd += stamp_now() - tb;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (STAMP && (t & 63) == 0) {
+        const unsigned long long tout = stamp_now();
+        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + w) * 4;
+        s[0] = tout - tin;
+        s[1] = tmf;
+        s[2] = tbd;
+        s[3] = nch;
     }
 
     // epilogue: register r of acc[cm][rn] is C(row = wr*64+16rn+l15, col = wc*64+16cm+l4+4r)
@@ -219,10 +288,166 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileTask* __res
         for (int rn = 0; rn < 4; ++rn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double* pc = tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc;
-                if (UPDATE) *pc = *pc - acc[cm][rn][r];
+                gf64_ptr pc = AS_GLOBAL_F64(tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc);
+                if (tk.update) *pc = *pc - acc[cm][rn][r];
                 else *pc = acc[cm][rn][r];
             }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined form of the same tile GEMM (same TileTask contract, same result bits per chunk order).
+//   - K is consumed in chunks of 8 columns (two 16-MFMA groups per wave) held in a 4-deep LDS ring
+//   - the MFMA operand fragments of the NEXT group are read from LDS while the current group's 16 MFMAs
+//     issue, also across the chunk boundary (the next chunk is already complete and visible in the ring)
+//   - global loads run two chunks ahead of their LDS write, in two alternating register sets
+//   - one barrier per chunk, with nothing else waiting at it
+constexpr int KC2 = 8;
+constexpr int NRING = 4;
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
+                                                              unsigned long long* __restrict__ stamps) {
+    __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
+    __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
+    const TileTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wr = w & 1, wc = w >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn) acc[cm][rn] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // staging: thread t moves column (t>>5) of the chunk, rows 2*(t&31) + 64j, j<2 (512 B per half wave)
+    const int scol = t >> 5, srow = 2 * (t & 31);
+    const double* gA = tk.A + srow + (size_t)(tk.k0 + scol) * tk.lda;
+    const double* gB = tk.B + srow + (size_t)(tk.k0 + scol) * tk.ldb;
+    const int sOff = scol * LDP + srow;
+    d2 ra0[2], rb0[2], ra1[2], rb1[2];
+
+#define GLOAD(RA, RB, CH)                                                                        \
+    do {                                                                                         \
+        const size_t oa_ = (size_t)(CH) * KC2 * tk.lda, ob_ = (size_t)(CH) * KC2 * tk.ldb;       \
+        RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
+        RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                                    \
+        RB[0] = *AS_GLOBAL_D2(gB + ob_);                                                         \
+        RB[1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                                    \
+    } while (0)
+#define SWRITE(RA, RB, BUF)                                                                      \
+    do {                                                                                         \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA[0];                                          \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                                     \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff]) = RB[0];                                          \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = RB[1];                                     \
+    } while (0)
+#define FRAGS(FA, FB, BUF, G)                                                                    \
+    do {                                                                                         \
+        const double* pa_ = &sB[BUF][((G) * 4 + l4) * LDP + wc * 64 + l15];                      \
+        const double* pb_ = &sA[BUF][((G) * 4 + l4) * LDP + wr * 64 + l15];                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
+            FA[i_] = pa_[16 * i_];                                                               \
+            FB[i_] = pb_[16 * i_];                                                               \
+        }                                                                                        \
+    } while (0)
+#define MFMA16(FA, FB)                                                                           \
+    do {                                                                                         \
+        _Pragma("unroll") for (int cm_ = 0; cm_ < 4; ++cm_)                                      \
+            _Pragma("unroll") for (int rn_ = 0; rn_ < 4; ++rn_)                                  \
+                acc[cm_][rn_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[cm_], FB[rn_], acc[cm_][rn_], 0, 0, 0); \
+    } while (0)
+
+    const int nch = (tk.k1 - tk.k0) / KC2;
+    // prologue: chunks 0..2 into the ring, chunk 3 in flight in set 1
+    for (int j = 0; j < 3 && j < nch; ++j) {
+        GLOAD(ra0, rb0, j);
+        SWRITE(ra0, rb0, j);
+    }
+    if (nch > 0) GLOAD(ra1, rb1, min(3, nch - 1));
+    __syncthreads();
+
+    double fa0[4], fb0[4], fa1[4], fb1[4];
+    if (nch > 0) FRAGS(fa0, fb0, 0, 0);
+    unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0;
+    if (STAMP) tin = stamp_now();
+
+    // one chunk: LOADSET receives chunk c+4, WRITESET (holding chunk c+3) goes to the ring
+#define CHUNK(C, LRA, LRB, WRA, WRB)                                                             \
+    do {                                                                                         \
+        const int c_ = (C);                                                                      \
+        const int buf_ = c_ & (NRING - 1);                                                       \
+        if (STAMP) { __builtin_amdgcn_sched_barrier(0); ta = stamp_now(); }                      \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        GLOAD(LRA, LRB, min(c_ + 4, nch - 1)); /* clamped: keeps the vmcnt counts static */      \
+        FRAGS(fa1, fb1, buf_, 1);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MFMA16(fa0, fb0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        SWRITE(WRA, WRB, (c_ + 3) & (NRING - 1)); /* past the end: lands in an unread slot */    \
+        FRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MFMA16(fa1, fb1);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (STAMP) { tb = stamp_now(); __builtin_amdgcn_sched_barrier(0); tmf += tb - ta; }      \
+        __syncthreads();                                                                         \
+        if (STAMP) { __builtin_amdgcn_sched_barrier(0); tbd += stamp_now() - tb; __builtin_amdgcn_sched_barrier(0); } \
+    } while (0)
+
+    int c = 0;
+    for (; c + 1 < nch; c += 2) {
+        CHUNK(c, ra0, rb0, ra1, rb1);
+        CHUNK(c + 1, ra1, rb1, ra0, rb0);
+    }
+    if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
+#undef CHUNK
+#undef MFMA16
+#undef FRAGS
+#undef SWRITE
+#undef GLOAD
+
+    if (STAMP && (t & 63) == 0) {
+        const unsigned long long tout = stamp_now();
+        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + w) * 4;
+        s[0] = tout - tin;
+        s[1] = tmf;
+        s[2] = tbd;
+        s[3] = nch / 2;
+    }
+
+#pragma unroll
+    for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gf64_ptr pc = AS_GLOBAL_F64(tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc);
+                if (tk.update) *pc = *pc - acc[cm][rn][r];
+                else *pc = acc[cm][rn][r];
+            }
+}
+
+// split-K epilogue: tile -= slab_0 + slab_1 + ... (fixed order, so results are bit-reproducible)
+struct ReduceTask {
+    double* C;
+    const double* slabs;   // nsplit consecutive 128x128 slabs, ld 128
+    int ldc;
+    int nsplit;
+};
+
+__global__ __launch_bounds__(256) void tile_reduce_kernel(const ReduceTask* __restrict__ tasks) {
+    const ReduceTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x;
+    const int r = (t & 63) * 2;
+#pragma unroll 4
+    for (int c = t >> 6; c < TB; c += 4) {
+        d2 s = {0.0, 0.0};
+        for (int q = 0; q < tk.nsplit; ++q) s += *reinterpret_cast<const d2*>(tk.slabs + (size_t)q * TB * TB + r + c * TB);
+        d2* pc = reinterpret_cast<d2*>(tk.C + r + (size_t)c * tk.ldc);
+        *pc = *pc - s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -593,17 +818,34 @@ __global__ __launch_bounds__(256) void pred_var_kernel(const LeafDev* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// f64 MFMA issue-rate probe: register-only chains, 4 independent accumulators per wave
-__global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, int iters) {
-    d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+// f64 MFMA issue-rate probe: register-only chains, 4 independent accumulators per wave.  Lane 0 of
+// every wave also records shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) so the
+// host can report cycles per MFMA and the clock the chip holds under this load.
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned long long* stamps, int iters) {
+    // 16 independent accumulators per wave (as in tile_gemm_kernel); inline asm keeps them in VGPRs
+    d4 a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = (d4){0.0, 0.0, 0.0, 0.0};
     const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
-    for (int i = 0; i < iters; ++i) {
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    double sink = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sink += a[i][i & 3];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sink;
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        stamps[2 * wv] = c1 - c0;
+        stamps[2 * wv + 1] = r1 - r0;
+    }
 }
 
 }  // namespace dsmgp

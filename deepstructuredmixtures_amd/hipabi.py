@@ -41,6 +41,8 @@ SIGNATURES = {
     "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
+    "dsmgp_probe_f64_mfma_detail": (C.c_int, [_ctx, C.c_int32, _dp]),
+    "dsmgp_bench_tile": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
 }
 
 _lib = None
@@ -222,6 +224,18 @@ class Context:
         b = C.c_int64(0)
         self._chk(self.lib.dsmgp_memory(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def probe_f64_mfma_detail(self, blocks_per_cu=4):
+        """dict(tflops, cycles_per_mfma, clock_ghz, waves_per_simd) of a register-only f64 MFMA loop."""
+        out = np.zeros(4)
+        self._chk(self.lib.dsmgp_probe_f64_mfma_detail(self.h, int(blocks_per_cu), out.ctypes.data_as(_dp)))
+        return dict(zip(("tflops", "cycles_per_mfma", "clock_ghz", "waves_per_simd"), out.tolist()))
+
+    def bench_tile(self, ntiles, K, mode=0, group=16, reps=3):
+        """TFLOP/s of the tile GEMM on a uniform batch (diagnostic)."""
+        s = C.c_double(0.0)
+        self._chk(self.lib.dsmgp_bench_tile(self.h, int(ntiles), int(K), int(mode), int(group), int(reps), C.byref(s)))
+        return 2.0 * 128 * 128 * K * ntiles / s.value / 1e12
 
     def probe_f64_mfma(self):
         t = C.c_double(0.0)

@@ -119,6 +119,14 @@ int dsmgp_memory(dsmgp_ctx* ctx, int64_t* needed, int64_t* free_bytes);
 /* f64 MFMA issue-rate probe used for the roofline peak (bench.py): returns TFLOP/s of a register-only
  * v_mfma_f64_16x16x4_f64 loop over the whole chip */
 int dsmgp_probe_f64_mfma(dsmgp_ctx* ctx, double* tflops);
+/* out[0] TFLOP/s, out[1] shader cycles per MFMA per wave, out[2] shader clock (GHz) held in the loop,
+ * out[3] = blocks_per_cu (256-thread workgroups per CU, i.e. waves per SIMD) */
+int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* ctx, int32_t blocks_per_cu, double* out);
+
+/* diagnostic: seconds per launch of the tile GEMM on a uniform batch of ntiles tiles of depth K
+ * (mode 0: own A panel per tile, B panel shared by `group` tiles; mode 1: all operands shared, L2-resident) */
+int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,
+                     double* seconds_per_launch);
 
 #ifdef __cplusplus
 }
