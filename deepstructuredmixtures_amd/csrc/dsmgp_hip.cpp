@@ -56,8 +56,29 @@ struct StepLists {
 // Collects the update tiles of one block step and splits their K range over several workgroups when
 // the step has too few tiles to fill the chip (tail of the factorisation, prediction sweeps).
 // Cost model in units of one K column on one CU: a workgroup costs (K/S + C0), rounds = ceil(T*S / CUs).
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its L2), so a run
+// of tasks that read the same B panel should sit at positions x, x+8, x+16, ...  Reorder [begin,end) so
+// that XCD slot x receives a contiguous chunk of the natural (leaf-major) order.  Speed only.
+template <class T, class U>
+void xcd_permute(std::vector<T>& a, std::vector<U>& b, size_t begin, size_t end, bool enable) {
+    const size_t n = end - begin;
+    if (!enable || n < 16) return;
+    const size_t q = n / 8, r = n % 8;
+    std::vector<T> ta(a.begin() + begin, a.begin() + end);
+    std::vector<U> tb(b.begin() + begin, b.begin() + end);
+    size_t src = 0;
+    for (size_t x = 0; x < 8; ++x) {
+        const size_t len = q + (x < r ? 1 : 0);
+        for (size_t j = 0; j < len; ++j, ++src) {
+            a[begin + x + 8 * j] = ta[src];
+            b[begin + x + 8 * j] = tb[src];
+        }
+    }
+}
+
 struct UpdateSplitter {
     int ncu = 256;
+    bool xcd = true;
     std::vector<TileTask> upd;
     std::vector<ReduceTask> red;
     std::vector<int64_t> upd_slab, red_slab;   // slab index of a task's output / first slab, -1 = none
@@ -86,34 +107,39 @@ struct UpdateSplitter {
     // tiles: tasks with k0 = 0, k1 = K, update = 1
     void add_step(const std::vector<TileTask>& tiles, int K) {
         const int S = choose_split((int)tiles.size(), K, ncu);
+        const size_t begin = upd.size();
         if (S == 1) {
             for (auto& t : tiles) {
                 upd.push_back(t);
                 upd_slab.push_back(-1);
             }
+            xcd_permute(upd, upd_slab, begin, upd.size(), xcd);
             return;
         }
         const int chunks = K / KC;
-        size_t slab = 0;
-        for (auto& t : tiles) {
+        const size_t T = tiles.size();
+        for (size_t i = 0; i < T; ++i) {
             ReduceTask r{};
-            r.C = t.C;
-            r.ldc = t.ldc;
+            r.C = tiles[i].C;
+            r.ldc = tiles[i].ldc;
             r.nsplit = S;
             red.push_back(r);
-            red_slab.push_back((int64_t)slab);
-            for (int s = 0; s < S; ++s) {
-                TileTask p = t;
+            red_slab.push_back((int64_t)(i * S));
+        }
+        // split-major order: tasks with the same K range (and, per leaf, the same B panel) stay adjacent
+        for (int s = 0; s < S; ++s)
+            for (size_t i = 0; i < T; ++i) {
+                TileTask p = tiles[i];
                 p.k0 = (int)((long)chunks * s / S) * KC;
                 p.k1 = (int)((long)chunks * (s + 1) / S) * KC;
                 p.update = 0;
                 p.C = nullptr;
                 p.ldc = TB;
                 upd.push_back(p);
-                upd_slab.push_back((int64_t)slab++);
+                upd_slab.push_back((int64_t)(i * S + s));
             }
-        }
-        max_slabs = std::max(max_slabs, slab);
+        xcd_permute(upd, upd_slab, begin, upd.size(), xcd);
+        max_slabs = std::max(max_slabs, T * (size_t)S);
     }
     void bind(double* workspace) {
         for (size_t i = 0; i < upd.size(); ++i)
@@ -165,6 +191,7 @@ struct dsmgp_ctx {
     int ncu = 256;
     int stagger = 0;                // s_sleep(16) units the odd-slot partner wave is delayed by (tile_gemm_kernel)
     int tile_variant = 2;           // 1: two-buffer kernel, 2: software-pipelined ring kernel
+    bool xcd_order = true;          // XCD-aware task order (speed only)
     std::vector<int> fwd_off, bwd_off;
     DevBuf<SolveTask> fwd, bwd;
     int solve_steps = 0;
@@ -450,6 +477,7 @@ int build_plan(dsmgp_ctx* c) {
         StepLists& S = c->phase[ph];
         UpdateSplitter& U = split[ph];
         U.ncu = c->ncu;
+        U.xcd = c->xcd_order;
         int nsteps = 0;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
@@ -602,6 +630,19 @@ int build_plan(dsmgp_ctx* c) {
 }
 
 void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int stagger) {
+    if (c->tile_variant >= 100) {   // ablation builds, micro-benchmark only
+        switch (c->tile_variant - 100) {
+            case 1: tile_gemm_kernel_v2<false, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+            case 2: tile_gemm_kernel_v2<false, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+            case 3: tile_gemm_kernel_v2<false, 3><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+            case 4: tile_gemm_kernel_v2<false, 4><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+            case 5: tile_gemm_kernel_v2<false, 5><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+            case 6: tile_gemm_kernel_v2<false, 6><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+            case 8: tile_gemm_kernel_v2<false, 8><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+            default: tile_gemm_kernel_v2<false, 7><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
+        }
+        return;
+    }
     if (c->tile_variant == 2) tile_gemm_kernel_v2<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
     else tile_gemm_kernel_t<false><<<n, 256, 0, c->stream>>>(tasks, stagger, nullptr);
 }
@@ -691,6 +732,7 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     }
     if (const char* s = std::getenv("DSMGP_STAGGER")) c->stagger = std::atoi(s);
     if (const char* s = std::getenv("DSMGP_TILE_V")) c->tile_variant = std::atoi(s);
+    if (const char* s = std::getenv("DSMGP_XCD")) c->xcd_order = std::atoi(s) != 0;
     const char* p = std::getenv("DSMGP_PROFILE");
     c->profile = p && p[0] == '1';
     *out = c;
@@ -1025,6 +1067,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     c->psteps = nsteps;
     UpdateSplitter U;
     U.ncu = c->ncu;
+    U.xcd = c->xcd_order;
     std::vector<TileTask> trsm;
     c->pupd_off.assign(nsteps + 1, 0);
     c->pred_off.assign(nsteps + 1, 0);
@@ -1338,6 +1381,10 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
         t.k1 = K;
         t.update = 1;
         tasks[i] = t;
+    }
+    {
+        std::vector<int> dummy(tasks.size());
+        xcd_permute(tasks, dummy, 0, tasks.size(), c->xcd_order && mode == 0);
     }
     DevBuf<TileTask> dt;
     if (int rc = dev_upload(c, dt, tasks)) return rc;

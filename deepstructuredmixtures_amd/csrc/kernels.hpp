@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_t(const TileTask* __r
 constexpr int KC2 = 8;
 constexpr int NRING = 4;
 
-template <bool STAMP>
+// ABL is an ablation mask for tools/bench_tile.py only (results are wrong when it is non-zero):
+//   1 = no global loads / LDS writes in the loop, 2 = no barrier in the loop, 4 = no fragment reads in the loop,
+//   8 = global loads kept but their LDS writes dropped
+template <bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
                                                               unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
@@ -371,28 +374,46 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
 
     double fa0[4], fb0[4], fa1[4], fb1[4];
     if (nch > 0) FRAGS(fa0, fb0, 0, 0);
+    if (ABL & 4) FRAGS(fa1, fb1, 0, 1);
     unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0;
     if (STAMP) tin = stamp_now();
 
     // one chunk: LOADSET receives chunk c+4, WRITESET (holding chunk c+3) goes to the ring
+    // Issue order inside a chunk: every memory instruction sits in the shadow of an MFMA (64 cycles in the
+    // matrix pipe, during which the wave may issue other work); clustering them ahead of the MFMAs leaves the
+    // pipe idle while they issue.  Group 0: 4 global loads + 4 ds_read2 between the first 8 MFMAs;
+    // group 1: 4 ds_write + 4 ds_read2 likewise.
+#define INTERLEAVE(MASK_A, MASK_B)                                                               \
+    do {                                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(MASK_A, 1, 0);                                  \
+        }                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(MASK_B, 1, 0);                                  \
+        }                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                       \
+    } while (0)
 #define CHUNK(C, LRA, LRB, WRA, WRB)                                                             \
     do {                                                                                         \
         const int c_ = (C);                                                                      \
         const int buf_ = c_ & (NRING - 1);                                                       \
         if (STAMP) { __builtin_amdgcn_sched_barrier(0); ta = stamp_now(); }                      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        GLOAD(LRA, LRB, min(c_ + 4, nch - 1)); /* clamped: keeps the vmcnt counts static */      \
-        FRAGS(fa1, fb1, buf_, 1);                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (!(ABL & 1)) GLOAD(LRA, LRB, min(c_ + 4, nch - 1)); /* clamped: static vmcnt counts */ \
+        if (!(ABL & 4)) FRAGS(fa1, fb1, buf_, 1);                                                \
         MFMA16(fa0, fb0);                                                                        \
+        if (!ABL) INTERLEAVE(0x020, 0x100);                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        SWRITE(WRA, WRB, (c_ + 3) & (NRING - 1)); /* past the end: lands in an unread slot */    \
-        FRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (!(ABL & 1) && !(ABL & 8)) SWRITE(WRA, WRB, (c_ + 3) & (NRING - 1)); /* past the end: unread slot */ \
+        if (ABL & 8) { asm volatile("" ::"v"(WRA[0]), "v"(WRA[1]), "v"(WRB[0]), "v"(WRB[1])); }  \
+        if (!(ABL & 4)) FRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                              \
         MFMA16(fa1, fb1);                                                                        \
+        if (!ABL) INTERLEAVE(0x200, 0x100);                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         if (STAMP) { tb = stamp_now(); __builtin_amdgcn_sched_barrier(0); tmf += tb - ta; }      \
-        __syncthreads();                                                                         \
+        if (!(ABL & 2)) __syncthreads();                                                         \
         if (STAMP) { __builtin_amdgcn_sched_barrier(0); tbd += stamp_now() - tb; __builtin_amdgcn_sched_barrier(0); } \
     } while (0)
 
@@ -403,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
     }
     if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
 #undef CHUNK
+#undef INTERLEAVE
 #undef MFMA16
 #undef FRAGS
 #undef SWRITE
