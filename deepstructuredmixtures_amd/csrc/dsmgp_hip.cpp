@@ -116,7 +116,6 @@ struct UpdateSplitter {
             xcd_permute(upd, upd_slab, begin, upd.size(), xcd);
             return;
         }
-        const int chunks = K / KC;
         const size_t T = tiles.size();
         for (size_t i = 0; i < T; ++i) {
             ReduceTask r{};
@@ -130,8 +129,9 @@ struct UpdateSplitter {
         for (int s = 0; s < S; ++s)
             for (size_t i = 0; i < T; ++i) {
                 TileTask p = tiles[i];
-                p.k0 = (int)((long)chunks * s / S) * KC;
-                p.k1 = (int)((long)chunks * (s + 1) / S) * KC;
+                const long chunks = (tiles[i].k1 - tiles[i].k0) / KC;   // this tile's own K range
+                p.k0 = tiles[i].k0 + (int)(chunks * s / S) * KC;
+                p.k1 = tiles[i].k0 + (int)(chunks * (s + 1) / S) * KC;
                 p.update = 0;
                 p.C = nullptr;
                 p.ldc = TB;
@@ -216,6 +216,23 @@ struct dsmgp_ctx {
     bool predicted = false;
     int64_t route_total = 0;
 
+    // gradients (built on first use)
+    bool grad_ready = false;
+    double* arenaX = nullptr;       // Xt = L^-T per factor owner, npad x npad
+    size_t arenaX_count = 0;
+    double* slabG = nullptr;
+    DevBuf<TransTask> gtrans;
+    std::vector<int> gupd_off, gred_off, gtrsm_off;
+    DevBuf<TileTask> gupd, gtrsm;
+    DevBuf<ReduceTask> gred;
+    int gsteps = 0;
+    DevBuf<FrobTask> gfrob;
+    std::vector<int> gfrob_leaf;    // owner leaf of each frob task
+    DevBuf<GradTask> gdot;
+    std::vector<int> gdot_leaf;     // leaf of each graddot task
+    double* d_gpart = nullptr;      // partial results: frob | graddot pairs | per-leaf dots
+    size_t gpart_count = 0;
+
     double timings[DSMGP_N_TIMINGS] = {0};
     double alg_flops_update = 0.0;  // algorithmic flops of the Cholesky update launches
     int n_update_launches = 0;
@@ -257,6 +274,19 @@ void dev_free(T*& p) {
     p = nullptr;
 }
 
+void free_grad(dsmgp_ctx* c) {
+    dev_free(c->arenaX);
+    dev_free(c->slabG);
+    dev_free(c->gtrans.p);
+    dev_free(c->gupd.p);
+    dev_free(c->gtrsm.p);
+    dev_free(c->gred.p);
+    dev_free(c->gfrob.p);
+    dev_free(c->gdot.p);
+    dev_free(c->d_gpart);
+    c->grad_ready = false;
+}
+
 void free_plan(dsmgp_ctx* c) {
     dev_free(c->arenaF);
     dev_free(c->arenaDinv);
@@ -275,6 +305,7 @@ void free_plan(dsmgp_ctx* c) {
     dev_free(c->slabF);
     dev_free(c->fwd.p);
     dev_free(c->bwd.p);
+    free_grad(c);
     c->plan_ready = false;
     c->fitted = false;
 }
@@ -876,6 +907,7 @@ int dsmgp_set_hyper(dsmgp_ctx* c, int32_t kernel_id, int32_t kind, const double*
     for (int i = 0; i < n; ++i)
         if (!std::isfinite(loghyp[i])) return fail(c, DSMGP_E_ARG, "set_hyper: non-finite hyper-parameter");
     if ((int)c->hyper.size() <= kernel_id) c->hyper.resize(kernel_id + 1);
+    if (c->hyper[kernel_id].kind != kind) free_grad(c);   // the contraction tiles depend on the kernel kind
     c->hyper[kernel_id].kind = kind;
     c->hyper[kernel_id].loghyp.assign(loghyp, loghyp + n);
     c->fitted = false;
@@ -1202,11 +1234,237 @@ int dsmgp_predict_leaves(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int6
     return dsmgp_predict_fetch(c, mu_out, var_out);
 }
 
+namespace {
+
+// Task lists of the gradient pass: Xt = L^-T by a blocked triangular inversion on the same tile kernels
+// (row tile t of Xt is e_t^T L^-T: zero left of block t, Dinv_t^T on the diagonal, then a left-looking sweep
+// whose K range starts at column 128 t), then the contraction tiles of tile_graddot_kernel.
+int build_grad_plan(dsmgp_ctx* c) {
+    const int L = c->L;
+    size_t xTot = 0;
+    std::vector<size_t> xoff(L, 0);
+    for (int l = 0; l < L; ++l)
+        if (c->leaves[l].owner == l) {
+            xoff[l] = xTot;
+            xTot += (size_t)c->leaves[l].npad * c->leaves[l].npad;
+        }
+    size_t freeB = 0, totalB = 0;
+    HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+    if (xTot * sizeof(double) + (size_t(2) << 30) > freeB)
+        return fail(c, DSMGP_E_NOMEM, "gradients need " + std::to_string((xTot * 8) >> 20) + " MiB for L^-1, device has " +
+                                          std::to_string(freeB >> 20) + " MiB free");
+    HIPCHK(c, hipMalloc(&c->arenaX, std::max<size_t>(1, xTot) * sizeof(double)));
+    c->arenaX_count = xTot;
+    auto Xt = [&](int l) { return c->arenaX + xoff[c->leaves[l].owner]; };
+
+    std::vector<TransTask> trans;
+    std::vector<FrobTask> frob;
+    c->gfrob_leaf.clear();
+    int nsteps = 0;
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (lf.owner != l) continue;
+        nsteps = std::max(nsteps, lf.nb);
+        const LeafDev& d = c->h_leaves[l];
+        for (int t = 0; t < lf.nb; ++t) {
+            TransTask tt{};
+            tt.src = d.Dinv + (size_t)t * TB * TB;
+            tt.dst = Xt(l) + (size_t)t * TB + (size_t)t * TB * lf.npad;
+            tt.ldd = lf.npad;
+            trans.push_back(tt);
+            FrobTask f{};
+            f.X = Xt(l) + (size_t)t * TB;
+            f.ld = lf.npad;
+            f.col0 = t * TB;
+            f.col1 = lf.npad;
+            f.nrows = std::max(0, std::min(TB, lf.n - t * TB));
+            f.n = lf.n;
+            frob.push_back(f);
+            c->gfrob_leaf.push_back(l);
+        }
+    }
+    c->gsteps = nsteps;
+    UpdateSplitter U;
+    U.ncu = c->ncu;
+    U.xcd = c->xcd_order;
+    std::vector<TileTask> trsm;
+    c->gupd_off.assign(nsteps + 1, 0);
+    c->gred_off.assign(nsteps + 1, 0);
+    c->gtrsm_off.assign(nsteps + 1, 0);
+    for (int k = 1; k < nsteps; ++k) {
+        c->gupd_off[k] = (int)U.upd.size();
+        c->gred_off[k] = (int)U.red.size();
+        c->gtrsm_off[k] = (int)trsm.size();
+        std::vector<TileTask> tiles;
+        double depth = 0.0;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.owner != l || lf.nb <= k) continue;
+            const LeafDev& d = c->h_leaves[l];
+            for (int t = 0; t < k; ++t) {
+                double* tile = Xt(l) + (size_t)t * TB + (size_t)k * TB * lf.npad;
+                TileTask u{};
+                u.A = Xt(l) + (size_t)t * TB;
+                u.B = d.F + (size_t)k * TB;
+                u.C = tile;
+                u.lda = u.ldb = u.ldc = lf.npad;
+                u.k0 = t * TB;
+                u.k1 = k * TB;
+                u.update = 1;            // Xt was zero-filled: 0 - product
+                tiles.push_back(u);
+                depth += u.k1 - u.k0;
+                TileTask s{};
+                s.A = tile;
+                s.B = d.Dinv + (size_t)k * TB * TB;
+                s.C = tile;
+                s.lda = lf.npad;
+                s.ldb = TB;
+                s.ldc = lf.npad;
+                s.k0 = 0;
+                s.k1 = TB;
+                s.update = 0;
+                trsm.push_back(s);
+            }
+        }
+        const int Kavg = tiles.empty() ? 0 : (int)(depth / tiles.size()) / TB * TB;
+        U.add_step(tiles, std::max(TB, Kavg));
+    }
+    c->gupd_off[0] = c->gred_off[0] = c->gtrsm_off[0] = 0;
+    if (nsteps > 0) {
+        c->gupd_off[nsteps] = (int)U.upd.size();
+        c->gred_off[nsteps] = (int)U.red.size();
+        c->gtrsm_off[nsteps] = (int)trsm.size();
+    }
+    if (U.max_slabs) HIPCHK(c, hipMalloc(&c->slabG, U.max_slabs * TB * TB * sizeof(double)));
+    U.bind(c->slabG);
+
+    // contraction tiles: every IsoSE leaf (COPY leaves too: their alpha is their own)
+    std::vector<GradTask> gd;
+    c->gdot_leaf.clear();
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (c->hyper[lf.kid].kind != DSMGP_KIND_ISO_SE) continue;
+        const LeafDev& d = c->h_leaves[l];
+        for (int j = 0; j < lf.nb; ++j)
+            for (int i = j; i < lf.nb; ++i) {
+                GradTask g{};
+                g.gemm.A = Xt(l) + (size_t)i * TB;
+                g.gemm.B = Xt(l) + (size_t)j * TB;
+                g.gemm.C = nullptr;
+                g.gemm.lda = g.gemm.ldb = lf.npad;
+                g.gemm.ldc = TB;
+                g.gemm.k0 = i * TB;
+                g.gemm.k1 = lf.npad;
+                g.gemm.update = 0;
+                g.xa = d.Xg + (size_t)i * TB;
+                g.xb = d.Xg + (size_t)j * TB;
+                g.alpha_a = d.alpha + (size_t)i * TB;
+                g.alpha_b = d.alpha + (size_t)j * TB;
+                g.ldx = lf.npad;
+                g.na = std::max(0, std::min(TB, lf.n - i * TB));
+                g.nb = std::max(0, std::min(TB, lf.n - j * TB));
+                g.diag = (i == j);
+                g.kid = lf.kid;
+                gd.push_back(g);
+                c->gdot_leaf.push_back(l);
+            }
+    }
+    if (int rc = dev_upload(c, c->gtrans, trans)) return rc;
+    if (int rc = dev_upload(c, c->gfrob, frob)) return rc;
+    if (int rc = dev_upload(c, c->gupd, U.upd)) return rc;
+    if (int rc = dev_upload(c, c->gred, U.red)) return rc;
+    if (int rc = dev_upload(c, c->gtrsm, trsm)) return rc;
+    if (int rc = dev_upload(c, c->gdot, gd)) return rc;
+    c->gpart_count = frob.size() + 2 * gd.size() + 2 * (size_t)L;
+    HIPCHK(c, hipMalloc(&c->d_gpart, std::max<size_t>(1, c->gpart_count) * sizeof(double)));
+    c->grad_ready = true;
+    return 0;
+}
+
+}  // namespace
+
 int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     if (!c) return DSMGP_E_ARG;
-    (void)grad_out;
-    (void)stride;
-    return fail(c, DSMGP_E_STATE, "gradients: not built yet");
+    if (!c->fitted) return fail(c, DSMGP_E_STATE, "gradients before fit");
+    if (!grad_out) return fail(c, DSMGP_E_ARG, "grad_out is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int L = c->L;
+    for (int l = 0; l < L; ++l) {
+        const HyperHost& h = c->hyper[c->leaves[l].kid];
+        if ((int)h.loghyp.size() > stride) return fail(c, DSMGP_E_ARG, "gradients: stride smaller than the hyper-vector");
+    }
+    if (!c->grad_ready)
+        if (int rc = build_grad_plan(c)) return rc;
+    c->timings[10] = 0.0;
+    hipEvent_t t0, t1;
+    HIPCHK(c, hipEventCreate(&t0));
+    HIPCHK(c, hipEventCreate(&t1));
+    HIPCHK(c, hipEventRecord(t0, c->stream));
+    // Xt = L^-T
+    HIPCHK(c, hipMemsetAsync(c->arenaX, 0, c->arenaX_count * sizeof(double), c->stream));
+    if (c->gtrans.count) transpose_tile_kernel<<<(int)c->gtrans.count * 16, 256, 0, c->stream>>>(c->gtrans.p);
+    for (int k = 1; k < c->gsteps; ++k) {
+        const int nu = c->gupd_off[k + 1] - c->gupd_off[k];
+        if (nu > 0) {
+            launch_tiles(c, c->gupd.p + c->gupd_off[k], nu, 0);
+            const int nr = c->gred_off[k + 1] - c->gred_off[k];
+            if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->gred.p + c->gred_off[k]);
+        }
+        const int ns = c->gtrsm_off[k + 1] - c->gtrsm_off[k];
+        if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns, 0);
+    }
+    double* pfrob = c->d_gpart;
+    double* pdot = pfrob + c->gfrob.count;
+    double* pleaf = pdot + 2 * c->gdot.count;
+    if (c->gfrob.count) frob_kernel<<<(int)c->gfrob.count, 256, 0, c->stream>>>(c->gfrob.p, pfrob);
+    if (c->gdot.count) tile_graddot_kernel<<<(int)c->gdot.count, 256, 0, c->stream>>>(c->gdot.p, c->d_kp, c->D, pdot);
+    dots_kernel<<<L, 256, 0, c->stream>>>(c->d_leaves, pleaf);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    c->timings[10] = ms * 1e-3;
+    std::vector<double> part(c->gpart_count);
+    HIPCHK(c, hipMemcpy(part.data(), c->d_gpart, c->gpart_count * sizeof(double), hipMemcpyDeviceToHost));
+    // host assembly (fixed summation order -> reproducible)
+    std::vector<double> trK(L, 0.0), S1(L, 0.0);
+    for (size_t i = 0; i < c->gfrob.count; ++i) trK[c->gfrob_leaf[i]] += part[i];
+    for (int l = 0; l < L; ++l)
+        if (c->leaves[l].owner != l) trK[l] = trK[c->leaves[l].owner];
+    const double* pd = part.data() + c->gfrob.count;
+    for (size_t i = 0; i < c->gdot.count; ++i) S1[c->gdot_leaf[i]] += pd[2 * i];
+    const double* pl = pd + 2 * c->gdot.count;
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        const HyperHost& h = c->hyper[lf.kid];
+        const int nl = (int)h.loghyp.size() - 2;
+        const double noise = std::exp(2.0 * h.loghyp[nl + 1]);
+        const double cc = noise + 1e-8;
+        const double ya = pl[2 * l], aa = pl[2 * l + 1];
+        const double n = (double)lf.n;
+        // tr(precomp K) with K = K_y - c I:  (y.alpha - c alpha.alpha) - (n - c tr K_y^-1)
+        const double trPK = (ya - cc * aa) - (n - cc * trK[l]);
+        double* g = grad_out + (size_t)l * stride;
+        for (int j = 0; j < stride; ++j) g[j] = 0.0;
+        if (h.kind == DSMGP_KIND_ISO_SE) {
+            const double sigma = std::exp(h.loghyp[1]);
+            const double ell2 = std::exp(2.0 * h.loghyp[0]);
+            g[0] = 0.5 * sigma * S1[l] / ell2;                // src/kernels.jl:95-97
+            g[1] = sigma * trPK;                              // src/kernels.jl:90-93
+        } else if (h.kind == DSMGP_KIND_ARD_SE) {
+            const double sigma = std::exp(h.loghyp[nl]);
+            for (int d = 0; d < nl; ++d) g[d] = 0.0;          // src/kernels.jl:161 (identically zero)
+            g[nl] = sigma * trPK;                             // src/kernels.jl:157
+        } else {
+            g[0] = -trPK;                                     // src/kernels.jl:198
+            g[1] = 0.0;                                       // src/kernels.jl:201
+        }
+        g[nl + 1] = noise * (aa - trK[l]);                    // src/gaussianprocess.jl:176
+    }
+    return 0;
 }
 
 // -------------------------------------------------------------------------------------------------

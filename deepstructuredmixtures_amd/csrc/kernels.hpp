@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_t(const TileTask* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 gf64_ptr pc = AS_GLOBAL_F64(tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc);
-                if (tk.update) *pc = *pc - acc[cm][rn][r];
+                if (tk.update == 1) *pc = *pc - acc[cm][rn][r];
+                else if (tk.update == 2) *pc = -acc[cm][rn][r];
                 else *pc = acc[cm][rn][r];
             }
 }
@@ -307,19 +308,15 @@ constexpr int NRING = 4;
 // ABL is an ablation mask for tools/bench_tile.py only (results are wrong when it is non-zero):
 //   1 = no global loads / LDS writes in the loop, 2 = no barrier in the loop, 4 = no fragment reads in the loop,
 //   8 = global loads kept but their LDS writes dropped
-template <bool STAMP, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
-                                                              unsigned long long* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
-    __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
-    const TileTask tk = tasks[blockIdx.x];
+template <bool STAMP, int ABL>
+__device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4][4], double (*sA)[KC2 * LDP],
+                                                 double (*sB)[KC2 * LDP], unsigned long long* __restrict__ stamps) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = t >> 6;
     const int wr = w & 1, wc = w >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    d4 acc[4][4];
 #pragma unroll
     for (int cm = 0; cm < 4; ++cm)
 #pragma unroll
@@ -438,7 +435,19 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
         s[2] = tbd;
         s[3] = nch / 2;
     }
+}
 
+// update: 0 = store the product, 1 = C - product, 2 = store the negated product
+template <bool STAMP, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
+                                                              unsigned long long* __restrict__ stamps) {
+    __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
+    __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
+    const TileTask tk = tasks[blockIdx.x];
+    d4 acc[4][4];
+    gemm_mainloop_v2<STAMP, ABL>(tk, acc, sA, sB, stamps);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int cm = 0; cm < 4; ++cm)
 #pragma unroll
@@ -446,10 +455,133 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 gf64_ptr pc = AS_GLOBAL_F64(tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc);
-                if (tk.update) *pc = *pc - acc[cm][rn][r];
+                if (tk.update == 1) *pc = *pc - acc[cm][rn][r];
+                else if (tk.update == 2) *pc = -acc[cm][rn][r];
                 else *pc = acc[cm][rn][r];
             }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gradient contraction (updategradients!, src/gaussianprocess.jl:165-178 + src/kernels.jl:85-99):
+// one tile G = (K_y^-1)[i-tile, j-tile] = sum_k Xt[i,k] Xt[j,k]^T with Xt = L^-T (rows = columns of L^-1),
+// never stored: the epilogue contracts  sum_rc (alpha_r alpha_c - G_rc) * K_rc * P_rc  (IsoSE: K = kernel
+// value without noise, P = squared distance) and, on diagonal tiles, trace(G).  Off-diagonal tiles count
+// twice (symmetry).  out[2*task] = weighted sum, out[2*task+1] = trace part.
+struct LeafDev;
+struct GradTask {
+    TileTask gemm;          // A = Xt row tile i, B = Xt row tile j, K range [128 i, npad)
+    const double* xa;       // inputs of the rows (tile i), ld = ldx
+    const double* xb;       // inputs of the columns (tile j)
+    const double* alpha_a;
+    const double* alpha_b;
+    int ldx;
+    int na, nb;             // valid rows / cols
+    int diag;               // tile on the block diagonal
+    int kid;
+    int pad;
+};
+
+__global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __restrict__ tasks,
+                                                              const KParam* __restrict__ kp, int D,
+                                                              double* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
+    __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
+    __shared__ double red[2][4];
+    const GradTask g = tasks[blockIdx.x];
+    const KParam p = kp[g.kid];
+    d4 acc[4][4];
+    gemm_mainloop_v2<false, 0>(g.gemm, acc, sA, sB, nullptr);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
+    const double l2 = p.l2[0];
+    double s = 0.0, tr = 0.0;
+#pragma unroll
+    for (int rn = 0; rn < 4; ++rn) {
+        const int r = wr * 64 + 16 * rn + l15;
+        const bool rv = r < g.na;
+        const double ar = rv ? g.alpha_a[r] : 0.0;
+#pragma unroll
+        for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = wc * 64 + 16 * cm + l4 + 4 * q;
+                if (rv && c < g.nb) {
+                    double z = 0.0;
+                    for (int d = 0; d < D; ++d) {
+                        const double u = g.xa[r + (size_t)d * g.ldx] - g.xb[c + (size_t)d * g.ldx];
+                        z = fma(u, u, z);
+                    }
+                    const double kv = p.sigma2 * exp(-0.5 * (z / l2));
+                    const double pre = ar * g.alpha_b[c] - acc[cm][rn][q];
+                    s = fma(pre * kv, z, s);
+                    if (g.diag && r == c) tr += acc[cm][rn][q];
+                }
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        tr += __shfl_down(tr, o);
+    }
+    if (lane == 0) {
+        red[0][w] = s;
+        red[1][w] = tr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double wgt = g.diag ? 1.0 : 2.0;
+        out[2 * blockIdx.x] = wgt * (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        out[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+// trace(K_y^-1) = |L^-1|_F^2 without forming K_y^-1: sum of squares of one row tile of Xt (columns >= its block)
+struct FrobTask {
+    const double* X;   // Xt + row0
+    int ld;
+    int col0, col1;    // column range (elements)
+    int nrows;         // valid rows in this tile
+    int n;             // valid columns (leaf size)
+};
+
+__global__ __launch_bounds__(256) void frob_kernel(const FrobTask* __restrict__ tasks, double* __restrict__ out) {
+    __shared__ double red[256];
+    const FrobTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x, r = t & 127, h = t >> 7;
+    double s = 0.0;
+    if (r < tk.nrows)
+        for (int c = tk.col0 + h; c < min(tk.col1, tk.n); c += 2) {
+            const double v = tk.X[r + (size_t)c * tk.ld];
+            s = fma(v, v, s);
+        }
+    red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) out[blockIdx.x] = red[0];
+}
+
+// Xt diagonal tiles: Xt[t,t] = Dinv_t^T
+struct TransTask {
+    const double* src;   // 128x128, ld 128
+    double* dst;
+    int ldd;
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void transpose_tile_kernel(const TransTask* __restrict__ tasks) {
+    __shared__ double tile[32][33];
+    const TransTask tk = tasks[blockIdx.x >> 4];
+    const int sub = blockIdx.x & 15, bi = sub >> 2, bj = sub & 3;   // 4x4 sub-tiles of 32x32
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int y = ty; y < 32; y += 8) tile[y][tx] = tk.src[(bi * 32 + tx) + (size_t)(bj * 32 + y) * TB];
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) tk.dst[(bj * 32 + tx) + (size_t)(bi * 32 + y) * tk.ldd] = tile[tx][y];
+}
+
+// per leaf: y.alpha and alpha.alpha (inputs of the gradient assembly)
+__global__ __launch_bounds__(256) void dots_kernel(const LeafDev* __restrict__ leaves, double* __restrict__ out);
 
 // split-K epilogue: tile -= slab_0 + slab_1 + ... (fixed order, so results are bit-reproducible)
 struct ReduceTask {
@@ -836,6 +968,32 @@ __global__ __launch_bounds__(256) void pred_var_kernel(const LeafDev* __restrict
             kss = q / p.l2[0];
         }
         lf.var[tk.row0 + t] = (kss - red[t]) + p.noise;
+    }
+}
+
+// per leaf: y.alpha and alpha.alpha (inputs of the gradient assembly)
+__global__ __launch_bounds__(256) void dots_kernel(const LeafDev* __restrict__ leaves, double* __restrict__ out) {
+    __shared__ double r1[256], r2[256];
+    const LeafDev lf = leaves[blockIdx.x];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = t; i < lf.n; i += 256) {
+        a = fma(lf.yc[i], lf.alpha[i], a);
+        b = fma(lf.alpha[i], lf.alpha[i], b);
+    }
+    r1[t] = a;
+    r2[t] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            r1[t] += r1[t + o];
+            r2[t] += r2[t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[2 * blockIdx.x] = r1[0];
+        out[2 * blockIdx.x + 1] = r2[0];
     }
 }
 

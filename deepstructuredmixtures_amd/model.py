@@ -342,6 +342,111 @@ def setparams(model, hyp):
         lf.kernel.set_loghyp(h[:-1])
 
 
+# ------------------------------------------------------------------------------------ gradients / training
+
+def updategradients(model):
+    """`updategradients!(spn)` (`src/fit.jl:306-311`): per-leaf gradient vectors in the reference's order
+    [dl..., ds, dnoise] (`src/gaussianprocess.jl:212-214`), computed on the device for the local leaves and
+    gathered.  Also stored on the leaves (kernel.dl / kernel.ds / dnoise) like the reference does."""
+    target = model.model if isinstance(model, GaussianProcess) else model
+    stride = max(lf.kernel.nparams() + 1 for lf in target.leaves)
+    g_loc = target.ctx.gradients(stride)
+    g = np.stack([target.shard.gather_leaf_values(g_loc[:, j]) for j in range(stride)], axis=1)
+    for lf, row in zip(target.leaves, g):
+        n = lf.kernel.nparams()
+        if lf.kernel.kind == KIND_ISO_LINEAR:
+            lf.kernel.dl = float(row[0])
+        else:
+            lf.kernel.dl = row[: n - 1].copy() if lf.kernel.kind == KIND_ARD_SE else float(row[0])
+            lf.kernel.ds = float(row[n - 1])
+        lf.dnoise = float(row[n])
+    target.leaf_grad = g
+    return g
+
+
+def grad_mll(model):
+    """`∇mll!(spn, 0.0, 0.0, L, L[root], grad)` (`src/optimize.jl:42-89`): gradient of the tree log marginal
+    w.r.t. the shared hyper-vector (concatenated per kernel id under sums over GPs)."""
+    if isinstance(model, GaussianProcess):
+        return model.model.leaf_grad[0][: model.node.kernel.nparams() + 1].copy()
+    tab = mll_table(model)
+    logS = tab[model.root.id]
+    n_hyp = getparams(model).size
+    grad = np.zeros(n_hyp)
+
+    def rec(node, dparent, lrho, g):
+        if node.kind == "gp":
+            w = np.exp(-logS + lrho + tab[node.id] + dparent)                 # :48
+            g += model.leaf_grad[node.leaf][: g.size] * w                     # :49
+        elif node.kind == "split":
+            for c in node.children:
+                rec(c, dparent + (tab[node.id] - tab[c.id]), lrho, g)         # :58-61
+        elif node.of_gps:
+            c0 = 0
+            for c in node.children:                                           # :76-89
+                nn = c.kernel.nparams() + 1
+                rec(c, dparent, lrho, g[c0:c0 + nn])
+                c0 += nn
+        else:
+            K = len(node.children)
+            for c in node.children:
+                rec(c, -np.log(K) + dparent, np.log(K) + lrho, g)             # :70-73
+
+    rec(model.root, 0.0, 0.0, grad)
+    return grad
+
+
+class ADAM:
+    """Flux.Optimise.ADAM stand-in for `train!`.  With stateful=False (default) the moment estimates are
+    reset every step, which is what the reference effectively runs: `hyp += grad` rebinds `hyp`, so Flux's
+    IdDict-keyed state never carries over and the step is eta*g/(|g|+eps) (`src/optimisers.jl:78-79`,
+    SURVEY F9).  stateful=True is the textbook optimiser."""
+
+    def __init__(self, eta=1e-3, beta=(0.9, 0.999), eps=1e-8, stateful=False):
+        self.eta, self.beta, self.eps, self.stateful = eta, beta, eps, stateful
+        self.m = self.v = None
+        self.t = 0
+
+    def apply(self, x, g):
+        if not self.stateful or self.m is None:
+            self.m = np.zeros_like(g)
+            self.v = np.zeros_like(g)
+            self.t = 0
+        b1, b2 = self.beta
+        self.t += 1
+        self.m = b1 * self.m + (1 - b1) * g
+        self.v = b2 * self.v + (1 - b2) * g * g
+        return self.m / (1 - b1 ** self.t) / (np.sqrt(self.v / (1 - b2 ** self.t)) + self.eps) * self.eta
+
+
+def train(model, optim=None, *, iterations=10_000, lam=0.05, randinit=True, earlystop=10, seed=0, tau=0.05, verbose=False):
+    """`train!(model, optim; iterations, λ, randinit, earlystop)` (`src/optimisers.jl:4-87`): gradient ASCENT
+    on the tree log marginal over one shared hyper-vector.  Returns (model, history of root mll)."""
+    from .datagen import normal
+    optim = ADAM() if optim is None else optim
+    n = getparams(model).size
+    hyp = normal(seed, 0, n) if randinit else getparams(model)
+    hist = []
+    c = 0
+    for it in range(1, iterations + 1):
+        setparams(model, hyp)
+        fit(model, tau=tau)
+        ell = mll(model)
+        hist.append(ell)
+        delta = abs(ell - np.mean(hist[-10:-1])) if it > 10 else np.inf       # :53
+        c = c + 1 if delta < lam else 0
+        if verbose:
+            print(f"iter {it}: mll {ell:.6f} delta {delta:.3g}")
+        if c >= earlystop:
+            return model, np.array(hist)
+        updategradients(model)
+        g = grad_mll(model)
+        hyp = hyp + optim.apply(hyp, g)                                       # :78-79 (ascent)
+    setparams(model, hyp)
+    fit(model, tau=tau)
+    return model, np.array(hist)
+
+
 # ------------------------------------------------------------------------------------ predict
 
 def _leaf_moments(model, xt, ptr, idx):

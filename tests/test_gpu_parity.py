@@ -255,6 +255,45 @@ def test_models_vs_oracle(family):
     assert np.allclose(var, vo, rtol=RTOL, atol=1e-10), float(np.max(np.abs(var - vo) / vo))
 
 
+@pytest.mark.parametrize("kind,n,D", [(0, 300, 2), (0, 1111, 5), (1, 400, 3), (2, 333, 2)])
+def test_gradients_vs_oracle(ctx, kind, n, D):
+    """updategradients!(gp): [dl..., ds, dnoise] with the reference's scaling and ArdSE dl == 0 (F6)."""
+    X = uniform(80 + n, 0, n * D).reshape((n, D), order="F")
+    y = np.sin(4 * X[:, 0]) + 0.1 * normal(81 + n, 0, n)
+    h = {0: [np.log(0.4), 0.2], 1: list(np.log(np.linspace(0.4, 0.9, D))) + [-0.1], 2: [np.log(0.9), 0.0]}[kind]
+    ln = np.log(0.25)
+    mean = float(np.mean(y))
+    _single(ctx, X, y, mean, kind, np.array(h), ln)
+    g = ctx.gradients(len(h) + 1)[0]
+    go = ogp.GaussianProcess(X, y, mean, ogp.make_kernel(kind, h), ln, True).update_cholesky().grad()
+    scale = max(1.0, float(np.max(np.abs(go))))
+    assert np.max(np.abs(g - go)) <= 1e-7 * scale, (g, go)
+    if kind == 1:
+        assert np.all(g[:D] == 0.0)
+
+
+def test_train_loop_follows_the_oracle_trajectory():
+    """train! (src/optimisers.jl:4-87) for a few iterations: same mll history and hyper-parameters as the
+    oracle-driven loop (gradient ascent, stateless ADAM step)."""
+    N, D = 1500, 2
+    X, y, _ = regression_data(N, D, n_test=10, seed=321)
+    m = dsm.buildDSMGP(X, y, 2, 4, M=60, kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.3), seed=9)
+    _, hist = dsm.train(m, dsm.ADAM(eta=0.02), iterations=4, randinit=False)
+    trained = dsm.getparams(m).copy()
+    hyp = np.array([np.log(0.5), 0.0, np.log(0.3)])
+    ref = []
+    opt = dsm.ADAM(eta=0.02)
+    for it in range(4):
+        dsm.setparams(m, hyp)
+        gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+        ospn.fit_naive(m.root, gps)
+        ref.append(ospn.mll(m.root, gps))
+        hyp = hyp + opt.apply(hyp, ospn.grad_tree(m.root, gps, 3))
+    assert np.allclose(hist, ref, rtol=1e-8)
+    assert np.allclose(trained, hyp, rtol=1e-9, atol=1e-12)
+    assert hist[-1] > hist[0]
+
+
 def test_full_size_properties_single_large_gp(ctx):
     """Config 2 (single exact GP N=4096, D=4, IsoSE) -- too large to compare entry by entry quickly,
     checked through size-independent properties: L L^T = K, K alpha = y, mll consistency,
