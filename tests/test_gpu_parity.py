@@ -325,3 +325,50 @@ def test_full_size_properties_single_large_gp(ctx):
     mo, vo = go.prediction(Xt)
     assert abs(mll[0] - go.mll()) <= RTOL * abs(go.mll())
     assert np.allclose(g_mu, mo, rtol=RTOL, atol=1e-9) and np.allclose(g_var, vo, rtol=RTOL, atol=1e-10)
+
+
+_SHARD_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as td
+sys.path.insert(0, {root!r})
+import deepstructuredmixtures_amd as dsm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+td.init_process_group("gloo", rank=rank, world_size=world)
+X, y, Xt = dsm.regression_data(4000, 3, n_test=300, seed=77)
+ref = np.load({ref!r})
+m = dsm.buildDSMGP(X, y, 3, 4, M=80, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=5,
+                   shard_world=(rank, world))
+assert 0 < len(m.shard.local) < m.L
+z = dsm.update(m)
+mu, var = dsm.predict(m, Xt)
+assert np.array_equal(m.leaf_mll, ref["leaf_mll"]) and z == float(ref["z"])
+assert np.array_equal(mu, ref["mu"]) and np.array_equal(var, ref["var"])
+dsm.updategradients(m)
+assert np.array_equal(dsm.grad_mll(m), ref["grad"])
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok", len(m.shard.local))
+"""
+
+
+def test_two_ranks_sharing_leaves_reproduce_the_single_process_result_bitwise(tmp_path):
+    """Leaf sharding through the real HIP contexts (two processes on the one GPU of this box, gloo for the
+    all-gather): identical bits to the unsharded run, because every per-leaf result is reproducible."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    X, y, Xt = regression_data(4000, 3, n_test=300, seed=77)
+    m = dsm.buildDSMGP(X, y, 3, 4, M=80, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=5)
+    z = dsm.update(m)
+    mu, var = dsm.predict(m, Xt)
+    dsm.updategradients(m)
+    ref = str(tmp_path / "ref.npz")
+    np.savez(ref, leaf_mll=m.leaf_mll, z=z, mu=mu, var=var, grad=dsm.grad_mll(m))
+    script = tmp_path / "worker.py"
+    script.write_text(_SHARD_WORKER.format(root=root, ref=ref))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
