@@ -104,30 +104,29 @@ struct UpdateSplitter {
         }
         return best;
     }
-    // tiles: tasks with k0 = 0, k1 = K, update = 1
-    void add_step(const std::vector<TileTask>& tiles, int K) {
-        const int S = choose_split((int)tiles.size(), K, ncu);
+    // Emit `tiles[from, to)` split S ways (S = 1: as they are), split-major, XCD-ordered.
+    void emit(const std::vector<TileTask>& tiles, size_t from, size_t to, int S, size_t& slab) {
         const size_t begin = upd.size();
-        if (S == 1) {
-            for (auto& t : tiles) {
-                upd.push_back(t);
+        if (S <= 1) {
+            for (size_t i = from; i < to; ++i) {
+                upd.push_back(tiles[i]);
                 upd_slab.push_back(-1);
             }
             xcd_permute(upd, upd_slab, begin, upd.size(), xcd);
             return;
         }
-        const size_t T = tiles.size();
-        for (size_t i = 0; i < T; ++i) {
+        const size_t first = slab;
+        for (size_t i = from; i < to; ++i) {
             ReduceTask r{};
             r.C = tiles[i].C;
             r.ldc = tiles[i].ldc;
             r.nsplit = S;
             red.push_back(r);
-            red_slab.push_back((int64_t)(i * S));
+            red_slab.push_back((int64_t)(first + (i - from) * S));
         }
         // split-major order: tasks with the same K range (and, per leaf, the same B panel) stay adjacent
         for (int s = 0; s < S; ++s)
-            for (size_t i = 0; i < T; ++i) {
+            for (size_t i = from; i < to; ++i) {
                 TileTask p = tiles[i];
                 const long chunks = (tiles[i].k1 - tiles[i].k0) / KC;   // this tile's own K range
                 p.k0 = tiles[i].k0 + (int)(chunks * s / S) * KC;
@@ -136,10 +135,31 @@ struct UpdateSplitter {
                 p.C = nullptr;
                 p.ldc = TB;
                 upd.push_back(p);
-                upd_slab.push_back((int64_t)(i * S + s));
+                upd_slab.push_back((int64_t)(first + (i - from) * S + s));
             }
         xcd_permute(upd, upd_slab, begin, upd.size(), xcd);
-        max_slabs = std::max(max_slabs, T * (size_t)S);
+        slab += (to - from) * (size_t)S;
+    }
+    // tiles: tasks of one block step with update = 1 and (nearly) equal depth K.
+    // Fewer tiles than CUs: split all of them (cost model).  Otherwise the step runs in rounds of one tile
+    // per CU; the last, partial round would hold the whole launch for a full tile time, so only the
+    // remainder tiles are split, finely enough to fit one short extra round, and issued last.
+    void add_step(const std::vector<TileTask>& tiles, int K) {
+        const size_t T = tiles.size();
+        size_t slab = 0;
+        if ((int)T < ncu) {
+            emit(tiles, 0, T, choose_split((int)T, K, ncu), slab);
+        } else {
+            const size_t r = T % (size_t)ncu;
+            int S = 1;
+            if (r > 0 && r * 10 < (size_t)ncu * 7) {
+                S = (int)std::min<size_t>((size_t)ncu / r, 32);
+                S = std::min(S, std::max(1, K / 256));
+            }
+            emit(tiles, 0, T - (S > 1 ? r : 0), 1, slab);
+            if (S > 1) emit(tiles, T - r, T, S, slab);
+        }
+        max_slabs = std::max(max_slabs, slab);
     }
     void bind(double* workspace) {
         for (size_t i = 0; i < upd.size(); ++i)
@@ -189,7 +209,6 @@ struct dsmgp_ctx {
     double* slabF = nullptr;        // split-K workspace of the factorisation
     double* slabP = nullptr;        // ... of the prediction sweep
     int ncu = 256;
-    int stagger = 0;                // s_sleep(16) units the odd-slot partner wave is delayed by (tile_gemm_kernel)
     int tile_variant = 2;           // 1: two-buffer kernel, 2: software-pipelined ring kernel
     bool xcd_order = true;          // XCD-aware task order (speed only)
     std::vector<int> fwd_off, bwd_off;
@@ -561,6 +580,10 @@ int build_plan(dsmgp_ctx* c) {
                         s.k0 = 0;
                         s.k1 = TB;
                         s.update = 0;
+                        if (ph == 0) {   // fused forward substitution for leaves factorised in full
+                            s.zk = d.z + (size_t)k * TB;
+                            s.wi = d.w + (size_t)i * TB;
+                        }
                         trsm.push_back(s);
                     }
                 }
@@ -568,6 +591,10 @@ int build_plan(dsmgp_ctx* c) {
                     DiagTask g{};
                     g.T = d.F + (size_t)k * TB + (size_t)k * TB * ld;
                     g.Dinv = d.Dinv + (size_t)k * TB * TB;
+                    if (ph == 0) {
+                        g.wk = d.w + (size_t)k * TB;
+                        g.zk = d.z + (size_t)k * TB;
+                    }
                     g.info = d.info;
                     g.ld = ld;
                     g.nvalid = std::max(0, std::min(TB, lf.n - k * TB));
@@ -596,7 +623,9 @@ int build_plan(dsmgp_ctx* c) {
     for (int l = 0; l < L; ++l)
         if (c->leaves[l].owner == l) c->alg_flops_update += update_flops(c->leaves[l].n);
 
-    // solve sweeps: every leaf (COPY leaves have their own right-hand side)
+    // solve sweeps.  Forward: only leaves whose factor came from elsewhere (COPY, PREFIX) -- leaves factorised
+    // in full get z = L^-1 y from the factorisation itself (chol_diag_kernel + the panel-solve epilogue).
+    // Backward: every leaf.
     {
         int nsteps = 0;
         for (auto& lf : c->leaves) nsteps = std::max(nsteps, lf.nb);
@@ -609,6 +638,7 @@ int build_plan(dsmgp_ctx* c) {
             for (int l = 0; l < L; ++l) {
                 const LeafHost& lf = c->leaves[l];
                 if (lf.nb <= k) continue;
+                if (lf.owner == l && lf.op == DSMGP_SHARE_FULL) continue;   // fused
                 const LeafDev& d = c->h_leaves[l];
                 for (int i = k; i < lf.nb; ++i) {
                     SolveTask s{};
@@ -660,7 +690,7 @@ int build_plan(dsmgp_ctx* c) {
     return 0;
 }
 
-void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int stagger) {
+void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n) {
     if (c->tile_variant >= 100) {   // ablation builds, micro-benchmark only
         switch (c->tile_variant - 100) {
             case 1: tile_gemm_kernel_v2<false, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
@@ -674,8 +704,8 @@ void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int stagger) {
         }
         return;
     }
-    if (c->tile_variant == 2) tile_gemm_kernel_v2<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
-    else tile_gemm_kernel_t<false><<<n, 256, 0, c->stream>>>(tasks, stagger, nullptr);
+    if (c->tile_variant == 3) tile_gemm_kernel_v3<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    else tile_gemm_kernel_v2<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
 }
 
 struct PhaseTimer {
@@ -713,7 +743,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
         if (nu > 0) {
             pt.begin(1);
-            launch_tiles(c, S.upd.p + S.upd_off[k], nu, c->stagger);
+            launch_tiles(c, S.upd.p + S.upd_off[k], nu);
             const int nr = S.red_off[k + 1] - S.red_off[k];
             if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
             pt.end();
@@ -728,7 +758,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
         if (ns > 0) {
             pt.begin(3);
-            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns, 0);
+            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns);
             pt.end();
         }
     }
@@ -761,7 +791,6 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             c->ncu = prop.multiProcessorCount;
     }
-    if (const char* s = std::getenv("DSMGP_STAGGER")) c->stagger = std::atoi(s);
     if (const char* s = std::getenv("DSMGP_TILE_V")) c->tile_variant = std::atoi(s);
     if (const char* s = std::getenv("DSMGP_XCD")) c->xcd_order = std::atoi(s) != 0;
     const char* p = std::getenv("DSMGP_PROFILE");
@@ -940,7 +969,12 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         gram_tile_kernel<<<2 * (int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
         pt.end();
     }
-    // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101)
+    // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101); w = y - m rides along
+    {
+        int maxpad = 0;
+        for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
+        copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
+    }
     if (int rc = run_phase(c, c->phase[0], pt, true)) return rc;
     // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
     bool any_prefix = false;
@@ -959,10 +993,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         if (int rc = run_phase(c, c->phase[1], pt, true)) return rc;
     // 4. alpha = L^-T (L^-1 y)                                (src/gaussianprocess.jl:105)
     {
-        int maxpad = 0;
-        for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
         pt.begin(4);
-        copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
         for (int k = 0; k < c->solve_steps; ++k) {
             const int n = c->fwd_off[k + 1] - c->fwd_off[k];
             if (n > 0) solve_fwd_kernel<<<n, 256, 0, c->stream>>>(c->fwd.p + c->fwd_off[k]);
@@ -1181,7 +1212,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
             const int nu = c->pupd_off[k + 1] - c->pupd_off[k];
             if (nu > 0) {
                 pt.begin(7);
-                launch_tiles(c, c->pupd.p + c->pupd_off[k], nu, c->stagger);
+                launch_tiles(c, c->pupd.p + c->pupd_off[k], nu);
                 const int nr = c->pred_off[k + 1] - c->pred_off[k];
                 if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->pred.p + c->pred_off[k]);
                 pt.end();
@@ -1189,7 +1220,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
             const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
             if (ns > 0) {
                 pt.begin(8);
-                launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns, 0);
+                launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns);
                 pt.end();
             }
         }
@@ -1406,12 +1437,12 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     for (int k = 1; k < c->gsteps; ++k) {
         const int nu = c->gupd_off[k + 1] - c->gupd_off[k];
         if (nu > 0) {
-            launch_tiles(c, c->gupd.p + c->gupd_off[k], nu, 0);
+            launch_tiles(c, c->gupd.p + c->gupd_off[k], nu);
             const int nr = c->gred_off[k + 1] - c->gred_off[k];
             if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->gred.p + c->gred_off[k]);
         }
         const int ns = c->gtrsm_off[k + 1] - c->gtrsm_off[k];
-        if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns, 0);
+        if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns);
     }
     double* pfrob = c->d_gpart;
     double* pdot = pfrob + c->gfrob.count;
@@ -1614,6 +1645,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     const size_t panel = (size_t)TB * K;
     const int nA = mode == 1 ? 1 : ntiles;
     const int nB = mode == 1 ? 1 : (ntiles + group - 1) / group;
+    if (mode == 2 && std::getenv("DSMGP_STAMPS")) return fail(c, DSMGP_E_ARG, "no stamps in mode 2");
     double *A = nullptr, *B = nullptr, *C = nullptr;
     HIPCHK(c, hipMalloc(&A, nA * panel * sizeof(double)));
     HIPCHK(c, hipMalloc(&B, nB * panel * sizeof(double)));
@@ -1640,30 +1672,50 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
         t.update = 1;
         tasks[i] = t;
     }
-    {
+    // mode 0/1: the raw batch; mode 2: the batch as UpdateSplitter would schedule it (split-K + reduce)
+    UpdateSplitter U;
+    U.ncu = c->ncu;
+    U.xcd = c->xcd_order;
+    double* slabs = nullptr;
+    if (mode == 2) {
+        U.add_step(tasks, K);
+        if (U.max_slabs) HIPCHK(c, hipMalloc(&slabs, U.max_slabs * TB * TB * sizeof(double)));
+        U.bind(slabs);
+        tasks = U.upd;
+        std::fprintf(stderr, "  splitter: %zu tiles -> %zu tasks, %zu reduces\n", (size_t)ntiles, tasks.size(), U.red.size());
+    } else {
         std::vector<int> dummy(tasks.size());
         xcd_permute(tasks, dummy, 0, tasks.size(), c->xcd_order && mode == 0);
     }
     DevBuf<TileTask> dt;
+    DevBuf<ReduceTask> dr;
     if (int rc = dev_upload(c, dt, tasks)) return rc;
+    if (int rc = dev_upload(c, dr, U.red)) return rc;
+    const int nt_ = (int)tasks.size();
+    auto run = [&]() {
+        launch_tiles(c, dt.p, nt_);
+        if (dr.count) tile_reduce_kernel<<<(int)dr.count, 256, 0, c->stream>>>(dr.p);
+    };
     hipEvent_t t0, t1;
     HIPCHK(c, hipEventCreate(&t0));
     HIPCHK(c, hipEventCreate(&t1));
-    launch_tiles(c, dt.p, ntiles, c->stagger);
+    run();
     HIPCHK(c, hipEventRecord(t0, c->stream));
-    for (int r = 0; r < reps; ++r) launch_tiles(c, dt.p, ntiles, c->stagger);
+    for (int r = 0; r < reps; ++r) run();
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
+    dev_free(dr.p);
+    dev_free(slabs);
     *seconds_per_launch = ms * 1e-3 / reps;
     if (std::getenv("DSMGP_STAMPS")) {
         unsigned long long* st = nullptr;
         HIPCHK(c, hipMalloc(&st, (size_t)ntiles * 16 * sizeof(unsigned long long)));
-        if (c->tile_variant == 2) tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
-        else tile_gemm_kernel_t<true><<<ntiles, 256, 0, c->stream>>>(dt.p, c->stagger, st);
+        if (c->tile_variant == 3) tile_gemm_kernel_v3<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
+        else tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<unsigned long long> hs((size_t)ntiles * 16);
         HIPCHK(c, hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1675,8 +1727,12 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
             bd += (double)hs[4 * i + 2];
             nchs += (double)hs[4 * i + 3];
         }
-        std::fprintf(stderr, "  stamps: cycles/chunk total %.0f  mfma-span %.0f  boundary %.0f (per wave, mean)\n",
-                     tot / nchs, mf / nchs, bd / nchs);
+        if (c->tile_variant == 3)
+            std::fprintf(stderr, "  stamps: cycles per 64 MFMA %.0f  mfma-span %.0f  in-kernel clock %.3f GHz\n", tot / nchs,
+                         mf / nchs, tot / bd / 10.0);
+        else
+            std::fprintf(stderr, "  stamps: cycles/chunk total %.0f  mfma-span %.0f  boundary %.0f (per wave, mean)\n",
+                         tot / nchs, mf / nchs, bd / nchs);
     }
     dev_free(dt.p);
     dev_free(A);

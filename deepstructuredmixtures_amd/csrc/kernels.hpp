@@ -3,9 +3,9 @@
 // Everything here works on 128x128 Float64 tiles of column-major matrices whose dimensions are
 // padded to multiples of 128 (padding = identity block, see gram_tile_kernel).  One leaf GP's
 // factor F (npad x npad) is produced by a LEFT-LOOKING blocked Cholesky, batched over all leaves:
-//   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel_t, update tasks, v_mfma_f64_16x16x4_f64)
+//   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel_v2, update tasks, v_mfma_f64_16x16x4_f64)
 //            F[k,k]  = chol(F[k,k]), Dinv_k = F[k,k]^-1   (chol_diag_kernel)
-//            F[i,k]  = F[i,k] Dinv_k^T       (tile_gemm_kernel_t, solve tasks)
+//            F[i,k]  = F[i,k] Dinv_k^T       (tile_gemm_kernel_v2, solve tasks; fused forward solve)
 // which is update_cholesky!/potrf! of the reference (src/gaussianprocess.jl:82-108) and, started at
 // a later column with the leading block copied, chol_continue! (src/AdvancedCholeskey.jl:152-174).
 // prediction() (src/gaussianprocess.jl:110-137) appends the test rows below the factor: V^T = K_tn L^-T
@@ -165,123 +165,26 @@ struct TileTask {
     const double* A;
     const double* B;
     double* C;
+    const double* zk;   // solve tasks of the factorisation: z_k = L_kk^-1 w_k (128) ...
+    double* wi;         // ... and the right-hand side block of this row tile: w_i -= X z_k (fused forward solve); else NULL
     int lda, ldb, ldc;
-    int k0, k1;      // K range, multiples of KC
-    int update;
+    int k0, k1;         // K range, multiples of 8
+    int update;         // 0 = store the product, 1 = C - product, 2 = store the negated product
 };
 
-// STAMP = true is a diagnostic build (tools/bench_tile.py): wave 0 of every workgroup accumulates shader
-// cycles spent in the MFMA stream of each chunk and at the chunk boundary; never used by fit!/predict.
+// diagnostic builds (tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
 
-template <bool STAMP>
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_t(const TileTask* __restrict__ tasks, int stagger,
-                                                             unsigned long long* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) double sA[2][KC * LDP];
-    __shared__ __attribute__((aligned(16))) double sB[2][KC * LDP];
-    const TileTask tk = tasks[blockIdx.x];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = t >> 6;
-    const int wr = w & 1, wc = w >> 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-
-    d4 acc[4][4];
-#pragma unroll
-    for (int cm = 0; cm < 4; ++cm)
-#pragma unroll
-        for (int rn = 0; rn < 4; ++rn) acc[cm][rn] = (d4){0.0, 0.0, 0.0, 0.0};
-
-    // staging: instruction q moves column kk = 4q + w of the chunk, rows 2*lane, 2*lane+1 (1 KiB per wave)
-    d2 ra[4], rb[4];
-    const double* gA = tk.A + 2 * lane + (size_t)(tk.k0 + w) * tk.lda;
-    const double* gB = tk.B + 2 * lane + (size_t)(tk.k0 + w) * tk.ldb;
-    const int sOff = w * LDP + 2 * lane;
-
-    auto gload = [&](int kk) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[q] = *AS_GLOBAL_D2(gA + (size_t)(kk + 4 * q) * tk.lda);
-            rb[q] = *AS_GLOBAL_D2(gB + (size_t)(kk + 4 * q) * tk.ldb);
-        }
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<d2*>(&sA[buf][sOff + 4 * q * LDP]) = ra[q];
-            *reinterpret_cast<d2*>(&sB[buf][sOff + 4 * q * LDP]) = rb[q];
-        }
-    };
-
-    const int nch = (tk.k1 - tk.k0) / KC;
-    if (nch > 0) {
-        gload(0);
-        swrite(0);
-    }
-    // Two workgroups share a CU (two waves per SIMD) and run the same program: left alone they reach the
-    // chunk-boundary barrier together and the matrix pipe idles.  Delay the wave in the odd hardware slot
-    // by about half a chunk once, so one partner is in its MFMA stream while the other crosses the barrier.
-    if (stagger > 0 && nch > 8) {
-        const int wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // HW_ID.WAVE_ID
-        if (wave_slot & 1) {
-            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
-        }
-    }
-    __syncthreads();
-    unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0;
-    if (STAMP) tin = stamp_now();
-    for (int c = 0; c < nch; ++c) {
-        const int buf = c & 1;
-        if (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            ta = stamp_now();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c + 1 < nch) gload((c + 1) * KC);
-        const double* pa = &sB[buf][l4 * LDP + wc * 64 + l15];   // MFMA A operand <- tile columns
-        const double* pb = &sA[buf][l4 * LDP + wr * 64 + l15];   // MFMA B operand <- tile rows
-#pragma unroll
-        for (int k4 = 0; k4 < KC / 4; ++k4) {
-            double fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = pa[k4 * 4 * LDP + 16 * i];
-                fb[i] = pb[k4 * 4 * LDP + 16 * i];
-            }
-#pragma unroll
-            for (int cm = 0; cm < 4; ++cm)
-#pragma unroll
-                for (int rn = 0; rn < 4; ++rn)
-                    acc[cm][rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cm], fb[rn], acc[cm][rn], 0, 0, 0);
-        }
-        if (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            tb = stamp_now();
-            __builtin_amdgcn_sched_barrier(0);
-            tmf += tb - ta;
-        }
-        if (c + 1 < nch) swrite(buf ^ 1);
-        __syncthreads();
-        if (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            tbd += stamp_now() - tb;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (STAMP && (t & 63) == 0) {
-        const unsigned long long tout = stamp_now();
-        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + w) * 4;
-        s[0] = tout - tin;
-        s[1] = tmf;
-        s[2] = tbd;
-        s[3] = nch;
-    }
-
-    // epilogue: register r of acc[cm][rn] is C(row = wr*64+16rn+l15, col = wc*64+16cm+l4+4r)
+// Epilogue shared by the tile kernels: register r of acc[cm][rn] is C(row = wr*64+16rn+l15, col = wc*64+16cm+l4+4r).
+// With tk.wi set (panel solve of the factorisation) the forward substitution y -> L^-1 y rides along:
+// w_i -= X z_k, summed per row over the 4 lanes l4, then over the two column halves through LDS (fixed order).
+__device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4], double* red /* >= 256 doubles of LDS */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int cm = 0; cm < 4; ++cm)
 #pragma unroll
@@ -293,10 +196,33 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_t(const TileTask* __r
                 else if (tk.update == 2) *pc = -acc[cm][rn][r];
                 else *pc = acc[cm][rn][r];
             }
+    if (tk.wi != nullptr) {
+        double p[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double z = tk.zk[wc * 64 + 16 * cm + l4 + 4 * r];
+#pragma unroll
+                for (int rn = 0; rn < 4; ++rn) p[rn] = fma(acc[cm][rn][r], z, p[rn]);
+            }
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn) {
+            p[rn] += __shfl_xor(p[rn], 16);
+            p[rn] += __shfl_xor(p[rn], 32);
+        }
+        __syncthreads();   // the ring is no longer read
+        if (l4 == 0) {
+#pragma unroll
+            for (int rn = 0; rn < 4; ++rn) red[wc * TB + wr * 64 + 16 * rn + l15] = p[rn];
+        }
+        __syncthreads();
+        if (threadIdx.x < TB) tk.wi[threadIdx.x] -= red[threadIdx.x] + red[TB + threadIdx.x];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Software-pipelined form of the same tile GEMM (same TileTask contract, same result bits per chunk order).
+// Software-pipelined tile GEMM.
 //   - K is consumed in chunks of 8 columns (two 16-MFMA groups per wave) held in a 4-deep LDS ring
 //   - the MFMA operand fragments of the NEXT group are read from LDS while the current group's 16 MFMAs
 //     issue, also across the chunk boundary (the next chunk is already complete and visible in the ring)
@@ -437,7 +363,137 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     }
 }
 
-// update: 0 = store the product, 1 = C - product, 2 = store the negated product
+// ---------------------------------------------------------------------------------------------
+// Same pipeline with LDS-DMA staging (global_load_lds_dwordx4): operands go HBM/L2 -> LDS without passing
+// through VGPRs, so the loop has no ds_write and no load-return traffic into the register file.
+// One wave instruction moves one 1 KiB column (128 rows) of a chunk; the LDS destination is wave-uniform
+// base + 16 B * lane, which is exactly a column of the padded [8][144] image.  A wave's DMAs are counted in
+// vmcnt: before the barrier that ends chunk c every wave waits until only its 4 newest DMAs (chunk c+3)
+// are in flight, so chunk c+2 is complete and visible one full chunk before its first fragment read.
+// All LDS lives in ONE array (a second __shared__ object makes hipcc drain vmcnt in the loop).
+constexpr int SLOT_DOUBLES = 2 * KC2 * LDP;
+
+template <bool STAMP>
+__device__ __forceinline__ void gemm_mainloop_v3(const TileTask& tk, d4 (&acc)[4][4], double* smem,
+                                                 unsigned long long* __restrict__ stamps) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w & 1, wc = w >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn) acc[cm][rn] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    typedef const __attribute__((address_space(1))) void* gvp;
+    typedef __attribute__((address_space(3))) void* lvp;
+    const double* gA = tk.A + 2 * lane + (size_t)(tk.k0 + w) * tk.lda;
+    const double* gB = tk.B + 2 * lane + (size_t)(tk.k0 + w) * tk.ldb;
+    const size_t a4 = (size_t)4 * tk.lda, b4 = (size_t)4 * tk.ldb;
+
+#define DMA(CH, SLOT)                                                                            \
+    do {                                                                                         \
+        const size_t oa_ = (size_t)(CH) * KC2 * tk.lda, ob_ = (size_t)(CH) * KC2 * tk.ldb;       \
+        double* sa_ = smem + (SLOT) * SLOT_DOUBLES + w * LDP;                                    \
+        double* sb_ = sa_ + KC2 * LDP;                                                           \
+        __builtin_amdgcn_global_load_lds((gvp)(gA + oa_), (lvp)sa_, 16, 0, 0);                   \
+        __builtin_amdgcn_global_load_lds((gvp)(gA + oa_ + a4), (lvp)(sa_ + 4 * LDP), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((gvp)(gB + ob_), (lvp)sb_, 16, 0, 0);                   \
+        __builtin_amdgcn_global_load_lds((gvp)(gB + ob_ + b4), (lvp)(sb_ + 4 * LDP), 16, 0, 0);  \
+    } while (0)
+#define FRAGS(FA, FB, SLOT, G)                                                                   \
+    do {                                                                                         \
+        const double* pb_ = smem + (SLOT) * SLOT_DOUBLES + ((G) * 4 + l4) * LDP + wr * 64 + l15; \
+        const double* pa_ = smem + (SLOT) * SLOT_DOUBLES + KC2 * LDP + ((G) * 4 + l4) * LDP + wc * 64 + l15; \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
+            FA[i_] = pa_[16 * i_];                                                               \
+            FB[i_] = pb_[16 * i_];                                                               \
+        }                                                                                        \
+    } while (0)
+#define MFMA16(FA, FB)                                                                           \
+    do {                                                                                         \
+        _Pragma("unroll") for (int cm_ = 0; cm_ < 4; ++cm_)                                      \
+            _Pragma("unroll") for (int rn_ = 0; rn_ < 4; ++rn_)                                  \
+                acc[cm_][rn_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[cm_], FB[rn_], acc[cm_][rn_], 0, 0, 0); \
+    } while (0)
+
+    const int nch = (tk.k1 - tk.k0) / KC2;
+    if (nch > 0) {
+        DMA(0, 0);
+        DMA(min(1, nch - 1), 1);
+        DMA(min(2, nch - 1), 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    double fa0[4], fb0[4], fa1[4], fb1[4];
+    if (nch > 0) FRAGS(fa0, fb0, 0, 0);
+    unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0, rin = 0;
+    if (STAMP) {
+        tin = stamp_now();
+        rin = __builtin_amdgcn_s_memrealtime();
+    }
+
+    for (int c = 0; c < nch; ++c) {
+        const int slot = c & (NRING - 1);
+        if (STAMP) { __builtin_amdgcn_sched_barrier(0); ta = stamp_now(); }
+        __builtin_amdgcn_sched_barrier(0);
+        DMA(min(c + 3, nch - 1), (c + 3) & (NRING - 1));   // clamped: past the end it refills an unread slot
+        FRAGS(fa1, fb1, slot, 1);
+        MFMA16(fa0, fb0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAGS(fa0, fb0, (c + 1) & (NRING - 1), 0);
+        MFMA16(fa1, fb1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { tb = stamp_now(); __builtin_amdgcn_sched_barrier(0); tmf += tb - ta; }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAMP) { tbd += stamp_now() - tb; __builtin_amdgcn_sched_barrier(0); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef MFMA16
+#undef FRAGS
+#undef DMA
+    if (STAMP && (t & 63) == 0) {
+        const unsigned long long tout = stamp_now();
+        const unsigned long long rout = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + w) * 4;
+        s[0] = tout - tin;
+        s[1] = tmf;
+        (void)tbd;
+        s[2] = rout - rin;      // 100 MHz ticks: clock = s[0] / s[2] / 10 GHz (v3 reports this instead of the boundary span)
+        s[3] = nch / 2;
+    }
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v3(const TileTask* __restrict__ tasks,
+                                                              unsigned long long* __restrict__ stamps) {
+    __shared__ __attribute__((aligned(16))) double smem[NRING * SLOT_DOUBLES];
+    const TileTask tk = tasks[blockIdx.x];
+    d4 acc[4][4];
+    gemm_mainloop_v3<STAMP>(tk, acc, smem, stamps);
+    tile_epilogue(tk, acc, smem);
+}
+
 template <bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
                                                               unsigned long long* __restrict__ stamps) {
@@ -446,19 +502,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
     const TileTask tk = tasks[blockIdx.x];
     d4 acc[4][4];
     gemm_mainloop_v2<STAMP, ABL>(tk, acc, sA, sB, stamps);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
-#pragma unroll
-    for (int cm = 0; cm < 4; ++cm)
-#pragma unroll
-        for (int rn = 0; rn < 4; ++rn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                gf64_ptr pc = AS_GLOBAL_F64(tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc);
-                if (tk.update == 1) *pc = *pc - acc[cm][rn][r];
-                else if (tk.update == 2) *pc = -acc[cm][rn][r];
-                else *pc = acc[cm][rn][r];
-            }
+    tile_epilogue(tk, acc, &sA[0][0]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,6 +655,8 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(const ReduceTask* __re
 struct DiagTask {
     double* T;        // diagonal tile of F
     double* Dinv;     // 128x128 output, ld 128
+    const double* wk; // fused forward solve: right-hand side block (NULL = not fused)
+    double* zk;       // z_k = L_kk^-1 w_k
     int* info;
     int ld;
     int nvalid;       // valid rows in this tile
@@ -766,6 +812,17 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restri
         tk.Dinv[r + (size_t)c * TB] = xinv;
     }
     if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
+    if (tk.wk != nullptr && t < TB) {
+        // z_k = L_kk^-1 w_k from the inverse blocks still in LDS (row t of the lower-triangular inverse)
+        const int R = t >> 4, ri = t & 15;
+        double s = 0.0;
+        for (int c = 0; c <= t; ++c) {
+            const int Cb = c >> 4, ci = c & 15;
+            const double x = (R == Cb) ? S[(R * 16 + ci) * DLD + TB + ri] : S[(R * 16 + ci) * DLD + Cb * 16 + ri];
+            s = fma(x, tk.wk[c], s);
+        }
+        tk.zk[t] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -496,6 +496,15 @@ def _aggregate_dsmgp(model, xt, ptr, mu, var):
     (`src/common.jl:134-196,275-302`) do it, from ONE set of leaf predictions."""
     n_t = xt.shape[0]
     all_rows = np.arange(n_t, dtype=np.int64)
+    sel_cache = {}
+
+    def child_masks(node, rows):
+        """getchild once per split node: the three recursions below partition the rows identically."""
+        m = sel_cache.get(node.id)
+        if m is None:
+            ch = get_child(node, xt[rows])
+            m = sel_cache[node.id] = [ch == k for k in range(len(node.children))]
+        return m
 
     def leaf_vals(node):
         a, b = ptr[node.leaf], ptr[node.leaf + 1]
@@ -506,9 +515,7 @@ def _aggregate_dsmgp(model, xt, ptr, mu, var):
             return leaf_vals(node)[0]
         if node.kind == "split":
             out = np.zeros(rows.size)
-            ch = get_child(node, xt[rows])
-            for k, c in enumerate(node.children):
-                sel = ch == k
+            for sel, c in zip(child_masks(node, rows), node.children):
                 out[sel] = minpred(c, rows[sel])
             return out
         out = np.full(rows.size, np.inf)
@@ -528,9 +535,7 @@ def _aggregate_dsmgp(model, xt, ptr, mu, var):
             lm = np.zeros(rows.size)
             lm2 = np.zeros(rows.size)
             ls = np.zeros(rows.size)
-            ch = get_child(node, xt[rows])
-            for k, c in enumerate(node.children):
-                sel = ch == k
+            for sel, c in zip(child_masks(node, rows), node.children):
                 a, b, d = pred(c, rows[sel], mmin[sel])
                 lm[sel], lm2[sel], ls[sel] = a, b, d
             return lm, lm2, ls
@@ -552,9 +557,7 @@ def _aggregate_dsmgp(model, xt, ptr, mu, var):
         if node.kind == "split":                 # src/common.jl:243-254
             m = np.zeros(rows.size)
             v = np.zeros(rows.size)
-            ch = get_child(node, xt[rows])
-            for k, c in enumerate(node.children):
-                sel = ch == k
+            for sel, c in zip(child_masks(node, rows), node.children):
                 m[sel], v[sel] = predict_node(c, rows[sel])
             return m, v
         mmin = minpred(node, rows)               # src/common.jl:294-302
