@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--config", default="dsmgp_n100k_d8", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
+    ap.add_argument("--simulate-shard", default=None, metavar="R/W",
+                    help="diagnostic: run only rank R's leaf shard of a W-rank job on this one GPU (no exchange; "
+                         "not a valid bench line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +114,32 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import deepstructuredmixtures_amd as dsm
-    model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank)
+    if args.simulate_shard:
+        from deepstructuredmixtures_amd import dist as pdist
+        r_, w_ = map(int, args.simulate_shard.split("/"))
+        model, X, y, Xt, ptr, idx = build_model(args.config, r_, w_, local_rank)
+        own = model.shard.owner
+        loc = np.flatnonzero(own == r_)
+
+        class _Solo(pdist.Shard):   # same leaf subset, no communication: other ranks' values are placeholders
+            def gather_leaf_values(self, v):
+                out = np.zeros(self.owner.size)
+                out[self.local] = v
+                return out
+
+            def gather_ragged(self, flat, counts):
+                out = np.ones(int(np.sum(counts)))
+                p = np.concatenate([[0], np.cumsum(counts)])
+                pos = 0
+                for g in self.local:
+                    out[p[g]:p[g + 1]] = flat[pos:pos + counts[g]]
+                    pos += counts[g]
+                return out
+        model.shard = _Solo(own, r_, w_)
+        n3 = np.array([lf.nobs for lf in model.leaves], dtype=float) ** 3
+        print(f"# shard {r_}/{w_}: {loc.size} leaves, {n3[loc].sum() / n3.sum():.3f} of the Cholesky flops", file=sys.stderr)
+    else:
+        model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank)
     ctx = model.ctx
     ctx.set_profile(not args.no_profile)
 
@@ -146,7 +174,7 @@ def main():
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
     per_step = elapsed / args.steps
-    assert np.all(np.isfinite(mu)) and np.all(var > 0)
+    assert args.simulate_shard or (np.all(np.isfinite(mu)) and np.all(var > 0))
 
     # roofline of the dominant kernel (f64-MFMA Cholesky update) on this rank
     alg_flops, _ = ctx.work()

@@ -1050,7 +1050,8 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     c->n_t = n_t;
     c->route_total = total;
     c->route_ptr.assign(route_ptr, route_ptr + L + 1);
-    size_t vTot = 0, xTot = 0, pTot = 0;
+    size_t vTot = 0, xTot = 0;
+    const size_t pTot = 2 * (size_t)total + 2 * TB;
     for (int l = 0; l < L; ++l) {
         LeafHost& lf = c->leaves[l];
         lf.nt = (int)(route_ptr[l + 1] - route_ptr[l]);
@@ -1060,8 +1061,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         vTot += (size_t)lf.ntpad * lf.npad;
         lf.xt_off = xTot;
         xTot += (size_t)lf.ntpad * c->D;
-        lf.pv_off = pTot;
-        pTot += (size_t)2 * lf.ntpad;
+        lf.pv_off = (size_t)route_ptr[l];   // mu / var of all leaves are contiguous in route order (unpadded)
     }
     size_t freeB = 0, totalB = 0;
     HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
@@ -1085,7 +1085,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         d.Vt = c->arenaVt + lf.vt_off;
         d.Xtg = c->arenaXt + lf.xt_off;
         d.mu = c->arenaPV + lf.pv_off;
-        d.var = d.mu + lf.ntpad;
+        d.var = c->arenaPV + (size_t)total + lf.pv_off;
         d.nt = lf.nt;
         d.ntpad = lf.ntpad;
         maxpad = std::max(maxpad, lf.ntpad);
@@ -1247,13 +1247,9 @@ int dsmgp_predict_fetch(dsmgp_ctx* c, double* mu_out, double* var_out) {
     if (!c) return DSMGP_E_ARG;
     if (!c->predicted) return fail(c, DSMGP_E_STATE, "predict_fetch before predict_run");
     HIPCHK(c, hipSetDevice(c->device));
-    for (int l = 0; l < c->L; ++l) {
-        const LeafHost& lf = c->leaves[l];
-        if (lf.nt == 0) continue;
-        const LeafDev& d = c->h_leaves[l];
-        if (mu_out) HIPCHK(c, hipMemcpyAsync(mu_out + lf.route_off, d.mu, lf.nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        if (var_out) HIPCHK(c, hipMemcpyAsync(var_out + lf.route_off, d.var, lf.nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
+    const size_t n = (size_t)c->route_total;
+    if (n && mu_out) HIPCHK(c, hipMemcpyAsync(mu_out, c->arenaPV, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (n && var_out) HIPCHK(c, hipMemcpyAsync(var_out, c->arenaPV + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -909,8 +909,8 @@ struct LeafDev {
     // prediction
     double* Vt;           // ntpad x npad (ld = ntpad): K_tn, then K_tn L^-T
     const double* Xtg;    // gathered test inputs, ntpad x D (ld = ntpad)
-    double* mu;           // ntpad
-    double* var;          // ntpad
+    double* mu;           // nt (contiguous over leaves in route order)
+    double* var;          // nt
     int nt, ntpad;
     int pad0, pad1;
 };
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void pred_mu_kernel(const LeafDev* __restrict_
     double s = 0.0;
     for (int c = h; c < lf.n; c += 2) s = fma(V[(size_t)c * lf.ntpad], lf.alpha[c], s);
     block_reduce_store(s, red, t);
-    if (t < TB) lf.mu[tk.row0 + t] = lf.mean + red[t];
+    if (t < TB && tk.row0 + t < lf.nt) lf.mu[tk.row0 + t] = lf.mean + red[t];
 }
 
 // var = k(x*,x*) + noise - sum_c V(t,c)^2
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void pred_var_kernel(const LeafDev* __restrict
         s = fma(v, v, s);
     }
     block_reduce_store(s, red, t);
-    if (t < TB) {
+    if (t < TB && tk.row0 + t < lf.nt) {
         double kss;
         if (p.kind == 0) kss = p.sigma2;
         else if (p.kind == 1) kss = p.sigma2 * (double)D;

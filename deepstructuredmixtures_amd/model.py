@@ -52,7 +52,7 @@ class Model:
         self.last_predict_seconds = 0.0
         self._uploaded = False
         self._schedule = None
-        self._test_key = None
+        self._route_cache = None
 
     @property
     def ctx(self):
@@ -104,7 +104,7 @@ class Model:
             self.ctx.set_sharing(None, None, None)
         self._uploaded = True
         self._schedule = key
-        self._test_key = None
+        self._route_cache = None      # set_leaves dropped the device-side test set
 
 
 class DSMGP(Model):
@@ -449,26 +449,34 @@ def train(model, optim=None, *, iterations=10_000, lam=0.05, randinit=True, earl
 
 # ------------------------------------------------------------------------------------ predict
 
-def _leaf_moments(model, xt, ptr, idx):
+def _routing(model, xt):
+    """Routes of one test set, cached on the model: which rows each leaf predicts (CSR over all leaves and over
+    this rank's leaves) and, filled lazily by the aggregation, the child masks of every split node."""
+    key = (xt.shape, hash(xt.tobytes()))
+    rc = model._route_cache
+    if rc is None or rc["key"] != key:
+        ptr, idx = route(model.root, xt) if model.family == "dsmgp" else route_all(model.root, xt.shape[0])
+        loc = model.shard.local
+        lptr = np.zeros(len(loc) + 1, dtype=np.int64)
+        parts = []
+        for i, g in enumerate(loc):
+            seg = idx[ptr[g]:ptr[g + 1]]
+            parts.append(seg)
+            lptr[i + 1] = lptr[i] + seg.size
+        lidx = np.concatenate(parts) if parts else np.zeros(0, np.int64)
+        rc = model._route_cache = dict(key=key, ptr=ptr, idx=idx, lptr=lptr, lidx=lidx, masks={}, uploaded=False)
+    return rc
+
+
+def _leaf_moments(model, xt, rc):
     """(mu, var) per (leaf, routed row) for ALL leaves, computed on the owning ranks."""
-    loc = model.shard.local
-    lptr = np.zeros(len(loc) + 1, dtype=np.int64)
-    parts = []
-    for i, g in enumerate(loc):
-        seg = idx[ptr[g]:ptr[g + 1]]
-        parts.append(seg)
-        lptr[i + 1] = lptr[i] + seg.size
-    lidx = np.concatenate(parts) if parts else np.zeros(0, np.int64)
-    key = (xt.shape, hash(xt.tobytes()) if xt.size < 1 << 16 else id(xt), int(lptr[-1]))
-    if model._test_key != key:
-        model.ctx.set_test(xt, lptr, lidx)
-        model._test_key = key
+    if not rc["uploaded"]:
+        model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
+        rc["uploaded"] = True
     model.last_predict_seconds = model.ctx.predict_run()
     mu_l, var_l = model.ctx.predict_fetch()
-    counts = np.diff(ptr)
-    mu = model.shard.gather_ragged(mu_l, counts)
-    var = model.shard.gather_ragged(var_l, counts)
-    return mu, var
+    counts = np.diff(rc["ptr"])
+    return model.shard.gather_ragged(mu_l, counts), model.shard.gather_ragged(var_l, counts)
 
 
 def predict(model, xtest):
@@ -480,23 +488,19 @@ def predict(model, xtest):
     xt = np.asfortranarray(xtest, dtype=np.float64)
     if xt.ndim == 1:
         xt = xt.reshape(-1, 1)
-    n_t = xt.shape[0]
+    rc = _routing(model, xt)
+    mu, var = _leaf_moments(model, xt, rc)
     if model.family == "dsmgp":
-        ptr, idx = route(model.root, xt)
-    else:
-        ptr, idx = route_all(model.root, n_t)
-    mu, var = _leaf_moments(model, xt, ptr, idx)
-    if model.family == "dsmgp":
-        return _aggregate_dsmgp(model, xt, ptr, mu, var)
-    return _aggregate_poe(model, xt, ptr, mu, var)
+        return _aggregate_dsmgp(model, xt, rc["ptr"], mu, var, rc["masks"])
+    return _aggregate_poe(model, xt, rc["ptr"], mu, var)
 
 
-def _aggregate_dsmgp(model, xt, ptr, mu, var):
+def _aggregate_dsmgp(model, xt, ptr, mu, var, sel_cache=None):
     """Sum/product aggregation of the leaf moments exactly as `_minpredict` + `_predict`
     (`src/common.jl:134-196,275-302`) do it, from ONE set of leaf predictions."""
     n_t = xt.shape[0]
     all_rows = np.arange(n_t, dtype=np.int64)
-    sel_cache = {}
+    sel_cache = {} if sel_cache is None else sel_cache
 
     def child_masks(node, rows):
         """getchild once per split node: the three recursions below partition the rows identically."""
