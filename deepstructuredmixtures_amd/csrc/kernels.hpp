@@ -694,6 +694,51 @@ __device__ __forceinline__ d4 blk_mma(const double* pa, int saa, int sak, const 
     return acc;
 }
 
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (no division, no sqrt call)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-d * y, y, 1.0);
+        y = fma(y * 0.5, e, y);
+    }
+    return y;
+}
+
+// potrf + inverse of one 16x16 diagonal block, in registers of one wave: lane c (c = lane & 15; lanes 16..63
+// mirror) owns column c of the symmetric block (a[]) and column c of the identity being forward-substituted
+// (b[]).  Per pivot j: d = A(j,j) by v_readlane, r = 1/sqrt(d), then every l(r,j) is broadcast once and used
+// for both the rank-1 update of the trailing block and the substitution step, so the inverse costs no extra
+// cross-lane traffic.  Returns the 1-based index of the first non-positive pivot (0 = none).
+__device__ __forceinline__ int potrf_inv16(double (&a)[16], double (&b)[16], int c) {
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double d = readlane_f64(a[j], j);
+        if (!(d > 0.0) && bad == 0) bad = j + 1;
+        const double inv = rsqrt_nr(d);
+        double sd = d * inv;
+        sd = fma(fma(-sd, sd, d), 0.5 * inv, sd);
+        const double lc = a[j] * inv;          // L(c,j) for c > j
+        const double xj = b[j] * inv;          // X(j,c)
+        b[j] = xj;
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) {
+            const double lr = readlane_f64(a[r], j) * inv;   // L(r,j), wave-uniform
+            if (c > j) a[r] = fma(-lr, lc, a[r]);
+            b[r] = fma(-lr, xj, b[r]);
+        }
+        if (c == j) {
+            a[j] = sd;
+#pragma unroll
+            for (int r = j + 1; r < 16; ++r) a[r] *= inv;
+        }
+    }
+    return bad;
+}
+
 __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restrict__ tasks) {
     extern __shared__ __attribute__((aligned(16))) double S[];   // [128 cols][DLD rows] + Winv[256]
     double* Winv = S + TB * DLD;                                  // Linv of the current step, col-major ld 16
@@ -711,62 +756,47 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restri
     __syncthreads();
 
     int bad = 0;
-    for (int J = 0; J < 8; ++J) {
-        // ---- P0: 16x16 diagonal block on wave 0 (lanes 16..63 mirror lanes 0..15, only 0..15 store)
-        if (w == 0) {
-            const int c = l15;
-            double a[16], x[16];
-            const double* src = S + offS(J, J) + c * DLD;
+    // diagonal block J on wave 0: S(J,J) <- L_JJ (upper part zeroed), B(J,J) and Winv <- L_JJ^-1
+    auto diag_block = [&](int J) {
+        const int c = l15;
+        double a[16], b[16];
+        const double* src = S + offS(J, J) + c * DLD;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = src[r];
+        for (int r = 0; r < 16; ++r) a[r] = src[r];
+        const int bj = potrf_inv16(a, b, c);
+        if (bj != 0 && bad == 0) bad = J * 16 + bj;
+        if (lane < 16) {
+            double* dS = S + offS(J, J) + c * DLD;
+            double* dB = S + offB(J, J) + c * DLD;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double d = readlane_f64(a[j], j);
-                if (!(d > 0.0) && bad == 0) bad = J * 16 + j + 1;
-                const double sd = sqrt(d);
-                const double inv = 1.0 / sd;
-                const double lc = a[j] * inv;
-#pragma unroll
-                for (int r = j + 1; r < 16; ++r) {
-                    const double lr = readlane_f64(a[r], j) * inv;
-                    if (c > j) a[r] = fma(-lr, lc, a[r]);
-                }
-                if (c == j) {
-                    a[j] = sd;
-#pragma unroll
-                    for (int r = j + 1; r < 16; ++r) a[r] *= inv;
-                }
-            }
-            // x = column c of the inverse of the lower-triangular block
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const double rinv = 1.0 / readlane_f64(a[i], i);
-                double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; ++k) s = fma(-readlane_f64(a[i], k), x[k], s);
-                x[i] = (i >= c) ? s * rinv : 0.0;
-            }
-            if (lane < 16) {
-                double* dS = S + offS(J, J) + c * DLD;
-                double* dB = S + offB(J, J) + c * DLD;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    dS[r] = (r >= c) ? a[r] : 0.0;
-                    dB[r] = x[r];
-                    Winv[c * 16 + r] = x[r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                dS[r] = (r >= c) ? a[r] : 0.0;
+                const double x = (r >= c) ? b[r] : 0.0;
+                dB[r] = x;
+                Winv[c * 16 + r] = x;
             }
         }
-        __syncthreads();
-        // ---- P1: panel solve and the inverse's row J
+    };
+    auto trailing_task = [&](int J, int I, int K) {   // S(I,K) -= S(I,J) S(K,J)^T
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        double* dst = S + offS(I, K);
+        acc = blk_mma(S + offS(K, J), 1, DLD, S + offS(I, J), DLD, acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] -= acc[r];
+    };
+
+    if (w == 0) diag_block(0);
+    __syncthreads();
+    for (int J = 0; J < 8; ++J) {
+        // ---- P1: panel solve S(I,J) <- S(I,J) Linv^T (I > J) and the inverse's row J: B(J,K) <- Linv B(J,K) (K < J)
         for (int task = w; task < 7; task += 4) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             double* dst;
-            if (task < 7 - J) {                       // S(I,J) <- S(I,J) Linv^T
+            if (task < 7 - J) {
                 const int I = J + 1 + task;
                 dst = S + offS(I, J);
                 acc = blk_mma(Winv, 1, 16, dst, DLD, acc, lane);
-            } else {                                  // B(J,K) <- Linv B(J,K)
+            } else {
                 const int K = task - (7 - J);
                 dst = S + offB(J, K);
                 acc = blk_mma(dst, DLD, 1, Winv, 16, acc, lane);
@@ -775,30 +805,38 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restri
             for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] = acc[r];
         }
         __syncthreads();
-        // ---- P2: trailing update of the factor and of the inverse
+        // ---- P2 with lookahead: wave 0 updates the next diagonal block and factorises it at once
+        //      (nothing else in P2 touches S(J+1,J+1), B(J+1,J+1) or Winv), waves 1..3 do the rest of the
+        //      trailing update S(I,K) -= S(I,J) S(K,J)^T and of B(I,K) -= S(I,J) B(J,K).
         const int m = 7 - J;
-        const int ntrail = m * (m + 1) / 2;
-        const int ninv = m * (J + 1);
-        for (int task = w; task < ntrail + ninv; task += 4) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            double* dst;
-            if (task < ntrail) {                      // S(I,K) -= S(I,J) S(K,J)^T, I >= K > J
-                int q = task, Kk = 0;
-                while (q >= m - Kk) { q -= m - Kk; ++Kk; }
-                const int K = J + 1 + Kk, I = K + q;
-                dst = S + offS(I, K);
-                acc = blk_mma(S + offS(K, J), 1, DLD, S + offS(I, J), DLD, acc, lane);
-            } else {                                  // B(I,K) -= S(I,J) B(J,K), I > J, K <= J
-                const int q = task - ntrail;
-                const int I = J + 1 + q / (J + 1), K = q % (J + 1);
-                dst = S + offB(I, K);
-                acc = blk_mma(S + offB(J, K), DLD, 1, S + offS(I, J), DLD, acc, lane);
+        if (w == 0) {
+            if (m > 0) {
+                trailing_task(J, J + 1, J + 1);
+                diag_block(J + 1);
             }
+        } else {
+            const int ntrail = m * (m + 1) / 2;
+            const int ninv = m * (J + 1);
+            for (int task = 1 + (w - 1); task < ntrail + ninv; task += 3) {   // task 0 = (J+1,J+1): wave 0
+                if (task < ntrail) {
+                    int q = task, Kk = 0;
+                    while (q >= m - Kk) { q -= m - Kk; ++Kk; }
+                    const int K = J + 1 + Kk, I = K + q;
+                    trailing_task(J, I, K);
+                } else {
+                    const int q = task - ntrail;
+                    const int I = J + 1 + q / (J + 1), K = q % (J + 1);
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+                    double* dst = S + offB(I, K);
+                    acc = blk_mma(S + offB(J, K), DLD, 1, S + offS(I, J), DLD, acc, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] -= acc[r];
+                    for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] -= acc[r];
+                }
+            }
         }
         __syncthreads();
     }
+    bad = __shfl(bad, 0);   // wave 0 holds it; the info store below runs on (w == 0, lane == 0)
     // ---- write L back to the tile (upper blocks and upper parts of diagonal blocks are zero) and L^-1 to Dinv
     for (int e = t; e < TB * TB; e += 256) {
         const int r = e % TB, c = e / TB;
