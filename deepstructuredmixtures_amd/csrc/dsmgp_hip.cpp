@@ -207,6 +207,13 @@ struct dsmgp_ctx {
     DevBuf<GramTask> gram;
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
     double* slabF = nullptr;        // split-K workspace of the factorisation
+    StepLists phaseJ[2];            // the same with the resident test rows riding along (built by set_test)
+    double* slabJ = nullptr;
+    double alg_flops_joint = 0.0;
+    bool joint = true;              // fit advances the resident test rows too
+    bool joint_ready = false;
+    bool vt_valid = false;          // Vt holds K_tn L^-T for the current factor
+    bool last_fit_joint = false;
     double* slabP = nullptr;        // ... of the prediction sweep
     int ncu = 256;
     int tile_variant = 2;           // 1: two-buffer kernel, 2: software-pipelined ring kernel
@@ -342,6 +349,15 @@ void free_test(dsmgp_ctx* c) {
     dev_free(c->ptrsm.p);
     dev_free(c->pred.p);
     dev_free(c->slabP);
+    for (auto& ph : c->phaseJ) {
+        dev_free(ph.upd.p);
+        dev_free(ph.trsm.p);
+        dev_free(ph.red.p);
+        dev_free(ph.diag.p);
+    }
+    dev_free(c->slabJ);
+    c->joint_ready = false;
+    c->vt_valid = false;
     c->test_ready = false;
     c->predicted = false;
 }
@@ -412,6 +428,158 @@ double update_flops(int n) {
         f += 2.0 * (double)c0 * elems;
     }
     return f;
+}
+
+// Per-leaf algorithmic flops of the test rows riding through the sweep: 2*K per (test row, column) element.
+double predict_update_flops(int n, int nt) {
+    double f = 0.0;
+    for (int k = 1; k * TB < n; ++k) f += 2.0 * (double)(k * TB) * (double)nt * (double)std::min(TB, n - k * TB);
+    return f;
+}
+
+// Step lists of the batched left-looking factorisation.  phase[0]: leaves factorised in full (and, with
+// `with_test`, the test rows of those leaves and of the COPY leaves that alias them); phase[1]: PREFIX leaves.
+// with_test: the rows of K_tn (Vt) of every leaf are appended below its factor and advance through the same
+// update / panel-solve launches -- prediction's triangular solves (src/gaussianprocess.jl:120) cost no launches
+// of their own when the test set is resident at fit time.
+int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops) {
+    const int L = c->L;
+    alg_flops = 0.0;
+    UpdateSplitter split[2];
+    for (int ph = 0; ph < 2; ++ph) {
+        StepLists& S = phase[ph];
+        UpdateSplitter& U = split[ph];
+        U.ncu = c->ncu;
+        U.xcd = c->xcd_order;
+        auto in_phase = [&](const LeafHost& lf) { return (lf.op == DSMGP_SHARE_PREFIX) == (ph == 1); };
+        int nsteps = 0;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (!in_phase(lf)) continue;
+            if (lf.owner == l || (with_test && lf.nt > 0)) nsteps = std::max(nsteps, lf.nb);
+        }
+        S.nsteps = nsteps;
+        std::vector<TileTask> trsm;
+        std::vector<DiagTask> diag;
+        S.upd_off.assign(nsteps + 1, 0);
+        S.red_off.assign(nsteps + 1, 0);
+        S.trsm_off.assign(nsteps + 1, 0);
+        S.diag_off.assign(nsteps + 1, 0);
+        for (int k = 0; k < nsteps; ++k) {
+            S.upd_off[k] = (int)U.upd.size();
+            S.red_off[k] = (int)U.red.size();
+            S.trsm_off[k] = (int)trsm.size();
+            S.diag_off[k] = (int)diag.size();
+            std::vector<TileTask> tiles;
+            for (int l = 0; l < L; ++l) {
+                const LeafHost& lf = c->leaves[l];
+                if (lf.nb <= k || !in_phase(lf)) continue;
+                const LeafDev& d = c->h_leaves[l];
+                const int ld = lf.npad;
+                if (lf.owner == l) {
+                    // a PREFIX leaf keeps the copied leading kb x kb blocks: for k < kb only rows >= kb are new
+                    const int i_first = (k < lf.kb) ? lf.kb : k;
+                    const bool own_diag = (k >= lf.kb);
+                    for (int i = i_first; i < lf.nb; ++i) {
+                        if (k > 0) {
+                            TileTask u{};
+                            u.A = d.F + (size_t)i * TB;
+                            u.B = d.F + (size_t)k * TB;
+                            u.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
+                            u.lda = u.ldb = u.ldc = ld;
+                            u.k0 = 0;
+                            u.k1 = k * TB;
+                            u.update = 1;
+                            tiles.push_back(u);
+                        }
+                        if (i > k) {
+                            TileTask s{};
+                            s.A = d.F + (size_t)i * TB + (size_t)k * TB * ld;
+                            s.B = d.Dinv + (size_t)k * TB * TB;
+                            s.C = const_cast<double*>(s.A);
+                            s.lda = ld;
+                            s.ldb = TB;
+                            s.ldc = ld;
+                            s.k0 = 0;
+                            s.k1 = TB;
+                            s.update = 0;
+                            if (ph == 0) {   // fused forward substitution for leaves factorised in full
+                                s.zk = d.z + (size_t)k * TB;
+                                s.wi = d.w + (size_t)i * TB;
+                            }
+                            trsm.push_back(s);
+                        }
+                    }
+                    if (own_diag) {
+                        DiagTask g{};
+                        g.T = d.F + (size_t)k * TB + (size_t)k * TB * ld;
+                        g.Dinv = d.Dinv + (size_t)k * TB * TB;
+                        if (ph == 0) {
+                            g.wk = d.w + (size_t)k * TB;
+                            g.zk = d.z + (size_t)k * TB;
+                        }
+                        g.info = d.info;
+                        g.ld = ld;
+                        g.nvalid = std::max(0, std::min(TB, lf.n - k * TB));
+                        g.row0 = k * TB;
+                        diag.push_back(g);
+                    }
+                }
+                if (with_test && lf.nt > 0) {
+                    for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
+                        double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
+                        if (k > 0) {
+                            TileTask u{};
+                            u.A = d.Vt + (size_t)ti * TB;
+                            u.B = d.F + (size_t)k * TB;
+                            u.C = tile;
+                            u.lda = lf.ntpad;
+                            u.ldb = ld;
+                            u.ldc = lf.ntpad;
+                            u.k0 = 0;
+                            u.k1 = k * TB;
+                            u.update = 1;
+                            tiles.push_back(u);
+                        }
+                        TileTask s{};
+                        s.A = tile;
+                        s.B = d.Dinv + (size_t)k * TB * TB;
+                        s.C = tile;
+                        s.lda = lf.ntpad;
+                        s.ldb = TB;
+                        s.ldc = lf.ntpad;
+                        s.k0 = 0;
+                        s.k1 = TB;
+                        s.update = 0;
+                        trsm.push_back(s);
+                    }
+                }
+            }
+            U.add_step(tiles, k * TB);
+        }
+        S.upd_off[nsteps] = (int)U.upd.size();
+        S.red_off[nsteps] = (int)U.red.size();
+        S.trsm_off[nsteps] = (int)trsm.size();
+        S.diag_off[nsteps] = (int)diag.size();
+        if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
+        if (int rc = dev_upload(c, S.diag, diag)) return rc;
+    }
+    {
+        const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
+        dev_free(slab_ws);
+        if (slabs) HIPCHK(c, hipMalloc(&slab_ws, slabs * TB * TB * sizeof(double)));
+        for (int ph = 0; ph < 2; ++ph) {
+            split[ph].bind(slab_ws);
+            if (int rc = dev_upload(c, phase[ph].upd, split[ph].upd)) return rc;
+            if (int rc = dev_upload(c, phase[ph].red, split[ph].red)) return rc;
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (lf.owner == l) alg_flops += update_flops(lf.n);
+        if (with_test && lf.nt > 0) alg_flops += predict_update_flops(lf.n, lf.nt);
+    }
+    return 0;
 }
 
 // Build arenas, the LeafDev table and every task list for the current leaf table + sharing schedule.
@@ -520,108 +688,8 @@ int build_plan(dsmgp_ctx* c) {
     }
     if (int rc = dev_upload(c, c->gram, gram)) return rc;
 
-    // factorisation phases
-    c->alg_flops_update = 0.0;
-    UpdateSplitter split[2];
-    for (int ph = 0; ph < 2; ++ph) {
-        StepLists& S = c->phase[ph];
-        UpdateSplitter& U = split[ph];
-        U.ncu = c->ncu;
-        U.xcd = c->xcd_order;
-        int nsteps = 0;
-        for (int l = 0; l < L; ++l) {
-            const LeafHost& lf = c->leaves[l];
-            if (lf.owner != l) continue;
-            if ((lf.op == DSMGP_SHARE_PREFIX) != (ph == 1)) continue;
-            nsteps = std::max(nsteps, lf.nb);
-        }
-        S.nsteps = nsteps;
-        std::vector<TileTask> trsm;
-        std::vector<DiagTask> diag;
-        S.upd_off.assign(nsteps + 1, 0);
-        S.red_off.assign(nsteps + 1, 0);
-        S.trsm_off.assign(nsteps + 1, 0);
-        S.diag_off.assign(nsteps + 1, 0);
-        for (int k = 0; k < nsteps; ++k) {
-            S.upd_off[k] = (int)U.upd.size();
-            S.red_off[k] = (int)U.red.size();
-            S.trsm_off[k] = (int)trsm.size();
-            S.diag_off[k] = (int)diag.size();
-            std::vector<TileTask> tiles;
-            for (int l = 0; l < L; ++l) {
-                const LeafHost& lf = c->leaves[l];
-                if (lf.owner != l || lf.nb <= k) continue;
-                if ((lf.op == DSMGP_SHARE_PREFIX) != (ph == 1)) continue;
-                const LeafDev& d = c->h_leaves[l];
-                const int ld = lf.npad;
-                // a PREFIX leaf keeps the copied leading kb x kb blocks: for k < kb only rows >= kb are new
-                const int i_first = (k < lf.kb) ? lf.kb : k;
-                const bool own_diag = (k >= lf.kb);
-                for (int i = i_first; i < lf.nb; ++i) {
-                    if (k > 0) {
-                        TileTask u{};
-                        u.A = d.F + (size_t)i * TB;
-                        u.B = d.F + (size_t)k * TB;
-                        u.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
-                        u.lda = u.ldb = u.ldc = ld;
-                        u.k0 = 0;
-                        u.k1 = k * TB;
-                        u.update = 1;
-                        tiles.push_back(u);
-                    }
-                    if (i > k) {
-                        TileTask s{};
-                        s.A = d.F + (size_t)i * TB + (size_t)k * TB * ld;
-                        s.B = d.Dinv + (size_t)k * TB * TB;
-                        s.C = const_cast<double*>(s.A);
-                        s.lda = ld;
-                        s.ldb = TB;
-                        s.ldc = ld;
-                        s.k0 = 0;
-                        s.k1 = TB;
-                        s.update = 0;
-                        if (ph == 0) {   // fused forward substitution for leaves factorised in full
-                            s.zk = d.z + (size_t)k * TB;
-                            s.wi = d.w + (size_t)i * TB;
-                        }
-                        trsm.push_back(s);
-                    }
-                }
-                if (own_diag) {
-                    DiagTask g{};
-                    g.T = d.F + (size_t)k * TB + (size_t)k * TB * ld;
-                    g.Dinv = d.Dinv + (size_t)k * TB * TB;
-                    if (ph == 0) {
-                        g.wk = d.w + (size_t)k * TB;
-                        g.zk = d.z + (size_t)k * TB;
-                    }
-                    g.info = d.info;
-                    g.ld = ld;
-                    g.nvalid = std::max(0, std::min(TB, lf.n - k * TB));
-                    g.row0 = k * TB;
-                    diag.push_back(g);
-                }
-            }
-            U.add_step(tiles, k * TB);
-        }
-        S.upd_off[nsteps] = (int)U.upd.size();
-        S.red_off[nsteps] = (int)U.red.size();
-        S.trsm_off[nsteps] = (int)trsm.size();
-        S.diag_off[nsteps] = (int)diag.size();
-        if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
-        if (int rc = dev_upload(c, S.diag, diag)) return rc;
-    }
-    {
-        const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
-        if (slabs) HIPCHK(c, hipMalloc(&c->slabF, slabs * TB * TB * sizeof(double)));
-        for (int ph = 0; ph < 2; ++ph) {
-            split[ph].bind(c->slabF);
-            if (int rc = dev_upload(c, c->phase[ph].upd, split[ph].upd)) return rc;
-            if (int rc = dev_upload(c, c->phase[ph].red, split[ph].red)) return rc;
-        }
-    }
-    for (int l = 0; l < L; ++l)
-        if (c->leaves[l].owner == l) c->alg_flops_update += update_flops(c->leaves[l].n);
+    // factorisation phases (train rows only; set_test adds a second set with the test rows riding along)
+    if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update)) return rc;
 
     // solve sweeps.  Forward: only leaves whose factor came from elsewhere (COPY, PREFIX) -- leaves factorised
     // in full get z = L^-1 y from the factorisation itself (chol_diag_kernel + the panel-solve epilogue).
@@ -657,7 +725,8 @@ int build_plan(dsmgp_ctx* c) {
             }
         }
         c->fwd_off[nsteps] = (int)fwd.size();
-        // backward sweep: step s handles block kb = nb-1-s of each leaf; z is consumed in place
+        // backward sweep: step s handles block kb = nb-1-s of each leaf, on w = copy of z (z itself is kept:
+        // the predictive mean is m + (K_tn L^-T) z)
         for (int s_ = 0; s_ < nsteps; ++s_) {
             c->bwd_off[s_] = (int)bwd.size();
             for (int l = 0; l < L; ++l) {
@@ -668,14 +737,14 @@ int build_plan(dsmgp_ctx* c) {
                 for (int j = 0; j <= kb; ++j) {
                     SolveTask s{};
                     s.Dk = d.Dinv + (size_t)kb * TB * TB;
-                    s.vk = d.z + (size_t)kb * TB;
+                    s.vk = d.w + (size_t)kb * TB;
                     s.ldt = lf.npad;
                     if (j == kb) {
                         s.self = 1;
                         s.out_k = d.alpha + (size_t)kb * TB;
                     } else {
                         s.T = d.F + (size_t)kb * TB + (size_t)j * TB * lf.npad;
-                        s.vi = d.z + (size_t)j * TB;
+                        s.vi = d.w + (size_t)j * TB;
                     }
                     bwd.push_back(s);
                 }
@@ -825,6 +894,12 @@ int dsmgp_device_name(dsmgp_ctx* c, char* buf, int32_t len) {
     return 0;
 }
 
+int dsmgp_set_joint(dsmgp_ctx* c, int32_t on) {
+    if (!c) return DSMGP_E_ARG;
+    c->joint = on != 0;
+    return 0;
+}
+
 int dsmgp_set_profile(dsmgp_ctx* c, int32_t on) {
     if (!c) return DSMGP_E_ARG;
     c->profile = on != 0;
@@ -941,6 +1016,7 @@ int dsmgp_set_hyper(dsmgp_ctx* c, int32_t kernel_id, int32_t kind, const double*
     c->hyper[kernel_id].loghyp.assign(loghyp, loghyp + n);
     c->fitted = false;
     c->predicted = false;
+    c->vt_valid = false;
     return 0;
 }
 
@@ -963,10 +1039,16 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     HIPCHK(c, hipEventRecord(t0, c->stream));
 
     HIPCHK(c, hipMemsetAsync(c->d_info, 0, L * sizeof(int), c->stream));
-    // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98)
+    // With a resident test set the rows of K_tn ride through the same launches (build_factor_steps).
+    const bool joint = c->joint && c->test_ready && c->joint_ready;
+    StepLists* phases = joint ? c->phaseJ : c->phase;
+    c->vt_valid = false;
+    // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98) [+ K_tn tiles]
     if (c->gram.count) {
         pt.begin(0);
         gram_tile_kernel<<<2 * (int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
+        if (joint && c->pgram.count)
+            gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
         pt.end();
     }
     // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101); w = y - m rides along
@@ -975,7 +1057,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
         copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
     }
-    if (int rc = run_phase(c, c->phase[0], pt, true)) return rc;
+    if (int rc = run_phase(c, phases[0], pt, true)) return rc;
     // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
     bool any_prefix = false;
     for (int l = 0; l < L; ++l) {
@@ -990,13 +1072,18 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         HIPCHK(c, hipMemcpyAsync(d.Dinv, s.Dinv, rows * TB * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     if (any_prefix)
-        if (int rc = run_phase(c, c->phase[1], pt, true)) return rc;
+        if (int rc = run_phase(c, phases[1], pt, true)) return rc;
     // 4. alpha = L^-T (L^-1 y)                                (src/gaussianprocess.jl:105)
     {
         pt.begin(4);
         for (int k = 0; k < c->solve_steps; ++k) {
             const int n = c->fwd_off[k + 1] - c->fwd_off[k];
             if (n > 0) solve_fwd_kernel<<<n, 256, 0, c->stream>>>(c->fwd.p + c->fwd_off[k]);
+        }
+        {
+            int maxpad = 0;
+            for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
+            copy_z_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);   // w = z
         }
         for (int s = 0; s < c->solve_steps; ++s) {
             const int n = c->bwd_off[s + 1] - c->bwd_off[s];
@@ -1027,6 +1114,8 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     }
     c->fitted = true;
     c->predicted = false;
+    c->vt_valid = joint;
+    c->last_fit_joint = joint;
     return 0;
 }
 
@@ -1184,8 +1273,12 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
     if (int rc = dev_upload(c, c->pgram, pg)) return rc;
     if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
+    // the same test rows as riders of the factorisation launches (used by fit while this test set is resident)
+    if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint)) return rc;
+    c->joint_ready = true;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->test_ready = true;
+    c->vt_valid = false;
     return 0;
 }
 
@@ -1202,30 +1295,33 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     HIPCHK(c, hipEventCreate(&t1));
     HIPCHK(c, hipEventRecord(t0, c->stream));
     if (c->pgram.count) {
-        // K_tn tiles and the predictive mean        (src/gaussianprocess.jl:117-118,133)
-        pt.begin(6);
-        gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
-        pred_mu_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p);
-        pt.end();
-        // V^T = K_tn L^-T, block column by block column (src/gaussianprocess.jl:120)
-        for (int k = 0; k < c->psteps; ++k) {
-            const int nu = c->pupd_off[k + 1] - c->pupd_off[k];
-            if (nu > 0) {
-                pt.begin(7);
-                launch_tiles(c, c->pupd.p + c->pupd_off[k], nu);
-                const int nr = c->pred_off[k + 1] - c->pred_off[k];
-                if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->pred.p + c->pred_off[k]);
-                pt.end();
+        if (!c->vt_valid) {
+            // K_tn tiles                                  (src/gaussianprocess.jl:133)
+            pt.begin(6);
+            gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
+            pt.end();
+            // V^T = K_tn L^-T, block column by block column (src/gaussianprocess.jl:120)
+            for (int k = 0; k < c->psteps; ++k) {
+                const int nu = c->pupd_off[k + 1] - c->pupd_off[k];
+                if (nu > 0) {
+                    pt.begin(7);
+                    launch_tiles(c, c->pupd.p + c->pupd_off[k], nu);
+                    const int nr = c->pred_off[k + 1] - c->pred_off[k];
+                    if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->pred.p + c->pred_off[k]);
+                    pt.end();
+                }
+                const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
+                if (ns > 0) {
+                    pt.begin(8);
+                    launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns);
+                    pt.end();
+                }
             }
-            const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
-            if (ns > 0) {
-                pt.begin(8);
-                launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns);
-                pt.end();
-            }
+            c->vt_valid = true;
         }
-        // diag(Ktt - V'V) + noise                   (src/gaussianprocess.jl:121-126)
+        // mu = m + V^T z (= m + K_tn alpha), diag(Ktt - V'V) + noise   (src/gaussianprocess.jl:117-126)
         pt.begin(9);
+        pred_mu_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p);
         pred_var_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p, c->d_kp, c->D);
         pt.end();
     }
@@ -1565,7 +1661,7 @@ int dsmgp_timings(dsmgp_ctx* c, double* out) {
 
 int dsmgp_work(dsmgp_ctx* c, double* alg_flops_update, int32_t* n_update_launches) {
     if (!c) return DSMGP_E_ARG;
-    if (alg_flops_update) *alg_flops_update = c->alg_flops_update;
+    if (alg_flops_update) *alg_flops_update = c->last_fit_joint ? c->alg_flops_joint : c->alg_flops_update;
     if (n_update_launches) *n_update_launches = c->n_update_launches;
     return 0;
 }
@@ -1639,7 +1735,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     if (!c || ntiles <= 0 || K <= 0 || K % KC || !seconds_per_launch || group <= 0) return DSMGP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t panel = (size_t)TB * K;
-    const int nA = mode == 1 ? 1 : ntiles;
+    const int nA = mode == 1 ? 1 : (mode == 3 ? (ntiles + group - 1) / group * group : ntiles);
     const int nB = mode == 1 ? 1 : (ntiles + group - 1) / group;
     if (mode == 2 && std::getenv("DSMGP_STAMPS")) return fail(c, DSMGP_E_ARG, "no stamps in mode 2");
     double *A = nullptr, *B = nullptr, *C = nullptr;
@@ -1662,6 +1758,10 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
         t.B = B + (mode == 1 ? 0 : (size_t)(i / group) * panel);
         t.C = C + (size_t)i * TB * TB;
         t.lda = t.ldb = TB;
+        if (mode == 3) {   // A tiles are row tiles of a (group*128) x K column-major matrix, like the rows of Vt
+            t.A = A + (size_t)(i / group) * group * panel + (size_t)(i % group) * TB;
+            t.lda = group * TB;
+        }
         t.ldc = TB;
         t.k0 = 0;
         t.k1 = K;

@@ -1006,6 +1006,13 @@ __global__ __launch_bounds__(256) void mll_kernel(const LeafDev* __restrict__ le
     }
 }
 
+// w = z (start of the backward sweep; z itself stays for the predictive mean)
+__global__ void copy_z_kernel(const LeafDev* __restrict__ leaves) {
+    const LeafDev lf = leaves[blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < lf.npad) lf.w[r] = lf.z[r];
+}
+
 // w = yc (start of the forward sweep)
 __global__ void copy_vec_kernel(const LeafDev* __restrict__ leaves) {
     const LeafDev lf = leaves[blockIdx.y];
@@ -1020,7 +1027,7 @@ struct PredTask {
     int row0;
 };
 
-// mu = m + K_tn alpha, from the freshly assembled K_tn (before the in-place solve overwrites it)
+// mu = m + K_tn alpha = m + (K_tn L^-T)(L^-1 y) = m + V^T z, from the solved rows
 __global__ __launch_bounds__(256) void pred_mu_kernel(const LeafDev* __restrict__ leaves,
                                                       const PredTask* __restrict__ tasks) {
     __shared__ double red[TB];
@@ -1029,7 +1036,7 @@ __global__ __launch_bounds__(256) void pred_mu_kernel(const LeafDev* __restrict_
     const int t = threadIdx.x, r = t & 127, h = t >> 7;
     const double* V = lf.Vt + tk.row0 + r;
     double s = 0.0;
-    for (int c = h; c < lf.n; c += 2) s = fma(V[(size_t)c * lf.ntpad], lf.alpha[c], s);
+    for (int c = h; c < lf.n; c += 2) s = fma(V[(size_t)c * lf.ntpad], lf.z[c], s);
     block_reduce_store(s, red, t);
     if (t < TB && tk.row0 + t < lf.nt) lf.mu[tk.row0 + t] = lf.mean + red[t];
 }

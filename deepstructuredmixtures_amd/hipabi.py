@@ -37,6 +37,7 @@ SIGNATURES = {
     "dsmgp_kernel_matrix": (C.c_int, [_ctx, C.c_int32, _dp, C.c_int64, _dp, C.c_int64, _dp]),
     "dsmgp_download_factor": (C.c_int, [_ctx, C.c_int32, _dp, _dp]),
     "dsmgp_set_profile": (C.c_int, [_ctx, C.c_int32]),
+    "dsmgp_set_joint": (C.c_int, [_ctx, C.c_int32]),
     "dsmgp_timings": (C.c_int, [_ctx, _dp]),
     "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
@@ -204,6 +205,9 @@ class Context:
         alpha = np.empty(n)
         self._chk(self.lib.dsmgp_download_factor(self.h, int(leaf), F.ctypes.data_as(_dp), alpha.ctypes.data_as(_dp)))
         return F, alpha
+
+    def set_joint(self, on):
+        self._chk(self.lib.dsmgp_set_joint(self.h, 1 if on else 0))
 
     def set_profile(self, on):
         self._chk(self.lib.dsmgp_set_profile(self.h, 1 if on else 0))

@@ -428,6 +428,14 @@ def train(model, optim=None, *, iterations=10_000, lam=0.05, randinit=True, earl
     hyp = normal(seed, 0, n) if randinit else getparams(model)
     hist = []
     c = 0
+    model.ctx.set_joint(False)     # fit is not followed by predict inside the loop: keep resident test rows out of it
+    try:
+        return _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose)
+    finally:
+        model.ctx.set_joint(True)
+
+
+def _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose):
     for it in range(1, iterations + 1):
         setparams(model, hyp)
         fit(model, tau=tau)

@@ -87,6 +87,10 @@ int dsmgp_fit(dsmgp_ctx* ctx, double* mll_out /* L */, int32_t* info_out /* L */
  *      mu  = m + Knt' alpha ; var = k(x*,x*) - |L^-1 k_n*|^2 + exp(2 logNoise)   (diag only; no clamp,
  *      the caller applies src/common.jl:137).  route_ptr/route_idx: per leaf, which rows of Xt.
  *      Outputs are aligned with route_idx. */
+/* While a test set is resident (dsmgp_set_test), dsmgp_fit also advances its rows through the factorisation
+ * launches (V^T = K_tn L^-T rides along as extra row tiles), and dsmgp_predict_run only finishes mu and var.
+ * dsmgp_set_joint(ctx, 0) switches that off (e.g. inside train!, where fit is not followed by predict). */
+int dsmgp_set_joint(dsmgp_ctx* ctx, int32_t on);
 int dsmgp_set_test(dsmgp_ctx* ctx, const double* Xt /* n_t x D */, int64_t n_t,
                    const int64_t* route_ptr /* L+1 */, const int64_t* route_idx);
 int dsmgp_predict_run(dsmgp_ctx* ctx, double* seconds);   /* device work only, inputs resident */

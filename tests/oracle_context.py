@@ -24,6 +24,9 @@ class OracleContext:
         self.L = len(self.obs)
         self.op = None
 
+    def set_joint(self, on):
+        pass
+
     def set_sharing(self, op, src, plen):
         self.op, self.src, self.plen = op, src, plen
 

@@ -191,6 +191,34 @@ def test_config1_readme_example(golden_dir):
     assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=RTOL, atol=1e-9)
 
 
+def test_resident_test_rows_riding_through_fit_equal_the_standalone_predict():
+    """With a test set resident, fit advances K_tn L^-T inside the factorisation launches and predict only
+    finishes mu/var; without it predict runs its own sweep.  Same numbers either way (summation order of the
+    split-K pieces may differ: 1e-11), for DSMGP (routed rows) and PoE (all rows to all leaves), incl. COPY leaves."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "config1.npz"))
+    X1, y1, xt1 = z["x"].reshape(-1, 1), z["y"], z["xt"]
+    X, y, Xt = regression_data(5000, 4, n_test=700, seed=1234)
+    cases = [lambda: dsm.buildDSMGP(X, y, 3, 4, M=100, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=8),
+             lambda: dsm.buildPoE(X, y, 4, M=300, kernel=dsm.ArdSE(np.log([0.3, 0.4, 0.5, 0.6]), 0.0), logNoise=np.log(0.2),
+                                  meanFun=dsm.ConstMean(0.1), seed=8),
+             lambda: dsm.buildDSMGP(X1, y1, 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5), seed=11)]
+    for make, xt in zip(cases, (Xt, Xt, xt1)):
+        m = make()
+        mu0, v0 = dsm.predict(m, xt)              # standalone sweep (fit ran before the test set existed)
+        t = m.ctx.timings()
+        assert t["predict_trsm"] > 0
+        dsm.fit(m)                                # test rows ride along
+        mu1, v1 = dsm.predict(m, xt)
+        t = m.ctx.timings()
+        assert t["predict_update"] == 0.0 and t["predict_trsm"] == 0.0
+        assert np.allclose(mu1, mu0, rtol=1e-11, atol=1e-12) and np.allclose(v1, v0, rtol=1e-10, atol=1e-13)
+        m.ctx.set_joint(False)
+        dsm.fit(m)
+        mu2, v2 = dsm.predict(m, xt)
+        assert np.array_equal(mu2, mu0) and np.array_equal(v2, v0)   # same path as the first time: same bits
+        m.ctx.set_joint(True)
+
+
 def test_prefix_continue_equals_full_factorisation(ctx):
     """chol_continue! property (src/AdvancedCholeskey.jl:121-135's intent): continuing from a copied
     leading block == factorising from scratch, at sizes that cross several 128-blocks."""
