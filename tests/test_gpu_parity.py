@@ -204,6 +204,7 @@ def test_resident_test_rows_riding_through_fit_equal_the_standalone_predict():
              lambda: dsm.buildDSMGP(X1, y1, 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5), seed=11)]
     for make, xt in zip(cases, (Xt, Xt, xt1)):
         m = make()
+        m.ctx.set_profile(True)                   # per-category device times
         mu0, v0 = dsm.predict(m, xt)              # standalone sweep (fit ran before the test set existed)
         t = m.ctx.timings()
         assert t["predict_trsm"] > 0
@@ -400,3 +401,111 @@ def test_two_ranks_sharing_leaves_reproduce_the_single_process_result_bitwise(tm
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-2000:]
+
+
+def test_config3_poe_ardse_full_size_sampled_against_oracle():
+    """BASELINE config 3 at full size: buildPoE K=8 splits, M=200, N=50k, D=8, additive ArdSE.  Every leaf is
+    oracle-sized (n ~ 200-400), so a sample of leaves is compared entry-wise and the PoE rule on top of them."""
+    N, D = 50_000, 8
+    X, y, Xt = regression_data(N, D, n_test=64, seed=20203)
+    kern = dsm.ArdSE(np.log(np.full(D, 0.3)), 0.0)
+    m = dsm.buildPoE(X, y, 8, M=200, kernel=kern, meanFun=dsm.ConstMean(float(np.mean(y))), logNoise=np.log(0.1), seed=3)
+    assert m.L >= 100 and max(lf.nobs for lf in m.leaves) <= 401
+    gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+    sample = list(range(0, m.L, max(1, m.L // 12)))
+    for j in sample:
+        gps[j].update_cholesky()
+        assert abs(m.leaf_mll[j] - gps[j].mll()) <= RTOL * abs(gps[j].mll())
+    ptr = np.arange(m.L + 1) * Xt.shape[0]
+    mu_l, var_l = m.ctx.predict_leaves(Xt, ptr, np.tile(np.arange(Xt.shape[0]), m.L))
+    for j in sample:
+        mo, vo = gps[j].prediction(Xt)
+        assert np.allclose(mu_l[ptr[j]:ptr[j + 1]], mo, rtol=RTOL, atol=1e-9)
+        assert np.allclose(var_l[ptr[j]:ptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
+    mu, var = dsm.predict(m, Xt)
+    t = 1.0 / var_l.reshape(m.L, -1)
+    assert np.allclose(var, 1.0 / t.sum(0), rtol=1e-12)
+    assert np.allclose(mu, (t * mu_l.reshape(m.L, -1)).sum(0) / t.sum(0), rtol=1e-11, atol=1e-12)
+
+
+def test_config4_headline_size_sampled_against_oracle_and_properties():
+    """BASELINE config 4 (the bench workload): buildDSMGP K=4 splits V=3 M=200 N=100k D=8 IsoSE, 144 leaves with
+    n ~ 1.4k-13k.  Too large for a full oracle run: three sampled leaves are compared with the oracle (mll,
+    alpha, predictions), and the whole model through size-independent properties."""
+    import bench
+    model, X, y, Xt, ptr, idx = bench.build_model("dsmgp_n100k_d8", 0, 1, 0)
+    assert model.L == 144
+    dsm.fit(model)
+    z = dsm.update(model)
+    mu, var = dsm.predict(model, Xt)
+    nobs = np.array([lf.nobs for lf in model.leaves])
+    order = np.argsort(nobs)
+    mu_l, var_l = model.ctx.predict_fetch()
+    for j in (order[0], order[20], order[60]):              # n = 1.4k, ~3k, ~5k
+        lf = model.leaves[j]
+        g = ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.IsoSE(lf.kernel.logl, lf.kernel.logs), lf.logNoise,
+                                exact_dist=True).update_cholesky()
+        assert abs(model.leaf_mll[j] - g.mll()) <= RTOL * abs(g.mll())
+        _, alpha = model.ctx.download_factor(j, lf.nobs)
+        assert np.max(np.abs(alpha - g.alpha)) <= 1e-7 * np.max(np.abs(g.alpha))
+        rows = idx[ptr[j]:ptr[j + 1]]
+        mo, vo = g.prediction(Xt[rows])
+        assert np.allclose(mu_l[ptr[j]:ptr[j + 1]], mo, rtol=RTOL, atol=1e-9)
+        assert np.allclose(var_l[ptr[j]:ptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
+    # properties of the whole model
+    m0 = model.leaf_mll.copy()
+    assert np.all(np.isfinite(model.leaf_mll)) and np.all(model.leaf_info == 0)
+    assert abs(z - dsm.mll(model)) <= 1e-9 * abs(z)                        # update! returns the tree mll
+    noise = np.exp(2 * np.log(0.1))
+    assert np.all(var_l > noise) and np.all(var_l < 1.0 + noise + 1e-9)    # prior variance bounds per leaf
+    assert np.all(var > noise * 0.999)                                     # law of total variance keeps the noise floor
+    cnt = np.diff(ptr)
+    assert cnt.sum() == 9 * Xt.shape[0]                                    # V^depth leaves per test row
+    # the mixture mean lies between the extreme leaf means of each row
+    lo = np.full(Xt.shape[0], np.inf)
+    hi = np.full(Xt.shape[0], -np.inf)
+    np.minimum.at(lo, idx, mu_l)
+    np.maximum.at(hi, idx, mu_l)
+    assert np.all(mu >= lo - 1e-9) and np.all(mu <= hi + 1e-9)
+    # refit is idempotent (bit-reproducible schedule, no atomics); the test set is resident now, so both fits
+    # below take the joint path (a different split-K schedule than the first fit: last-bit differences only)
+    dsm.fit(model)
+    assert np.allclose(m1 := model.leaf_mll.copy(), model.leaf_mll, rtol=0) and np.allclose(m1, m0, rtol=1e-12)
+    dsm.fit(model)
+    assert np.array_equal(m1, model.leaf_mll)
+    mu2, var2 = dsm.predict(model, Xt)
+    assert np.allclose(mu2, mu, rtol=1e-10, atol=1e-12) and np.allclose(var2, var, rtol=1e-9, atol=1e-13)
+    rmse = np.sqrt(np.mean((mu - (np.mean([np.sin(2 * np.pi * (d + 1) * Xt[:, d]) for d in range(8)], axis=0))) ** 2))
+    assert rmse < 0.35                                                     # bounded error against the noiseless target
+
+
+def test_config5_scaled_kernel_vector_training():
+    """BASELINE config 5 scaled to oracle size: KernelFunction[IsoSE, IsoLinear], D=16, train!(ADAM) loop -- the
+    per-kernel-id hyper-vector, sum-over-GPs weights (infer!) and the gradient back-propagation through them."""
+    N, D = 4000, 16
+    X, y, Xt = regression_data(N, D, n_test=100, seed=20205)
+    kv = [dsm.IsoSE(np.log(1.0), 0.0), dsm.IsoLinear(np.log(2.0))]
+    m = dsm.buildDSMGP(X, y, 3, 4, M=150, kernel=kv, logNoise=np.log(0.3), seed=5)
+    h0 = dsm.getparams(m).copy()
+    _, hist = dsm.train(m, dsm.ADAM(eta=0.01), iterations=3, randinit=False)
+    hyp = h0.copy()
+    opt = dsm.ADAM(eta=0.01)
+    ref = []
+    trained = dsm.getparams(m).copy()
+    for it in range(3):
+        dsm.setparams(m, hyp)
+        gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+        ospn.fit_naive(m.root, gps)
+        ref.append(ospn.mll(m.root, gps))
+        hyp = hyp + opt.apply(hyp, ospn.grad_tree(m.root, gps, hyp.size))
+    assert np.allclose(hist, ref, rtol=RTOL)
+    assert np.allclose(trained, hyp, rtol=1e-9, atol=1e-12)
+    dsm.setparams(m, trained)
+    dsm.fit(m)
+    zi = dsm.infer(m)
+    gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+    ospn.fit_naive(m.root, gps)
+    assert abs(zi - ospn.infer(m.root, gps)) <= RTOL * abs(zi)
+    mu, var = dsm.predict(m, Xt)
+    mo, vo = ospn.predict(m.root, gps, Xt)
+    assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9) and np.allclose(var, vo, rtol=RTOL, atol=1e-10)
