@@ -183,12 +183,17 @@ def main():
         avg_launch = cats["chol_update"] / max(1, upd_launches)
         flops_per_launch = alg_flops * args.steps / max(1, upd_launches)
         achieved = flops_per_launch / avg_launch / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_update_kernel_traffic.json")
+        if os.path.exists(tpath) and world == 1:   # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": None, "kernel": "tile_gemm_kernel<true> (chol_update)",
+                "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                "kernel": "tile_gemm_kernel_v2 (update launches of the factorisation, test rows riding along)",
                 "avg_launch_ms": avg_launch * 1e3, "launches_per_step": upd_launches // args.steps,
                 "alg_flops_per_step": alg_flops}
     nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)
-    chol_flops_total = float(np.sum(nobs ** 3) / 3)
+    matrix_flops_total = float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2 * np.diff(ptr)))   # Cholesky + predict solves
 
     if rank == 0:
         c = CONFIGS[args.config]
@@ -202,8 +207,8 @@ def main():
                                    f"n_t={Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; "
                                    f"fit! (Gram+Cholesky+alpha+mll) + update! + predict",
                        "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and (mu, var)"},
-            "leaf_cholesky_tflops": chol_flops_total / (cats.get("total_fit", per_step * args.steps) / args.steps) / 1e12 / 1.0
-            if world == 1 else None,
+            "matrix_tflops_fit_predict": matrix_flops_total / ((cats.get("total_fit", 0.0) + cats.get("total_predict", 0.0))
+                                                               / args.steps) / 1e12 if world == 1 else None,
             "device_seconds_per_step": {k: v / args.steps for k, v in cats.items() if v > 0},
         }
         if roof is not None:
