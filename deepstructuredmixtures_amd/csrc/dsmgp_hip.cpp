@@ -79,6 +79,8 @@ void xcd_permute(std::vector<T>& a, std::vector<U>& b, size_t begin, size_t end,
 struct UpdateSplitter {
     int ncu = 256;
     bool xcd = true;
+    int tail_split = 4;     // K pieces per tile in the tail of a launch
+    int tail_rounds = 1;    // full rounds (of ncu tiles) that belong to the tail
     std::vector<TileTask> upd;
     std::vector<ReduceTask> red;
     std::vector<int64_t> upd_slab, red_slab;   // slab index of a task's output / first slab, -1 = none
@@ -150,14 +152,18 @@ struct UpdateSplitter {
         if ((int)T < ncu) {
             emit(tiles, 0, T, choose_split((int)T, K, ncu), slab);
         } else {
+            // Whole tiles first, in rounds of one per CU; the tail of the launch -- the partial last round plus
+            // `tail_rounds` full ones -- is cut into `tail_split` K pieces per tile and issued last, so the
+            // launch ends on short tasks instead of idling CUs for up to a whole tile time.
             const size_t r = T % (size_t)ncu;
-            int S = 1;
-            if (r > 0 && r * 10 < (size_t)ncu * 7) {
-                S = (int)std::min<size_t>((size_t)ncu / r, 32);
-                S = std::min(S, std::max(1, K / 256));
-            }
-            emit(tiles, 0, T - (S > 1 ? r : 0), 1, slab);
-            if (S > 1) emit(tiles, T - r, T, S, slab);
+            size_t ntail = r + (size_t)tail_rounds * ncu;
+            if (ntail > T) ntail = T;
+            int S = std::min(tail_split, std::max(1, K / 256));
+            if (r > 0 && r * 4 < (size_t)ncu) S = std::max(S, (int)std::min<size_t>((size_t)ncu / r, 16));   // tiny remainder: finer
+            S = std::min(S, std::max(1, K / 256));
+            if (S <= 1 || r == 0) ntail = 0;   // an exact multiple of the CU count already ends evenly
+            emit(tiles, 0, T - ntail, 1, slab);
+            if (ntail) emit(tiles, T - ntail, T, S, slab);
         }
         max_slabs = std::max(max_slabs, slab);
     }
@@ -218,6 +224,7 @@ struct dsmgp_ctx {
     int ncu = 256;
     int tile_variant = 2;           // 1: two-buffer kernel, 2: software-pipelined ring kernel
     bool xcd_order = true;          // XCD-aware task order (speed only)
+    int tail_split = 4, tail_rounds = 1;
     std::vector<int> fwd_off, bwd_off;
     DevBuf<SolveTask> fwd, bwd;
     int solve_steps = 0;
@@ -451,6 +458,8 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         UpdateSplitter& U = split[ph];
         U.ncu = c->ncu;
         U.xcd = c->xcd_order;
+        U.tail_split = c->tail_split;
+        U.tail_rounds = c->tail_rounds;
         auto in_phase = [&](const LeafHost& lf) { return (lf.op == DSMGP_SHARE_PREFIX) == (ph == 1); };
         int nsteps = 0;
         for (int l = 0; l < L; ++l) {
@@ -862,6 +871,8 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     }
     if (const char* s = std::getenv("DSMGP_TILE_V")) c->tile_variant = std::atoi(s);
     if (const char* s = std::getenv("DSMGP_XCD")) c->xcd_order = std::atoi(s) != 0;
+    if (const char* s = std::getenv("DSMGP_TAIL_SPLIT")) c->tail_split = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("DSMGP_TAIL_ROUNDS")) c->tail_rounds = std::max(0, std::atoi(s));
     const char* p = std::getenv("DSMGP_PROFILE");
     c->profile = p && p[0] == '1';
     *out = c;
@@ -1220,6 +1231,8 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     UpdateSplitter U;
     U.ncu = c->ncu;
     U.xcd = c->xcd_order;
+    U.tail_split = c->tail_split;
+    U.tail_rounds = c->tail_rounds;
     std::vector<TileTask> trsm;
     c->pupd_off.assign(nsteps + 1, 0);
     c->pred_off.assign(nsteps + 1, 0);
@@ -1410,6 +1423,8 @@ int build_grad_plan(dsmgp_ctx* c) {
     UpdateSplitter U;
     U.ncu = c->ncu;
     U.xcd = c->xcd_order;
+    U.tail_split = c->tail_split;
+    U.tail_rounds = c->tail_rounds;
     std::vector<TileTask> trsm;
     c->gupd_off.assign(nsteps + 1, 0);
     c->gred_off.assign(nsteps + 1, 0);
@@ -1772,6 +1787,8 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     UpdateSplitter U;
     U.ncu = c->ncu;
     U.xcd = c->xcd_order;
+    U.tail_split = c->tail_split;
+    U.tail_rounds = c->tail_rounds;
     double* slabs = nullptr;
     if (mode == 2) {
         U.add_step(tasks, K);
