@@ -185,7 +185,7 @@ def main():
         achieved = flops_per_launch / avg_launch / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_update_kernel_traffic.json")
-        if os.path.exists(tpath) and world == 1:   # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        if os.path.exists(tpath) and world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard:   # from the committed rocprofv3 --pmc passes of this command
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic,

@@ -238,7 +238,9 @@ struct dsmgp_ctx {
     std::vector<int64_t> route_ptr;
     double* arenaVt = nullptr;
     double* arenaXt = nullptr;
-    double* arenaPV = nullptr;      // per leaf: mu, var (2 x ntpad)
+    double* arenaPV = nullptr;      // mu | var (route order, unpadded) | macc | sacc (padded accumulators of the sweep)
+    size_t acc_off = 0, acc_count = 0;
+    DevBuf<PredTask> ptasks_slow;   // test tiles of leaves whose z is not produced during the factorisation
     DevBuf<GramTask> pgram;
     DevBuf<PredTask> ptasks;
     std::vector<int> pupd_off, pred_off, ptrsm_off;
@@ -352,6 +354,7 @@ void free_test(dsmgp_ctx* c) {
     dev_free(c->arenaPV);
     dev_free(c->pgram.p);
     dev_free(c->ptasks.p);
+    dev_free(c->ptasks_slow.p);
     dev_free(c->pupd.p);
     dev_free(c->ptrsm.p);
     dev_free(c->pred.p);
@@ -560,6 +563,11 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         s.k0 = 0;
                         s.k1 = TB;
                         s.update = 0;
+                        if (d.zfused) {   // z_k exists by the time this launch runs: accumulate mu and the variance term
+                            s.zk = d.z + (size_t)k * TB;
+                            s.wi = d.macc + (size_t)ti * TB;
+                            s.sq = d.sacc + (size_t)ti * TB;
+                        }
                         trsm.push_back(s);
                     }
                 }
@@ -734,26 +742,35 @@ int build_plan(dsmgp_ctx* c) {
             }
         }
         c->fwd_off[nsteps] = (int)fwd.size();
-        // backward sweep: step s handles block kb = nb-1-s of each leaf, on w = copy of z (z itself is kept:
-        // the predictive mean is m + (K_tn L^-T) z)
+        // backward sweep on w = copy of z (z itself is kept: the predictive mean is m + (K_tn L^-T) z).
+        // launch 0: alpha of every leaf's last block; launch s >= 1: block kb = nb-s updates the blocks left of
+        // it with alpha_kb, and the task of block kb-1 finishes alpha_{kb-1} in the same workgroup.
         for (int s_ = 0; s_ < nsteps; ++s_) {
             c->bwd_off[s_] = (int)bwd.size();
             for (int l = 0; l < L; ++l) {
                 const LeafHost& lf = c->leaves[l];
-                const int kb = lf.nb - 1 - s_;
-                if (kb < 0) continue;
                 const LeafDev& d = c->h_leaves[l];
-                for (int j = 0; j <= kb; ++j) {
+                if (s_ == 0) {
                     SolveTask s{};
-                    s.Dk = d.Dinv + (size_t)kb * TB * TB;
-                    s.vk = d.w + (size_t)kb * TB;
+                    s.self = 1;
+                    s.Dk = d.Dinv + (size_t)(lf.nb - 1) * TB * TB;
+                    s.vk = d.w + (size_t)(lf.nb - 1) * TB;
+                    s.out_k = d.alpha + (size_t)(lf.nb - 1) * TB;
                     s.ldt = lf.npad;
-                    if (j == kb) {
-                        s.self = 1;
-                        s.out_k = d.alpha + (size_t)kb * TB;
-                    } else {
-                        s.T = d.F + (size_t)kb * TB + (size_t)j * TB * lf.npad;
-                        s.vi = d.w + (size_t)j * TB;
+                    bwd.push_back(s);
+                    continue;
+                }
+                const int kb = lf.nb - s_;
+                if (kb < 1) continue;
+                for (int j = 0; j < kb; ++j) {
+                    SolveTask s{};
+                    s.T = d.F + (size_t)kb * TB + (size_t)j * TB * lf.npad;
+                    s.ldt = lf.npad;
+                    s.vk = d.alpha + (size_t)kb * TB;
+                    s.vi = d.w + (size_t)j * TB;
+                    if (j == kb - 1) {
+                        s.Dk = d.Dinv + (size_t)j * TB * TB;
+                        s.out_k = d.alpha + (size_t)j * TB;
                     }
                     bwd.push_back(s);
                 }
@@ -1054,6 +1071,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     const bool joint = c->joint && c->test_ready && c->joint_ready;
     StepLists* phases = joint ? c->phaseJ : c->phase;
     c->vt_valid = false;
+    if (joint && c->acc_count) HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
     // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98) [+ K_tn tiles]
     if (c->gram.count) {
         pt.begin(0);
@@ -1151,7 +1169,9 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     c->route_total = total;
     c->route_ptr.assign(route_ptr, route_ptr + L + 1);
     size_t vTot = 0, xTot = 0;
-    const size_t pTot = 2 * (size_t)total + 2 * TB;
+    size_t accTot = 0;
+    for (int l = 0; l < L; ++l) accTot += (size_t)round_up((int)(route_ptr[l + 1] - route_ptr[l]), TB);
+    const size_t pTot = 2 * (size_t)total + 2 * accTot + 2 * TB;
     for (int l = 0; l < L; ++l) {
         LeafHost& lf = c->leaves[l];
         lf.nt = (int)(route_ptr[l + 1] - route_ptr[l]);
@@ -1179,6 +1199,9 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     HIPCHK(c, hipMalloc(&c->arenaXt, std::max<size_t>(1, xTot) * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->arenaPV, std::max<size_t>(1, pTot) * sizeof(double)));
     int maxpad = 0;
+    size_t accOff = 0;
+    c->acc_off = 2 * (size_t)total;
+    c->acc_count = 2 * accTot;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
         LeafDev& d = c->h_leaves[l];
@@ -1186,6 +1209,10 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         d.Xtg = c->arenaXt + lf.xt_off;
         d.mu = c->arenaPV + lf.pv_off;
         d.var = c->arenaPV + (size_t)total + lf.pv_off;
+        d.macc = c->arenaPV + 2 * (size_t)total + accOff;
+        d.sacc = d.macc + accTot;
+        d.zfused = (lf.owner == l && lf.op == DSMGP_SHARE_FULL) ? 1 : 0;
+        accOff += (size_t)lf.ntpad;
         d.nt = lf.nt;
         d.ntpad = lf.ntpad;
         maxpad = std::max(maxpad, lf.ntpad);
@@ -1201,7 +1228,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     }
     // task lists
     std::vector<GramTask> pg;
-    std::vector<PredTask> ptk;
+    std::vector<PredTask> ptk, ptk_slow;
     int nsteps = 0;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
@@ -1210,6 +1237,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         const LeafDev& d = c->h_leaves[l];
         for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
             ptk.push_back(PredTask{l, ti * TB});
+            if (!d.zfused) ptk_slow.push_back(PredTask{l, ti * TB});
             for (int j = 0; j < lf.nb; ++j) {
                 GramTask g{};
                 g.xa = d.Xtg + (size_t)ti * TB;
@@ -1271,6 +1299,9 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                 s.k0 = 0;
                 s.k1 = TB;
                 s.update = 0;
+                s.zk = d.z + (size_t)k * TB;           // predictive mean and variance ride along
+                s.wi = d.macc + (size_t)ti * TB;
+                s.sq = d.sacc + (size_t)ti * TB;
                 trsm.push_back(s);
             }
         }
@@ -1286,6 +1317,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
     if (int rc = dev_upload(c, c->pgram, pg)) return rc;
     if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
+    if (int rc = dev_upload(c, c->ptasks_slow, ptk_slow)) return rc;
     // the same test rows as riders of the factorisation launches (used by fit while this test set is resident)
     if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint)) return rc;
     c->joint_ready = true;
@@ -1308,7 +1340,9 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     HIPCHK(c, hipEventCreate(&t1));
     HIPCHK(c, hipEventRecord(t0, c->stream));
     if (c->pgram.count) {
-        if (!c->vt_valid) {
+        const bool standalone = !c->vt_valid;
+        if (standalone) {
+            HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
             // K_tn tiles                                  (src/gaussianprocess.jl:133)
             pt.begin(6);
             gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
@@ -1332,10 +1366,15 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
             }
             c->vt_valid = true;
         }
-        // mu = m + V^T z (= m + K_tn alpha), diag(Ktt - V'V) + noise   (src/gaussianprocess.jl:117-126)
+        // mu = m + V^T z (= m + K_tn alpha), var = diag(Ktt - V'V) + noise   (src/gaussianprocess.jl:117-126):
+        // both sums were accumulated by the panel-solve epilogues of the sweep; leaves whose z did not exist yet
+        // while their rows rode through the factorisation (COPY / PREFIX) are finished from the stored rows
         pt.begin(9);
-        pred_mu_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p);
-        pred_var_kernel<<<(int)c->ptasks.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks.p, c->d_kp, c->D);
+        pred_finish_kernel<<<(int)c->ptasks.count, 128, 0, c->stream>>>(c->d_leaves, c->ptasks.p, c->d_kp, c->D);
+        if (!standalone && c->ptasks_slow.count) {
+            pred_mu_kernel<<<(int)c->ptasks_slow.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks_slow.p);
+            pred_var_kernel<<<(int)c->ptasks_slow.count, 256, 0, c->stream>>>(c->d_leaves, c->ptasks_slow.p, c->d_kp, c->D);
+        }
         pt.end();
     }
     HIPCHK(c, hipGetLastError());

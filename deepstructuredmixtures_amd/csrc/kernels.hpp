@@ -165,8 +165,10 @@ struct TileTask {
     const double* A;
     const double* B;
     double* C;
-    const double* zk;   // solve tasks of the factorisation: z_k = L_kk^-1 w_k (128) ...
-    double* wi;         // ... and the right-hand side block of this row tile: w_i -= X z_k (fused forward solve); else NULL
+    const double* zk;   // panel-solve tasks: z_k = L_kk^-1 w_k (128) ...
+    double* wi;         // ... train rows: right-hand side block of this row tile, w_i -= X z_k (fused forward solve);
+                        //     test rows (sq set): running predictive mean, wi += X z_k.  NULL = no rider
+    double* sq;         // test rows: running sum of squares of the solved row, sq += rowsumsq(X); else NULL
     int lda, ldb, ldc;
     int k0, k1;         // K range, multiples of 8
     int update;         // 0 = store the product, 1 = C - product, 2 = store the negated product
@@ -182,7 +184,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 // Epilogue shared by the tile kernels: register r of acc[cm][rn] is C(row = wr*64+16rn+l15, col = wc*64+16cm+l4+4r).
 // With tk.wi set (panel solve of the factorisation) the forward substitution y -> L^-1 y rides along:
 // w_i -= X z_k, summed per row over the 4 lanes l4, then over the two column halves through LDS (fixed order).
-__device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4], double* red /* >= 256 doubles of LDS */) {
+__device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4], double* red /* >= 512 doubles of LDS */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
@@ -197,27 +199,42 @@ __device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4
                 else *pc = acc[cm][rn][r];
             }
     if (tk.wi != nullptr) {
-        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        double p[4] = {0.0, 0.0, 0.0, 0.0}, q2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int cm = 0; cm < 4; ++cm)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double z = tk.zk[wc * 64 + 16 * cm + l4 + 4 * r];
 #pragma unroll
-                for (int rn = 0; rn < 4; ++rn) p[rn] = fma(acc[cm][rn][r], z, p[rn]);
+                for (int rn = 0; rn < 4; ++rn) {
+                    p[rn] = fma(acc[cm][rn][r], z, p[rn]);
+                    q2[rn] = fma(acc[cm][rn][r], acc[cm][rn][r], q2[rn]);
+                }
             }
 #pragma unroll
         for (int rn = 0; rn < 4; ++rn) {
             p[rn] += __shfl_xor(p[rn], 16);
             p[rn] += __shfl_xor(p[rn], 32);
+            q2[rn] += __shfl_xor(q2[rn], 16);
+            q2[rn] += __shfl_xor(q2[rn], 32);
         }
         __syncthreads();   // the ring is no longer read
         if (l4 == 0) {
 #pragma unroll
-            for (int rn = 0; rn < 4; ++rn) red[wc * TB + wr * 64 + 16 * rn + l15] = p[rn];
+            for (int rn = 0; rn < 4; ++rn) {
+                red[wc * TB + wr * 64 + 16 * rn + l15] = p[rn];
+                red[2 * TB + wc * TB + wr * 64 + 16 * rn + l15] = q2[rn];
+            }
         }
         __syncthreads();
-        if (threadIdx.x < TB) tk.wi[threadIdx.x] -= red[threadIdx.x] + red[TB + threadIdx.x];
+        if (threadIdx.x < TB) {
+            const double s = red[threadIdx.x] + red[TB + threadIdx.x];
+            if (tk.sq == nullptr) tk.wi[threadIdx.x] -= s;
+            else {
+                tk.wi[threadIdx.x] += s;
+                tk.sq[threadIdx.x] += red[2 * TB + threadIdx.x] + red[3 * TB + threadIdx.x];
+            }
+        }
     }
 }
 
@@ -287,12 +304,17 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     } while (0)
 
     const int nch = (tk.k1 - tk.k0) / KC2;
-    // prologue: chunks 0..2 into the ring, chunk 3 in flight in set 1
-    for (int j = 0; j < 3 && j < nch; ++j) {
-        GLOAD(ra0, rb0, j);
-        SWRITE(ra0, rb0, j);
+    // prologue: chunks 0..2 into the ring with the loads overlapped (two memory latencies, not three),
+    // chunk 3 in flight in set 1
+    if (nch > 0) {
+        GLOAD(ra0, rb0, 0);
+        GLOAD(ra1, rb1, min(1, nch - 1));
+        SWRITE(ra0, rb0, 0);
+        GLOAD(ra0, rb0, min(2, nch - 1));
+        SWRITE(ra1, rb1, 1);
+        GLOAD(ra1, rb1, min(3, nch - 1));
+        SWRITE(ra0, rb0, 2);
     }
-    if (nch > 0) GLOAD(ra1, rb1, min(3, nch - 1));
     __syncthreads();
 
     double fa0[4], fb0[4], fa1[4], fb1[4];
@@ -907,28 +929,45 @@ __global__ __launch_bounds__(256) void solve_fwd_kernel(const SolveTask* __restr
     if (t < TB) tk.vi[t] -= red[t];
 }
 
-// backward: a_k = Dk^T v_k ; v_j -= L[k,j]^T a_k
+// backward sweep alpha = L^-T z on w (a copy of z), one launch per block step, block kb = nb-1-s of each leaf:
+//   self task  (first launch only): alpha_kb = D_kb^T w_kb
+//   other tasks: w_j -= L[kb,j]^T alpha_kb (alpha_kb read from memory: tk.vk), and the task of j = kb-1, whose
+//   block is final after this update, goes on to alpha_j = D_j^T w_j (tk.Dk / tk.out_k set), so every step
+//   reads each off-diagonal tile once and each inverse block once.
+__device__ __forceinline__ void matvec_t128(const double* __restrict__ M, int ld, const double* __restrict__ x /* LDS, 128 */,
+                                            double* __restrict__ y /* LDS, 128 */, int lane, int w) {
+    // y = M^T x for a 128x128 column-major block: one column per wave iteration, lanes over rows
+    for (int c = w; c < TB; c += 4) {
+        double s = M[lane + (size_t)c * ld] * x[lane] + M[lane + 64 + (size_t)c * ld] * x[lane + 64];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) y[c] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void solve_bwd_kernel(const SolveTask* __restrict__ tasks) {
     __shared__ double vin[TB], a[TB];
     const SolveTask tk = tasks[blockIdx.x];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t < TB) vin[t] = tk.vk[t];
     __syncthreads();
-    for (int c = w; c < TB; c += 4) {
-        double s = tk.Dk[lane + (size_t)c * TB] * vin[lane] + tk.Dk[lane + 64 + (size_t)c * TB] * vin[lane + 64];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (lane == 0) a[c] = s;
-    }
-    __syncthreads();
     if (tk.self) {
+        matvec_t128(tk.Dk, TB, vin, a, lane, w);
+        __syncthreads();
         if (t < TB) tk.out_k[t] = a[t];
         return;
     }
-    for (int c = w; c < TB; c += 4) {
-        double s = tk.T[lane + (size_t)c * tk.ldt] * a[lane] + tk.T[lane + 64 + (size_t)c * tk.ldt] * a[lane + 64];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (lane == 0) tk.vi[c] -= s;
+    matvec_t128(tk.T, tk.ldt, vin, a, lane, w);      // a = L[kb,j]^T alpha_kb
+    __syncthreads();
+    if (t < TB) {
+        const double v = tk.vi[t] - a[t];
+        tk.vi[t] = v;
+        vin[t] = v;
     }
+    if (tk.Dk == nullptr) return;
+    __syncthreads();
+    matvec_t128(tk.Dk, TB, vin, a, lane, w);         // block j is final: alpha_j = D_j^T w_j
+    __syncthreads();
+    if (t < TB) tk.out_k[t] = a[t];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -949,8 +988,11 @@ struct LeafDev {
     const double* Xtg;    // gathered test inputs, ntpad x D (ld = ntpad)
     double* mu;           // nt (contiguous over leaves in route order)
     double* var;          // nt
+    double* macc;         // ntpad: running V^T z of the sweep (panel-solve epilogue)
+    double* sacc;         // ntpad: running rowsumsq(V^T)
     int nt, ntpad;
-    int pad0, pad1;
+    int zfused;           // z is produced during the factorisation (leaf factorised in full)
+    int pad1;
 };
 
 // yc = y[obs] - mean, Xg = X[obs, :]; one workgroup per (leaf, 256-row slab)
@@ -1039,6 +1081,29 @@ __global__ __launch_bounds__(256) void pred_mu_kernel(const LeafDev* __restrict_
     for (int c = h; c < lf.n; c += 2) s = fma(V[(size_t)c * lf.ntpad], lf.z[c], s);
     block_reduce_store(s, red, t);
     if (t < TB && tk.row0 + t < lf.nt) lf.mu[tk.row0 + t] = lf.mean + red[t];
+}
+
+// mu = m + macc, var = k(x*,x*) + noise - sacc for the rows whose moments were accumulated by the sweep
+__global__ __launch_bounds__(128) void pred_finish_kernel(const LeafDev* __restrict__ leaves, const PredTask* __restrict__ tasks,
+                                                          const KParam* __restrict__ kp, int D) {
+    const PredTask tk = tasks[blockIdx.x];
+    const LeafDev lf = leaves[tk.leaf];
+    const KParam p = kp[lf.kid];
+    const int r = tk.row0 + threadIdx.x;
+    if (r >= lf.nt) return;
+    double kss;
+    if (p.kind == 0) kss = p.sigma2;
+    else if (p.kind == 1) kss = p.sigma2 * (double)D;
+    else {
+        double q = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double x = lf.Xtg[r + (size_t)d * lf.ntpad];
+            q = fma(x, x, q);
+        }
+        kss = q / p.l2[0];
+    }
+    lf.mu[r] = lf.mean + lf.macc[r];
+    lf.var[r] = (kss - lf.sacc[r]) + p.noise;
 }
 
 // var = k(x*,x*) + noise - sum_c V(t,c)^2

@@ -499,8 +499,39 @@ def predict(model, xtest):
     rc = _routing(model, xt)
     mu, var = _leaf_moments(model, xt, rc)
     if model.family == "dsmgp":
-        return _aggregate_dsmgp(model, xt, rc["ptr"], mu, var, rc["masks"])
+        return _aggregate_dsmgp_flat(model, xt.shape[0], rc, mu, var)
     return _aggregate_poe(model, xt, rc["ptr"], mu, var)
+
+
+def _aggregate_dsmgp_flat(model, n_t, rc, mu, var):
+    """The nested log-domain recursion of `_predict` (`src/common.jl:275-302`) is linear in the leaf quantities
+    (mu - c, mu^2, sigma^2): unrolled, a test row's prediction is the flat mixture over the leaves it visits with
+    weight = product of the sum-node weights on the leaf's path (split nodes only route).  So
+        mu = sum_l W_l mu_l,   v = sum_l W_l sigma2_l + sum_l W_l mu_l^2 - mu^2
+    in three weighted bincounts over the (leaf, row) entries.  `_aggregate_dsmgp` below is the literal recursion,
+    kept as the cross-check (tests/test_host_cpu.py)."""
+    logW = np.zeros(model.L)
+
+    def rec(node, lw):
+        if node.kind == "gp":
+            logW[node.leaf] = lw
+        elif node.kind == "sum":
+            for k, c in enumerate(node.children):
+                rec(c, lw + node.logweights[k])
+        else:
+            for c in node.children:
+                rec(c, lw)
+
+    rec(model.root, 0.0)
+    ptr, idx = rc["ptr"], rc["idx"]
+    w = np.repeat(np.exp(logW), np.diff(ptr))
+    s2 = np.where(var <= 0, EPS, var)                       # src/common.jl:137
+    m = np.bincount(idx, weights=w * mu, minlength=n_t)
+    m2 = np.bincount(idx, weights=w * mu * mu, minlength=n_t)
+    sv = np.bincount(idx, weights=w * s2, minlength=n_t)
+    if model.root.kind == "gp":
+        return m, sv
+    return m, sv + (m2 - m * m)
 
 
 def _aggregate_dsmgp(model, xt, ptr, mu, var, sel_cache=None):

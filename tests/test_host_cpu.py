@@ -128,6 +128,12 @@ def test_host_aggregation_matches_reference_recursion(golden_dir, fixture):
     mu, var = dsm.predict(m, xt)
     assert np.allclose(mu, z["mu"], rtol=1e-9, atol=1e-10)
     assert np.allclose(var, z["var"], rtol=1e-8, atol=1e-10)
+    # the flat weighted-bincount aggregation used by predict == the literal reference recursion
+    from deepstructuredmixtures_amd import model as pmodel
+    rc = m._route_cache
+    mu_l, var_l = m.ctx.predict_fetch()
+    mr, vr = pmodel._aggregate_dsmgp(m, np.asfortranarray(xt), rc["ptr"], mu_l, var_l)
+    assert np.allclose(mu, mr, rtol=1e-12, atol=1e-13) and np.allclose(var, vr, rtol=1e-9, atol=1e-13)
     tab = dsm.mll_table(m)
     assert abs(tab[m.root.id] - dsm.mll(m)) < 1e-12
     # infer! resets non-GP sums to uniform (src/common.jl:347-353)
