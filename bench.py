@@ -109,8 +109,16 @@ def main():
     td = None
     if world > 1:
         import torch.distributed as td
+        ndev = torch.cuda.device_count()
+        backend = os.environ.get("DSMGP_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on one GPU
+        if backend == "nccl":
+            assert ndev >= world, f"{world} ranks need {world} GPUs, {ndev} visible"
+        local_rank = local_rank % max(1, ndev)
         torch.cuda.set_device(local_rank)
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import deepstructuredmixtures_amd as dsm
@@ -170,7 +178,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if td is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
     per_step = elapsed / args.steps
