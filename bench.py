@@ -33,13 +33,13 @@ CONFIGS = {
 }
 
 
-def build_model(cfg, rank, world, device):
+def build_model(cfg, rank, world, device, n_sub=1):
     import deepstructuredmixtures_amd as dsm
     from deepstructuredmixtures_amd import dist as pdist, tree as ptree
     c = CONFIGS[cfg]
     X, y, Xt = dsm.regression_data(c["N"], c["D"], seed=20204)
     model = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=dsm.IsoSE(np.log(0.3), 0.0),
-                           logNoise=np.log(0.1), seed=20204, fit_now=False, device=device)
+                           logNoise=np.log(0.1), seed=20204, fit_now=False, device=device, n_sub=n_sub)
     ptr, idx = ptree.route(model.root, Xt)
     if world > 1:
         op, src, _ = ptree.share_schedule(model.leaves, model.D, 0.05)
@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--config", default="dsmgp_n100k_d8", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
+    ap.add_argument("--sub", type=int, default=None,
+                    help="concurrent contexts per GPU (default: 1 on one GPU, 2 per rank when sharded)")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
                     help="diagnostic: run only rank R's leaf shard of a W-rank job on this one GPU (no exchange; "
                          "not a valid bench line)")
@@ -125,7 +127,8 @@ def main():
     if args.simulate_shard:
         from deepstructuredmixtures_amd import dist as pdist
         r_, w_ = map(int, args.simulate_shard.split("/"))
-        model, X, y, Xt, ptr, idx = build_model(args.config, r_, w_, local_rank)
+        n_sub = args.sub if args.sub is not None else 2
+        model, X, y, Xt, ptr, idx = build_model(args.config, r_, w_, local_rank, n_sub)
         own = model.shard.owner
         loc = np.flatnonzero(own == r_)
 
@@ -147,7 +150,8 @@ def main():
         n3 = np.array([lf.nobs for lf in model.leaves], dtype=float) ** 3
         print(f"# shard {r_}/{w_}: {loc.size} leaves, {n3[loc].sum() / n3.sum():.3f} of the Cholesky flops", file=sys.stderr)
     else:
-        model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank)
+        n_sub = args.sub if args.sub is not None else (1 if world == 1 else 2)
+        model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
     ctx = model.ctx
     ctx.set_profile(not args.no_profile)
 

@@ -192,13 +192,12 @@ struct dsmgp_ctx {
     std::vector<int64_t> obs_ptr, obs_idx;
     int64_t* d_obs_ptr = nullptr;
     int64_t* d_obs_idx = nullptr;
-    bool sharing_set = false;
     bool plan_ready = false;
 
     std::vector<HyperHost> hyper;
     KParam* d_kp = nullptr;
     double* d_l2 = nullptr;
-    int kp_count = 0;
+    size_t kp_cap = 0, l2_cap = 0;   // capacities of d_kp / d_l2 (elements)
 
     double* arenaF = nullptr;
     double* arenaDinv = nullptr;
@@ -401,14 +400,20 @@ int upload_hyper(dsmgp_ctx* c) {
         kp[k].sigma = (h.kind == DSMGP_KIND_ISO_LINEAR) ? 1.0 : std::exp(logs);
         kp[k].noise = std::exp(2.0 * logn);
     }
-    dev_free(c->d_l2);
-    dev_free(c->d_kp);
-    HIPCHK(c, hipMalloc(&c->d_l2, std::max<size_t>(1, l2pool.size()) * sizeof(double)));
-    HIPCHK(c, hipMemcpy(c->d_l2, l2pool.data(), l2pool.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (l2pool.size() > c->l2_cap || !c->d_l2) {   // (re)allocate only when the table grows: fit is called in loops
+        dev_free(c->d_l2);
+        c->l2_cap = std::max<size_t>(16, 2 * l2pool.size());
+        HIPCHK(c, hipMalloc(&c->d_l2, c->l2_cap * sizeof(double)));
+    }
+    if ((size_t)nk > c->kp_cap || !c->d_kp) {
+        dev_free(c->d_kp);
+        c->kp_cap = std::max<size_t>(4, 2 * (size_t)nk);
+        HIPCHK(c, hipMalloc(&c->d_kp, c->kp_cap * sizeof(KParam)));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_l2, l2pool.data(), l2pool.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     for (int k = 0; k < nk; ++k) kp[k].l2 = c->d_l2 + off[k];
-    HIPCHK(c, hipMalloc(&c->d_kp, std::max(1, nk) * sizeof(KParam)));
-    HIPCHK(c, hipMemcpy(c->d_kp, kp.data(), nk * sizeof(KParam), hipMemcpyHostToDevice));
-    c->kp_count = nk;
+    HIPCHK(c, hipMemcpyAsync(c->d_kp, kp.data(), nk * sizeof(KParam), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // l2pool / kp are stack storage
     return 0;
 }
 
@@ -989,7 +994,6 @@ int dsmgp_set_leaves(dsmgp_ctx* c, int32_t L, const int64_t* obs_ptr, const int6
     HIPCHK(c, hipMalloc(&c->d_obs_idx, std::max<size_t>(1, c->obs_idx.size()) * sizeof(int64_t)));
     HIPCHK(c, hipMemcpy(c->d_obs_ptr, obs_ptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_obs_idx, obs_idx, c->obs_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    c->sharing_set = false;
     return 0;
 }
 
@@ -1027,7 +1031,6 @@ int dsmgp_set_sharing(dsmgp_ctx* c, const int32_t* op, const int32_t* src, const
         lf.op = o;
         lf.src = src[l];
     }
-    c->sharing_set = true;
     free_plan(c);
     return 0;
 }

@@ -171,7 +171,7 @@ struct TileTask {
     double* sq;         // test rows: running sum of squares of the solved row, sq += rowsumsq(X); else NULL
     int lda, ldb, ldc;
     int k0, k1;         // K range, multiples of 8
-    int update;         // 0 = store the product, 1 = C - product, 2 = store the negated product
+    int update;         // 0 = store the product, 1 = C - product
 };
 
 // diagnostic builds (tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
@@ -195,7 +195,6 @@ __device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4
             for (int r = 0; r < 4; ++r) {
                 gf64_ptr pc = AS_GLOBAL_F64(tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc);
                 if (tk.update == 1) *pc = *pc - acc[cm][rn][r];
-                else if (tk.update == 2) *pc = -acc[cm][rn][r];
                 else *pc = acc[cm][rn][r];
             }
     if (tk.wi != nullptr) {

@@ -245,3 +245,176 @@ class Context:
         t = C.c_double(0.0)
         self._chk(self.lib.dsmgp_probe_f64_mfma(self.h, C.byref(t)))
         return t.value
+
+
+class MultiContext:
+    """Several contexts on ONE GPU, each with a share of the leaves and its own HIP stream, driven concurrently
+    from host threads (the ABI calls release the GIL).  While one context sits in the latency-bound panel phases
+    of its factorisation (diagonal blocks, panel solves, split-K reduces), the other's update launches fill the
+    chip.  Leaves are independent, so results are exactly those of the single-context run per leaf.  Used for the
+    per-rank shard of multi-GPU runs, where launches are too small to fill the GPU on their own."""
+
+    def __init__(self, device=0, n=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.subs = [Context(device) for _ in range(n)]
+        self.pool = ThreadPoolExecutor(max_workers=n)
+        self.L = 0
+        self.route_total = 0
+        self._leaves = None
+        self._sharing = (None, None, None)
+        self._dirty = True
+        self._test = None
+        self._test_dirty = False
+        self.part = None
+
+    def close(self):
+        for s in self.subs:
+            s.close()
+        self.pool.shutdown(wait=False)
+
+    def device_name(self):
+        return self.subs[0].device_name()
+
+    def _each(self, fn):
+        return list(self.pool.map(fn, self.subs))
+
+    def set_train(self, X, y):
+        for s in self.subs:
+            s.set_train(X, y)
+        self._dirty = True
+
+    def set_leaves(self, obs_ptr, obs_idx, kernel_id, mean):
+        self._leaves = (np.asarray(obs_ptr, dtype=np.int64), np.asarray(obs_idx, dtype=np.int64),
+                        np.asarray(kernel_id, dtype=np.int32), np.asarray(mean, dtype=np.float64))
+        self.L = len(obs_ptr) - 1
+        self._sharing = (None, None, None)
+        self._dirty = True
+        self._test = None
+
+    def set_sharing(self, op, src, plen):
+        self._sharing = (None, None, None) if op is None else (np.asarray(op), np.asarray(src), np.asarray(plen))
+        self._dirty = True
+
+    def set_hyper(self, kernel_id, kind, loghyp):
+        for s in self.subs:
+            s.set_hyper(kernel_id, kind, loghyp)
+
+    def set_joint(self, on):
+        for s in self.subs:
+            s.set_joint(on)
+
+    def set_profile(self, on):
+        for s in self.subs:
+            s.set_profile(on)
+
+    def _partition(self):
+        """Leaves -> sub-context by longest-processing-time on n^3, sharing groups kept together."""
+        ptr = self._leaves[0]
+        n = np.diff(ptr).astype(np.float64)
+        op, src, _ = self._sharing
+        group = np.arange(self.L)
+        if op is not None:
+            for j in range(self.L):
+                if op[j] != 0 and src[j] >= 0:
+                    group[j] = src[j]
+        cost = np.zeros(self.L)
+        for j in range(self.L):
+            cost[group[j]] += n[j] ** 3 if (op is None or op[j] == 0) else n[j] ** 2
+        load = np.zeros(len(self.subs))
+        owner_of = {}
+        for g in sorted(set(group.tolist()), key=lambda g: -cost[g]):
+            r = int(np.argmin(load))
+            owner_of[g] = r
+            load[r] += cost[g]
+        owner = np.array([owner_of[g] for g in group])
+        return [np.flatnonzero(owner == r) for r in range(len(self.subs))]
+
+    def _upload(self):
+        if not self._dirty:
+            return
+        ptr, idx, kid, mean = self._leaves
+        op, src, plen = self._sharing
+        self.part = self._partition()
+        for s, loc in zip(self.subs, self.part):
+            lptr = np.concatenate([[0], np.cumsum(ptr[loc + 1] - ptr[loc])])
+            lidx = np.concatenate([idx[ptr[g]:ptr[g + 1]] for g in loc]) if len(loc) else np.zeros(0, np.int64)
+            s.set_leaves(lptr, lidx, kid[loc], mean[loc])
+            if op is None:
+                s.set_sharing(None, None, None)
+            else:
+                g2l = {int(g): i for i, g in enumerate(loc)}
+                s.set_sharing(op[loc], np.array([g2l.get(int(src[g]), -1) for g in loc], dtype=np.int32), plen[loc])
+        self._dirty = False
+        self._test_dirty = self._test is not None
+
+    def _upload_test(self):
+        if not self._test_dirty:
+            return
+        Xt, rptr, ridx = self._test
+        for s, loc in zip(self.subs, self.part):
+            lptr = np.concatenate([[0], np.cumsum(rptr[loc + 1] - rptr[loc])])
+            lidx = np.concatenate([ridx[rptr[g]:rptr[g + 1]] for g in loc]) if len(loc) else np.zeros(0, np.int64)
+            s.set_test(Xt, lptr, lidx)
+        self._test_dirty = False
+
+    def fit(self):
+        self._upload()
+        self._upload_test()
+        res = self._each(lambda s: s.fit())
+        mll = np.empty(self.L)
+        info = np.empty(self.L, dtype=np.int32)
+        for (m, i, _), loc in zip(res, self.part):
+            mll[loc] = m
+            info[loc] = i
+        return mll, info, max(r[2] for r in res)
+
+    def set_test(self, Xt, route_ptr, route_idx):
+        self._test = (np.asfortranarray(Xt, dtype=np.float64), np.asarray(route_ptr, dtype=np.int64),
+                      np.asarray(route_idx, dtype=np.int64))
+        self.route_total = int(route_ptr[-1])
+        self._test_dirty = True
+        if not self._dirty:
+            self._upload_test()
+
+    def predict_run(self):
+        self._upload()
+        self._upload_test()
+        return max(self._each(lambda s: s.predict_run()))
+
+    def predict_fetch(self):
+        _, rptr, _ = self._test
+        mu = np.empty(self.route_total)
+        var = np.empty(self.route_total)
+        for s, loc in zip(self.subs, self.part):
+            m, v = s.predict_fetch()
+            pos = 0
+            for g in loc:
+                c = int(rptr[g + 1] - rptr[g])
+                mu[rptr[g]:rptr[g + 1]] = m[pos:pos + c]
+                var[rptr[g]:rptr[g + 1]] = v[pos:pos + c]
+                pos += c
+        return mu, var
+
+    def predict_leaves(self, Xt, route_ptr, route_idx):
+        self.set_test(Xt, route_ptr, route_idx)
+        self.predict_run()
+        return self.predict_fetch()
+
+    def gradients(self, stride):
+        self._upload()
+        res = self._each(lambda s: s.gradients(stride))
+        g = np.zeros((self.L, stride))
+        for r, loc in zip(res, self.part):
+            g[loc] = r
+        return g
+
+    def timings(self):
+        ts = [s.timings() for s in self.subs]
+        return {k: max(t[k] for t in ts) for k in ts[0]}
+
+    def work(self):
+        ws = [s.work() for s in self.subs]
+        return sum(w[0] for w in ws), max(w[1] for w in ws)
+
+    def probe_f64_mfma(self):
+        return self.subs[0].probe_f64_mfma()

@@ -509,3 +509,25 @@ def test_config5_scaled_kernel_vector_training():
     mu, var = dsm.predict(m, Xt)
     mo, vo = ospn.predict(m.root, gps, Xt)
     assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9) and np.allclose(var, vo, rtol=RTOL, atol=1e-10)
+
+
+def test_concurrent_sub_contexts_give_the_single_context_result():
+    """hipabi.MultiContext: the leaves of one GPU split over two contexts driven from two host threads
+    (overlaps one context's panel phases with the other's update launches).  Per-leaf results are independent
+    of the split, so everything matches the single-context model (last-bit differences from split-K schedules)."""
+    X, y, Xt = regression_data(6000, 3, n_test=400, seed=555)
+    kw = dict(M=80, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=5)
+    m1 = dsm.buildDSMGP(X, y, 3, 4, **kw)
+    m2 = dsm.buildDSMGP(X, y, 3, 4, n_sub=2, **kw)
+    assert isinstance(m2.ctx, hipabi.MultiContext) and all(len(p) > 0 for p in m2.ctx.part)
+    assert np.allclose(m1.leaf_mll, m2.leaf_mll, rtol=1e-12)
+    z1, z2 = dsm.update(m1), dsm.update(m2)
+    assert abs(z1 - z2) <= 1e-11 * abs(z1)
+    for _ in range(2):                       # second round: test rows ride through fit in both models
+        a, b = dsm.predict(m1, Xt), dsm.predict(m2, Xt)
+        assert np.allclose(a[0], b[0], rtol=1e-10, atol=1e-12) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-13)
+        dsm.fit(m1)
+        dsm.fit(m2)
+    dsm.updategradients(m1)
+    dsm.updategradients(m2)
+    assert np.allclose(dsm.grad_mll(m1), dsm.grad_mll(m2), rtol=1e-9, atol=1e-10)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-rank step time of a W-rank job, simulated one shard at a time on one GPU (no exchange)
 for sh in "$@"; do
-  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --simulate-shard $sh > /tmp/sim.out 2> /tmp/sim.err
+  python bench.py --steps 3 --warmup 2 --no-cpu-baseline $SIMFLAGS --simulate-shard $sh > /tmp/sim.out 2> /tmp/sim.err
   grep "^# shard" /tmp/sim.err
   tail -1 /tmp/sim.out | python -c "
 import json,sys
