@@ -1723,6 +1723,30 @@ int dsmgp_work(dsmgp_ctx* c, double* alg_flops_update, int32_t* n_update_launche
     return 0;
 }
 
+// Free every device buffer that scales with the leaf sizes (factors, inverse blocks, K_tn rows, L^-1, task lists),
+// keeping the training data, the leaf table, the sharing schedule and the hyper-parameters: the next fit rebuilds
+// them.  This is the "discard" half of the factor-and-discard streaming mode (hipabi.StreamingContext).
+int dsmgp_release(dsmgp_ctx* c) {
+    if (!c) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_plan(c);
+    free_test(c);
+    return 0;
+}
+
+// Device bytes a leaf table of these sizes needs resident (factor + inverse blocks + gathered inputs + vectors,
+// K_tn rows for n_test routed rows per leaf, and L^-1 when gradients are wanted); no context state involved.
+int64_t dsmgp_estimate_bytes(int32_t L, const int64_t* n, const int64_t* n_test, int32_t D, int32_t with_gradients) {
+    int64_t tot = 0;
+    for (int l = 0; l < L; ++l) {
+        const int64_t np_ = (n[l] + TB - 1) / TB * TB;
+        const int64_t nt_ = n_test ? (n_test[l] + TB - 1) / TB * TB : 0;
+        tot += np_ * np_ * (with_gradients ? 2 : 1) + np_ * TB + np_ * (D + 4) + nt_ * np_ + nt_ * (D + 4);
+    }
+    return tot * (int64_t)sizeof(double);
+}
+
 int dsmgp_memory(dsmgp_ctx* c, int64_t* needed, int64_t* free_bytes) {
     if (!c) return DSMGP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1781,6 +1805,42 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* c, int32_t blocks_per_cu, double* out
     out[1] = cyc[nwaves / 2];
     out[2] = clk[nwaves / 2];   // cycles per 10 ns tick / 10 = GHz
     out[3] = blocks_per_cu;
+    return 0;
+}
+
+// Diagnostic: f64 MFMA and f64 VALU FMA alone and co-issued (two waves per SIMD).  out[3*mode + {0,1,2}] =
+// {MFMA TFLOP/s, VALU TFLOP/s, wall ms} for mode 0 (MFMA only), 1 (VALU only), 2 (one wave of each per SIMD).
+int dsmgp_probe_coissue(dsmgp_ctx* c, double* out) {
+    if (!c || !out) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int blocks = c->ncu, iters = 2000;
+    double* sink = nullptr;
+    unsigned long long* st = nullptr;
+    HIPCHK(c, hipMalloc(&sink, (size_t)blocks * 512 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&st, (size_t)blocks * 8 * 2 * sizeof(unsigned long long)));
+    for (int mode = 0; mode < 3; ++mode) {
+        hipEvent_t t0, t1;
+        HIPCHK(c, hipEventCreate(&t0));
+        HIPCHK(c, hipEventCreate(&t1));
+        coissue_probe_kernel<<<blocks, 512, 0, c->stream>>>(sink, st, iters, mode);
+        HIPCHK(c, hipEventRecord(t0, c->stream));
+        coissue_probe_kernel<<<blocks, 512, 0, c->stream>>>(sink, st, iters, mode);
+        HIPCHK(c, hipEventRecord(t1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+        const double waves_mfma = (mode == 0) ? 8.0 : (mode == 2 ? 4.0 : 0.0);
+        const double waves_valu = (mode == 1) ? 8.0 : (mode == 2 ? 4.0 : 0.0);
+        const double fl_m = (double)blocks * waves_mfma * iters * 16.0 * 2048.0;
+        const double fl_v = (double)blocks * waves_valu * iters * 8.0 * 32.0 * 128.0;   // 64 lanes x 2 flops per v_fma_f64
+        out[3 * mode] = fl_m / (ms * 1e-3) / 1e12;
+        out[3 * mode + 1] = fl_v / (ms * 1e-3) / 1e12;
+        out[3 * mode + 2] = ms;
+    }
+    dev_free(sink);
+    dev_free(st);
     return 0;
 }
 

@@ -1194,4 +1194,48 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned l
     }
 }
 
+// Co-issue probe: do the f64 matrix pipe and the f64 vector pipe run at the same time?  mode 0: every wave
+// issues MFMAs; mode 1: every wave issues v_fma_f64; mode 2: even waves MFMA, odd waves v_fma_f64 (two waves per
+// SIMD: one of each).  out[wave] = {cycles, ticks}; flops are counted by the host.
+__global__ __launch_bounds__(512) void coissue_probe_kernel(double* out, unsigned long long* stamps, int iters, int mode) {
+    const int w = threadIdx.x >> 6;
+    const bool do_mfma = (mode == 0) || (mode == 2 && (w & 4) == 0);   // waves 0..3 and 4..7 share the SIMDs pairwise
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    double sink = 0.0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    if (do_mfma) {
+        d4 a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sink += a[i][i & 3];
+    } else {
+        double f[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) f[i] = 1e-3 * i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[i]) : "v"(x), "v"(y));
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) sink += f[i];
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sink;
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = blockIdx.x * (blockDim.x >> 6) + w;
+        stamps[2 * wv] = c1 - c0;
+        stamps[2 * wv + 1] = r1 - r0;
+    }
+}
+
 }  // namespace dsmgp

@@ -40,9 +40,12 @@ SIGNATURES = {
     "dsmgp_set_joint": (C.c_int, [_ctx, C.c_int32]),
     "dsmgp_timings": (C.c_int, [_ctx, _dp]),
     "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
+    "dsmgp_release": (C.c_int, [_ctx]),
+    "dsmgp_estimate_bytes": (C.c_int64, [C.c_int32, _lp, _lp, C.c_int32, C.c_int32]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
     "dsmgp_probe_f64_mfma_detail": (C.c_int, [_ctx, C.c_int32, _dp]),
+    "dsmgp_probe_coissue": (C.c_int, [_ctx, _dp]),
     "dsmgp_bench_tile": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
 }
 
@@ -209,6 +212,10 @@ class Context:
     def set_joint(self, on):
         self._chk(self.lib.dsmgp_set_joint(self.h, 1 if on else 0))
 
+    def release(self):
+        """Free the factors and everything else that scales with the leaf sizes (streaming mode)."""
+        self._chk(self.lib.dsmgp_release(self.h))
+
     def set_profile(self, on):
         self._chk(self.lib.dsmgp_set_profile(self.h, 1 if on else 0))
 
@@ -234,6 +241,12 @@ class Context:
         out = np.zeros(4)
         self._chk(self.lib.dsmgp_probe_f64_mfma_detail(self.h, int(blocks_per_cu), out.ctypes.data_as(_dp)))
         return dict(zip(("tflops", "cycles_per_mfma", "clock_ghz", "waves_per_simd"), out.tolist()))
+
+    def probe_coissue(self):
+        out = np.zeros(9)
+        self._chk(self.lib.dsmgp_probe_coissue(self.h, out.ctypes.data_as(_dp)))
+        return {m: dict(mfma_tflops=out[3 * i], valu_tflops=out[3 * i + 1], ms=out[3 * i + 2])
+                for i, m in enumerate(("mfma_only", "valu_only", "both"))}
 
     def bench_tile(self, ntiles, K, mode=0, group=16, reps=3):
         """TFLOP/s of the tile GEMM on a uniform batch (diagnostic)."""
@@ -418,3 +431,205 @@ class MultiContext:
 
     def probe_f64_mfma(self):
         return self.subs[0].probe_f64_mfma()
+
+
+def estimate_bytes(n, n_test, D, with_gradients=False):
+    """Device bytes a group of leaves with sizes n (and n_test routed rows each) needs resident."""
+    lib = load_library()
+    n = np.ascontiguousarray(n, dtype=np.int64)
+    nt = None if n_test is None else np.ascontiguousarray(n_test, dtype=np.int64)
+    return int(lib.dsmgp_estimate_bytes(len(n), n.ctypes.data_as(_lp), None if nt is None else nt.ctypes.data_as(_lp),
+                                        int(D), 1 if with_gradients else 0))
+
+
+class StreamingContext:
+    """Factor-and-discard mode for leaf tables that do not fit in HBM (config 5 at depth 2 needs 1.4 TB
+    per kernel).  The leaves are packed into groups that fit a byte budget; one pass over the groups does, per
+    group: upload -> fit (the resident test rows ride along) -> fetch mll / predictive moments [-> gradients] ->
+    release.  Only per-leaf results survive a group (log-marginals, moments, gradient vectors): factors are
+    recomputed by the next pass, which is what `train!` does anyway (every iteration changes the hyper-parameters).
+    Interface of `Context`; results per leaf are those of the resident run."""
+
+    def __init__(self, device=0, budget_bytes=None, headroom=0.85):
+        self.ctx = Context(device)
+        self.budget = budget_bytes
+        self.headroom = headroom
+        self.L = 0
+        self.D = 0
+        self.route_total = 0
+        self._leaves = None
+        self._sharing = (None, None, None)
+        self._hyper = {}
+        self._test = None
+        self.want_gradients = 0        # stride of the gradient rows to collect during the pass (0 = none)
+        self.groups = None
+        self._res = None               # results of the last pass
+        self.passes = 0
+
+    def close(self):
+        self.ctx.close()
+
+    def device_name(self):
+        return self.ctx.device_name()
+
+    def set_train(self, X, y):
+        self.ctx.set_train(X, y)
+        self.D = np.asarray(X).shape[1]
+        self._res = None
+
+    def set_leaves(self, obs_ptr, obs_idx, kernel_id, mean):
+        self._leaves = (np.asarray(obs_ptr, dtype=np.int64), np.asarray(obs_idx, dtype=np.int64),
+                        np.asarray(kernel_id, dtype=np.int32), np.asarray(mean, dtype=np.float64))
+        self.L = len(obs_ptr) - 1
+        self._sharing = (None, None, None)
+        self._test = None
+        self.groups = None
+        self._res = None
+
+    def set_sharing(self, op, src, plen):
+        self._sharing = (None, None, None) if op is None else (np.asarray(op), np.asarray(src), np.asarray(plen))
+        self.groups = None
+        self._res = None
+
+    def set_hyper(self, kernel_id, kind, loghyp):
+        self.ctx.set_hyper(kernel_id, kind, loghyp)
+        self._res = None
+
+    def set_joint(self, on):
+        pass                           # the test rows always ride along here: factors do not outlive their group
+
+    def set_profile(self, on):
+        self.ctx.set_profile(on)
+
+    def set_test(self, Xt, route_ptr, route_idx):
+        self._test = (np.asfortranarray(Xt, dtype=np.float64), np.asarray(route_ptr, dtype=np.int64),
+                      np.asarray(route_idx, dtype=np.int64))
+        self.route_total = int(route_ptr[-1])
+        self.groups = None
+        self._res = None
+
+    def _make_groups(self):
+        ptr = self._leaves[0]
+        n = np.diff(ptr)
+        nt = np.diff(self._test[1]) if self._test is not None else np.zeros(self.L, dtype=np.int64)
+        op, src, _ = self._sharing
+        unit = np.arange(self.L)
+        if op is not None:
+            for j in range(self.L):
+                if op[j] != 0 and src[j] >= 0:
+                    unit[j] = src[j]           # leaves sharing a factor travel together
+        budget = self.budget
+        if budget is None:
+            budget = int(self.ctx.memory()[1] * self.headroom)
+        units = {}
+        for j in range(self.L):
+            units.setdefault(int(unit[j]), []).append(j)
+        sized = []
+        for u, members in units.items():
+            m = np.array(members)
+            # COPY leaves alias the factor of their source: count the factor once per unit
+            own = m if op is None else m[op[m] != 1]
+            b = estimate_bytes(n[own], nt[own], self.D, bool(self.want_gradients))
+            if op is not None and np.any(op[m] == 1):
+                cp = m[op[m] == 1]
+                b += int(np.sum((nt[cp] + 128) * (n[cp] + 128) * 8))
+            sized.append((b, members))
+        sized.sort(key=lambda t: -t[0])
+        if sized and sized[0][0] > budget:
+            raise DsmgpError(-4, f"one leaf group needs {sized[0][0] >> 20} MiB, budget is {budget >> 20} MiB")
+        groups, loads = [], []
+        for b, members in sized:                   # first-fit decreasing
+            for gi in range(len(groups)):
+                if loads[gi] + b <= budget:
+                    groups[gi].extend(members)
+                    loads[gi] += b
+                    break
+            else:
+                groups.append(list(members))
+                loads.append(b)
+        self.groups = [np.array(sorted(g)) for g in groups]
+
+    def _pass(self):
+        """One sweep over the groups; fills self._res."""
+        if self.groups is None:
+            self._make_groups()
+        ptr, idx, kid, mean = self._leaves
+        op, src, plen = self._sharing
+        mll = np.empty(self.L)
+        info = np.zeros(self.L, dtype=np.int32)
+        mu = np.empty(self.route_total)
+        var = np.empty(self.route_total)
+        grads = np.zeros((self.L, self.want_gradients)) if self.want_gradients else None
+        seconds, tpred = 0.0, 0.0
+        tsum = {}
+        flops, launches = 0.0, 0
+        for loc in self.groups:
+            c = self.ctx
+            lptr = np.concatenate([[0], np.cumsum(ptr[loc + 1] - ptr[loc])])
+            c.set_leaves(lptr, np.concatenate([idx[ptr[g]:ptr[g + 1]] for g in loc]), kid[loc], mean[loc])
+            if op is None:
+                c.set_sharing(None, None, None)
+            else:
+                g2l = {int(g): i for i, g in enumerate(loc)}
+                c.set_sharing(op[loc], np.array([g2l.get(int(src[g]), -1) for g in loc], dtype=np.int32), plen[loc])
+            if self._test is not None:
+                Xt, rptr, ridx = self._test
+                tptr = np.concatenate([[0], np.cumsum(rptr[loc + 1] - rptr[loc])])
+                c.set_test(Xt, tptr, np.concatenate([ridx[rptr[g]:rptr[g + 1]] for g in loc]))
+            m, i, s = c.fit()
+            mll[loc], info[loc] = m, i
+            seconds += s
+            if self._test is not None:
+                tpred += c.predict_run()
+                gm, gv = c.predict_fetch()
+                pos = 0
+                for g in loc:
+                    k = int(rptr[g + 1] - rptr[g])
+                    mu[rptr[g]:rptr[g + 1]] = gm[pos:pos + k]
+                    var[rptr[g]:rptr[g + 1]] = gv[pos:pos + k]
+                    pos += k
+            if self.want_gradients:
+                grads[loc] = c.gradients(self.want_gradients)
+            for k_, v_ in c.timings().items():
+                tsum[k_] = tsum.get(k_, 0.0) + v_
+            f_, n_ = c.work()
+            flops += f_
+            launches += n_
+            c.release()
+        self.passes += 1
+        self._res = dict(mll=mll, info=info, mu=mu, var=var, grads=grads, seconds=seconds, tpred=tpred, timings=tsum,
+                         work=(flops, launches), has_test=self._test is not None)
+
+    def fit(self):
+        self._pass()
+        r = self._res
+        return r["mll"], r["info"], r["seconds"]
+
+    def predict_run(self):
+        if self._res is None or not self._res["has_test"]:
+            self._pass()
+        return self._res["tpred"]
+
+    def predict_fetch(self):
+        return self._res["mu"], self._res["var"]
+
+    def predict_leaves(self, Xt, route_ptr, route_idx):
+        self.set_test(Xt, route_ptr, route_idx)
+        self.predict_run()
+        return self.predict_fetch()
+
+    def gradients(self, stride):
+        if self._res is None or self._res["grads"] is None or self._res["grads"].shape[1] < stride:
+            self.want_gradients = int(stride)
+            self.groups = None              # L^-1 doubles the footprint of a group
+            self._pass()
+        return self._res["grads"][:, :stride].copy()
+
+    def timings(self):
+        return dict(self._res["timings"]) if self._res else {k: 0.0 for k in TIMING_NAMES}
+
+    def work(self):
+        return self._res["work"] if self._res else (0.0, 0)
+
+    def memory(self):
+        return self.ctx.memory()

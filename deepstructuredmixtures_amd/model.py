@@ -36,7 +36,7 @@ class Model:
     """Common state of DSMGP / PoE / gPoE / rBCM (`src/DeepStructuredMixtures.jl:108-130`)."""
     family = "dsmgp"
 
-    def __init__(self, root, x, y, overlap, ctx=None, device=0, shard=None, n_sub=1):
+    def __init__(self, root, x, y, overlap, ctx=None, device=0, shard=None, n_sub=1, stream_budget=None):
         self.root = root
         self.x = np.asfortranarray(x, dtype=np.float64)
         self.y = np.ascontiguousarray(y, dtype=np.float64)
@@ -47,6 +47,7 @@ class Model:
         self._ctx = ctx
         self._device = device
         self._n_sub = int(n_sub)      # > 1: that many concurrent contexts on this GPU (hipabi.MultiContext)
+        self._stream_budget = stream_budget   # bytes (or "auto"): factor-and-discard over leaf groups (hipabi.StreamingContext)
         self.leaf_mll = np.full(self.L, np.nan)
         self.leaf_info = np.zeros(self.L, dtype=np.int32)
         self.last_fit_seconds = 0.0
@@ -59,7 +60,13 @@ class Model:
     def ctx(self):
         """GPU context, created on first use; raises if the HIP library or a GPU is missing."""
         if self._ctx is None:
-            self._ctx = hipabi.Context(self._device) if self._n_sub <= 1 else hipabi.MultiContext(self._device, self._n_sub)
+            if self._stream_budget is not None:
+                b = None if self._stream_budget == "auto" else int(self._stream_budget)
+                self._ctx = hipabi.StreamingContext(self._device, b)
+            elif self._n_sub > 1:
+                self._ctx = hipabi.MultiContext(self._device, self._n_sub)
+            else:
+                self._ctx = hipabi.Context(self._device)
         return self._ctx
 
     # ---- kernel ids -> shared hyper-parameters --------------------------------------------------
@@ -127,7 +134,7 @@ class rBCM(Model):
 # ------------------------------------------------------------------------------------ builders
 
 def build(x, y, K, V, eps, M, D, kernel, meanFun, logNoise, useSum, *, seed=7, device=0, ctx=None,
-          cls=DSMGP, tau=0.05, fit_now=True, shard_world=None, n_sub=1):
+          cls=DSMGP, tau=0.05, fit_now=True, shard_world=None, n_sub=1, stream_budget=None):
     """`src/treeStructure.jl:405-437`. NOTE the reference swaps its positional K/V into the config:
     config.K (splits per split node) = V argument, config.V (children per sum node) = K argument."""
     x = np.asarray(x, dtype=np.float64)
@@ -137,7 +144,7 @@ def build(x, y, K, V, eps, M, D, kernel, meanFun, logNoise, useSum, *, seed=7, d
     root = build_tree(x, np.asarray(y, dtype=np.float64), config, seed=seed)
     L = len(get_leaves(root))
     overlap = get_overlap(root, L)
-    model = cls(root, x, y, overlap, ctx=ctx, device=device, n_sub=n_sub)
+    model = cls(root, x, y, overlap, ctx=ctx, device=device, n_sub=n_sub, stream_budget=stream_budget)
     if shard_world is not None:
         rank, world = shard_world
         op, src, _ = share_schedule(model.leaves, overlap, tau)

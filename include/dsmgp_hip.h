@@ -117,6 +117,11 @@ int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the
  * all its launches (2*K per lower-triangle element of every block column, unpadded sizes) and the
  * number of launches */
 int dsmgp_work(dsmgp_ctx* ctx, double* alg_flops_update, int32_t* n_update_launches);
+/* streaming ("factor and discard"): drop every buffer that scales with the leaf sizes, keep data, leaf table,
+ * schedule and hyper-parameters; the next dsmgp_fit rebuilds.  dsmgp_estimate_bytes sizes a leaf group beforehand. */
+int dsmgp_release(dsmgp_ctx* ctx);
+int64_t dsmgp_estimate_bytes(int32_t L, const int64_t* n, const int64_t* n_test /* may be NULL */, int32_t D,
+                             int32_t with_gradients);
 /* bytes of device memory the current leaf table needs / the device has free */
 int dsmgp_memory(dsmgp_ctx* ctx, int64_t* needed, int64_t* free_bytes);
 
@@ -127,6 +132,8 @@ int dsmgp_probe_f64_mfma(dsmgp_ctx* ctx, double* tflops);
  * out[3] = blocks_per_cu (256-thread workgroups per CU, i.e. waves per SIMD) */
 int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* ctx, int32_t blocks_per_cu, double* out);
 
+/* diagnostic: f64 MFMA vs f64 VALU FMA rates alone and co-issued: out[9] = {mfma TF/s, valu TF/s, ms} x {MFMA only, VALU only, both} */
+int dsmgp_probe_coissue(dsmgp_ctx* ctx, double* out);
 /* diagnostic: seconds per launch of the tile GEMM on a uniform batch of ntiles tiles of depth K
  * (mode 0: own A panel per tile, B panel shared by `group` tiles; mode 1: all operands shared, L2-resident) */
 int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,

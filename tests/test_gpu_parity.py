@@ -531,3 +531,35 @@ def test_concurrent_sub_contexts_give_the_single_context_result():
     dsm.updategradients(m1)
     dsm.updategradients(m2)
     assert np.allclose(dsm.grad_mll(m1), dsm.grad_mll(m2), rtol=1e-9, atol=1e-10)
+
+
+def test_streaming_factor_and_discard_equals_resident():
+    """hipabi.StreamingContext: leaf groups under a byte budget, factors discarded after each group.  Same
+    log-marginals, predictions and gradients as the resident model (the mode config 5 needs)."""
+    X, y, Xt = regression_data(6000, 3, n_test=400, seed=556)
+    kw = dict(M=80, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=5)
+    m1 = dsm.buildDSMGP(X, y, 3, 4, **kw)
+    n = np.array([lf.nobs for lf in m1.leaves])
+    budget = int(0.3 * hipabi.estimate_bytes(n, np.full(n.size, 400 * 9 // n.size + 1), 3, True))
+    m2 = dsm.buildDSMGP(X, y, 3, 4, stream_budget=budget, **kw)
+    assert isinstance(m2.ctx, hipabi.StreamingContext) and len(m2.ctx.groups) >= 2
+    assert np.allclose(m1.leaf_mll, m2.leaf_mll, rtol=1e-12)
+    dsm.update(m1)
+    dsm.update(m2)
+    a, b = dsm.predict(m1, Xt), dsm.predict(m2, Xt)
+    assert np.allclose(a[0], b[0], rtol=1e-10, atol=1e-12) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-13)
+    p0 = m2.ctx.passes
+    b2 = dsm.predict(m2, Xt)                                  # cached: no new pass over the groups
+    assert m2.ctx.passes == p0 and np.array_equal(b[0], b2[0])
+    dsm.updategradients(m1)
+    dsm.updategradients(m2)
+    assert np.allclose(dsm.grad_mll(m1), dsm.grad_mll(m2), rtol=1e-9, atol=1e-10)
+    assert len(m2.ctx.groups) >= 3                            # L^-1 and the test rows count against the budget
+    _, h1 = dsm.train(m1, dsm.ADAM(eta=0.01), iterations=2, randinit=False)
+    _, h2 = dsm.train(m2, dsm.ADAM(eta=0.01), iterations=2, randinit=False)
+    assert np.allclose(h1, h2, rtol=1e-10)
+    # a copy-sharing model (config 1) streams too: leaves that alias a factor stay in one group
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "config1.npz"))
+    mc = dsm.buildDSMGP(z["x"].reshape(-1, 1), z["y"], 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5),
+                        seed=11, stream_budget=6 << 20)
+    assert len(mc.ctx.groups) >= 2 and np.allclose(mc.leaf_mll, z["leaf_mll"], rtol=RTOL, atol=1e-9)

@@ -243,7 +243,7 @@ def test_two_rank_gloo_sharding_reproduces_the_single_process_result(tmp_path):
 def test_c_abi_library_exports_every_declared_symbol():
     """Loads libdsmgp_hip.so (no compute) and checks it exports exactly what include/dsmgp_hip.h declares."""
     hdr = open(os.path.join(ROOT, "include", "dsmgp_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(dsmgp_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|const char\*|int64_t)\s+(dsmgp_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(hipabi.SIGNATURES), declared ^ set(hipabi.SIGNATURES)
     if not os.path.exists(hipabi.LIB_PATH):
         import __graft_entry__
