@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
     ap.add_argument("--sub", type=int, default=None,
-                    help="concurrent contexts per GPU (default: 1 on one GPU, 2 per rank when sharded)")
+                    help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
                     help="diagnostic: run only rank R's leaf shard of a W-rank job on this one GPU (no exchange; "
                          "not a valid bench line)")
@@ -127,7 +127,7 @@ def main():
     if args.simulate_shard:
         from deepstructuredmixtures_amd import dist as pdist
         r_, w_ = map(int, args.simulate_shard.split("/"))
-        n_sub = args.sub if args.sub is not None else 2
+        n_sub = args.sub if args.sub is not None else 1
         model, X, y, Xt, ptr, idx = build_model(args.config, r_, w_, local_rank, n_sub)
         own = model.shard.owner
         loc = np.flatnonzero(own == r_)
@@ -150,7 +150,7 @@ def main():
         n3 = np.array([lf.nobs for lf in model.leaves], dtype=float) ** 3
         print(f"# shard {r_}/{w_}: {loc.size} leaves, {n3[loc].sum() / n3.sum():.3f} of the Cholesky flops", file=sys.stderr)
     else:
-        n_sub = args.sub if args.sub is not None else (1 if world == 1 else 2)
+        n_sub = args.sub if args.sub is not None else 1
         model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
     ctx = model.ctx
     ctx.set_profile(not args.no_profile)

@@ -215,8 +215,30 @@ def build_tree(X, y, config, seed=7):
 # ----------------------------------------------------------------------------- overlap + schedule
 
 def get_overlap(root, L):
-    """Leaf-overlap matrix (`src/fit.jl:12-39`): D[n,m] = 1 - |n \\ m| / |n| for leaves under
-    different children of a common sum node, forced to 1 when kernel ids differ."""
+    """Leaf-overlap matrix (`src/fit.jl:12-39`): D[n,m] = 1 - |n \\ m| / |n| for leaves under different
+    children of a common sum node, forced to 1 when kernel ids differ.
+
+    Two leaves that share an observation always hang under different children of some sum node (split nodes
+    partition), and leaves that share none get 1 - |n|/|n| = 0, the default.  With a single kernel id the whole
+    matrix therefore follows from the intersection counts C = M M^T of the sparse leaf-membership matrix M
+    (L x N) -- one sparse product instead of the reference's O(L^2) bitset loops.  Kernel vectors (ids differ,
+    forced ones also for disjoint pairs) take the literal pairwise recursion."""
+    leaves = get_leaves(root)
+    if len({lf.kernelid for lf in leaves}) > 1 or L > 8192:
+        return _get_overlap_pairwise(root, L)
+    import scipy.sparse as sp
+    nobs = np.array([lf.nobs for lf in leaves], dtype=np.int64)
+    rows = np.repeat(np.arange(L), nobs)
+    cols = np.concatenate([lf.obs for lf in leaves]) if L else np.zeros(0, np.int64)
+    N = int(cols.max()) + 1 if cols.size else 1
+    M = sp.csr_matrix((np.ones(rows.size, dtype=np.int32), (rows, cols)), shape=(L, N))
+    C = np.asarray((M @ M.T).todense(), dtype=np.float64)
+    Dm = np.where(C > 0, 1.0 - (nobs[:, None] - C) / nobs[:, None], 0.0)   # same expression as src/fit.jl:30
+    np.fill_diagonal(Dm, 0.0)
+    return Dm
+
+
+def _get_overlap_pairwise(root, L):
     Dm = np.zeros((L, L))
 
     def rec(node):

@@ -85,7 +85,11 @@ def test_overlap_schedule_and_routing_match_the_oracle(golden_dir):
     # the committed leaf table pins the builder (RNG stream + cut rules)
     assert np.array_equal(np.concatenate([lf.obs for lf in m.leaves]), z["obs_idx"])
     D_or = ospn.get_overlap(m.root, m.L)
-    assert np.array_equal(m.D, D_or)
+    assert np.array_equal(m.D, D_or)                                  # sparse-product path == bitset loops, bit for bit
+    assert np.array_equal(ptree._get_overlap_pairwise(m.root, m.L), D_or)
+    Xr, yr = _small_problem(1500, 3, seed=91)
+    mr = dsm.buildDSMGP(Xr, yr, 3, 4, M=25, kernel=dsm.IsoSE(0.0, 0.0), fit_now=False, seed=2)
+    assert np.array_equal(mr.D, ospn.get_overlap(mr.root, mr.L))
     op, src, plen = ptree.share_schedule(m.leaves, m.D, 0.05)
     full, copy, prefix, lowrank = z["census"]
     assert np.count_nonzero(op == ptree.SHARE_COPY) == copy
