@@ -180,7 +180,7 @@ struct dsmgp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    bool profile = false;
+    int profile = 0;                // 0: totals only, 1: events around the update launches (dominant kernel), 2: every category
 
     int64_t N = 0;
     int D = 0;
@@ -813,8 +813,10 @@ struct PhaseTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;
     explicit PhaseTimer(dsmgp_ctx* c_) : c(c_) {}
+    bool on = false;
     void begin(int slot) {
-        if (!c->profile) return;
+        on = c->profile >= 2 || (c->profile == 1 && slot == 1);
+        if (!on) return;
         hipEvent_t a, b;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
@@ -822,7 +824,7 @@ struct PhaseTimer {
         spans.push_back({slot, {a, b}});
     }
     void end() {
-        if (!c->profile) return;
+        if (!on) return;
         (void)hipEventRecord(spans.back().second.second, c->stream);
     }
     void collect() {
@@ -896,7 +898,7 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     if (const char* s = std::getenv("DSMGP_TAIL_SPLIT")) c->tail_split = std::max(1, std::atoi(s));
     if (const char* s = std::getenv("DSMGP_TAIL_ROUNDS")) c->tail_rounds = std::max(0, std::atoi(s));
     const char* p = std::getenv("DSMGP_PROFILE");
-    c->profile = p && p[0] == '1';
+    c->profile = p ? std::atoi(p) * 2 : 0;   // DSMGP_PROFILE=1 -> every category
     *out = c;
     return 0;
 }
@@ -935,7 +937,7 @@ int dsmgp_set_joint(dsmgp_ctx* c, int32_t on) {
 
 int dsmgp_set_profile(dsmgp_ctx* c, int32_t on) {
     if (!c) return DSMGP_E_ARG;
-    c->profile = on != 0;
+    c->profile = on < 0 ? 0 : (on > 2 ? 2 : on);
     return 0;
 }
 

@@ -216,8 +216,10 @@ class Context:
         """Free the factors and everything else that scales with the leaf sizes (streaming mode)."""
         self._chk(self.lib.dsmgp_release(self.h))
 
-    def set_profile(self, on):
-        self._chk(self.lib.dsmgp_set_profile(self.h, 1 if on else 0))
+    def set_profile(self, level):
+        """0/False: totals only; 1: update launches only; 2/True: every kernel category."""
+        lv = 2 if level is True else int(level)
+        self._chk(self.lib.dsmgp_set_profile(self.h, lv))
 
     def timings(self):
         t = np.zeros(N_TIMINGS)

@@ -109,9 +109,10 @@ int dsmgp_kernel_matrix(dsmgp_ctx* ctx, int32_t kernel_id, const double* x1, int
                         const double* x2, int64_t n2, double* K_out /* n1 x n2 */);
 /* gp.cK.factors (lower triangle = L, strict upper = 0) and gp.alpha of one leaf; either may be NULL */
 int dsmgp_download_factor(dsmgp_ctx* ctx, int32_t leaf, double* F /* n x n */, double* alpha /* n */);
-/* per-launch hipEvent timing of every kernel category (adds event records between launches);
- * also switched on by the environment variable DSMGP_PROFILE=1 at dsmgp_create */
-int dsmgp_set_profile(dsmgp_ctx* ctx, int32_t on);
+/* hipEvent timing per launch: level 0 = totals only, 1 = the update launches of the factorisation (the dominant
+ * kernel; what bench.py's roofline uses), 2 = every kernel category (adds event records between all launches;
+ * also switched on by the environment variable DSMGP_PROFILE=1 at dsmgp_create) */
+int dsmgp_set_profile(dsmgp_ctx* ctx, int32_t level);
 int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the last fit/predict */);
 /* work of the dominant kernel (the f64-MFMA Cholesky update) in the last fit: algorithmic flops over
  * all its launches (2*K per lower-triangle element of every block column, unpadded sizes) and the
