@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
 #include <vector>
 
 using namespace dsmgp;
@@ -47,6 +48,7 @@ struct DevBuf {
 struct StepLists {
     // one phase (wave) of factorisation: per block step k the tasks for update / split-K reduce / diag / trsm
     std::vector<int> upd_off, red_off, diag_off, trsm_off;   // size nsteps+1
+    std::vector<int> step_tiles;                             // whole update tiles per step (before split-K)
     DevBuf<TileTask> upd, trsm;
     DevBuf<ReduceTask> red;
     DevBuf<DiagTask> diag;
@@ -482,6 +484,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.red_off.assign(nsteps + 1, 0);
         S.trsm_off.assign(nsteps + 1, 0);
         S.diag_off.assign(nsteps + 1, 0);
+        S.step_tiles.assign(nsteps, 0);
         for (int k = 0; k < nsteps; ++k) {
             S.upd_off[k] = (int)U.upd.size();
             S.red_off[k] = (int)U.red.size();
@@ -578,6 +581,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 }
             }
             U.add_step(tiles, k * TB);
+            S.step_tiles[k] = (int)tiles.size();
         }
         S.upd_off[nsteps] = (int)U.upd.size();
         S.red_off[nsteps] = (int)U.red.size();
@@ -812,6 +816,7 @@ struct PhaseTimer {
     dsmgp_ctx* c;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;
+    std::vector<std::array<int, 3>> notes;   // per span: (step, tasks, reduce tasks), for DSMGP_STEPLOG
     explicit PhaseTimer(dsmgp_ctx* c_) : c(c_) {}
     bool on = false;
     void begin(int slot) {
@@ -822,20 +827,30 @@ struct PhaseTimer {
         (void)hipEventCreate(&b);
         (void)hipEventRecord(a, c->stream);
         spans.push_back({slot, {a, b}});
+        notes.push_back({-1, 0, 0});
+    }
+    void note(int step, int ntasks, int nred) {
+        if (on) notes.back() = {step, ntasks, nred};
     }
     void end() {
         if (!on) return;
         (void)hipEventRecord(spans.back().second.second, c->stream);
     }
     void collect() {
-        for (auto& s : spans) {
+        const bool log = std::getenv("DSMGP_STEPLOG") != nullptr;
+        for (size_t i = 0; i < spans.size(); ++i) {
+            auto& s = spans[i];
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, s.second.first, s.second.second);
             c->timings[s.first] += ms * 1e-3;
+            if (log && notes[i][0] >= 0)
+                std::fprintf(stderr, "steplog slot %d step %d tasks %d tiles %d ms %.4f\n", s.first, notes[i][0],
+                             notes[i][1], notes[i][2], ms);
             (void)hipEventDestroy(s.second.first);
             (void)hipEventDestroy(s.second.second);
         }
         spans.clear();
+        notes.clear();
     }
 };
 
@@ -848,19 +863,22 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
             launch_tiles(c, S.upd.p + S.upd_off[k], nu);
             const int nr = S.red_off[k + 1] - S.red_off[k];
             if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
+            pt.note(k, nu, S.step_tiles[k]);
             pt.end();
             if (count_launches) c->n_update_launches++;
         }
         const int nd = S.diag_off[k + 1] - S.diag_off[k];
         if (nd > 0) {
             pt.begin(2);
-            chol_diag_kernel<<<nd, 256, (TB * DLD + 256) * sizeof(double), c->stream>>>(S.diag.p + S.diag_off[k]);
+            chol_diag_kernel<<<nd, 256, DIAG_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
+            pt.note(k, nd, 0);
             pt.end();
         }
         const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
         if (ns > 0) {
             pt.begin(3);
             launch_tiles(c, S.trsm.p + S.trsm_off[k], ns);
+            pt.note(k, ns, 0);
             pt.end();
         }
     }
@@ -887,7 +905,7 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (TB * DLD + 256) * (int)sizeof(double));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1843,6 +1861,90 @@ int dsmgp_probe_coissue(dsmgp_ctx* c, double* out) {
     }
     dev_free(sink);
     dev_free(st);
+    return 0;
+}
+
+// Diagnostic: the diagonal-block kernel on its own, with in-kernel phase stamps.
+int dsmgp_probe_diag(dsmgp_ctx* c, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us) {
+    if (!c || ntiles <= 0 || ld < TB || reps <= 0 || !kernel_us || !phases_us) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t tile = (size_t)ld * TB;
+    std::vector<double> h(tile, 0.0);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        return (double)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    };
+    for (int cidx = 0; cidx < TB; ++cidx)
+        for (int r = cidx; r < TB; ++r) h[r + (size_t)cidx * ld] = (r == cidx) ? 64.0 + rnd() : rnd();
+    double *T0 = nullptr, *T = nullptr, *Dinv = nullptr, *wz = nullptr;
+    int* info = nullptr;
+    unsigned long long* stamps = nullptr;
+    DiagTask* dt = nullptr;
+    HIPCHK(c, hipMalloc(&T0, tile * sizeof(double)));
+    HIPCHK(c, hipMalloc(&T, ntiles * tile * sizeof(double)));
+    HIPCHK(c, hipMalloc(&Dinv, (size_t)ntiles * TB * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&wz, (size_t)ntiles * 2 * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&info, ntiles * sizeof(int)));
+    HIPCHK(c, hipMalloc(&stamps, (size_t)ntiles * 24 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&dt, ntiles * sizeof(DiagTask)));
+    HIPCHK(c, hipMemcpy(T0, h.data(), tile * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(wz, 0, (size_t)ntiles * 2 * TB * sizeof(double)));
+    HIPCHK(c, hipMemset(info, 0, ntiles * sizeof(int)));
+    std::vector<DiagTask> tasks(ntiles);
+    for (int i = 0; i < ntiles; ++i) {
+        DiagTask g{};
+        g.T = T + i * tile;
+        g.Dinv = Dinv + (size_t)i * TB * TB;
+        g.wk = wz + (size_t)i * 2 * TB;
+        g.zk = wz + (size_t)i * 2 * TB + TB;
+        g.info = info + i;
+        g.ld = ld;
+        g.nvalid = TB;
+        g.row0 = 0;
+        tasks[i] = g;
+    }
+    HIPCHK(c, hipMemcpy(dt, tasks.data(), ntiles * sizeof(DiagTask), hipMemcpyHostToDevice));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_stamp_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
+    const size_t lds = DIAG_LDS_BYTES;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    auto refill = [&]() {
+        for (int i = 0; i < ntiles; ++i)
+            (void)hipMemcpyAsync(T + i * tile, T0, tile * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    };
+    double total = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {
+        refill();
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        chol_diag_kernel<<<ntiles, 256, lds, c->stream>>>(dt);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+    }
+    *kernel_us = total / reps * 1e3;
+    refill();
+    chol_diag_stamp_kernel<<<ntiles, 256, lds, c->stream>>>(dt, stamps);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long hs[24];
+    HIPCHK(c, hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 19; ++i) phases_us[i] = (double)(hs[i + 1] - hs[i]) * 0.01;   // 100 MHz
+    // inside wave 0's share of J3.P2: block product, LDS reads, potrf_inv16, LDS writes
+    phases_us[19] = (double)(hs[20] - hs[8]) * 0.01;
+    phases_us[20] = (double)(hs[21] - hs[20]) * 0.01;
+    phases_us[21] = (double)(hs[22] - hs[21]) * 0.01;
+    phases_us[22] = (double)(hs[23] - hs[22]) * 0.01;
+    int bad = 0;
+    HIPCHK(c, hipMemcpy(&bad, info, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(T0); (void)hipFree(T); (void)hipFree(Dinv); (void)hipFree(wz);
+    (void)hipFree(info); (void)hipFree(stamps); (void)hipFree(dt);
+    if (bad != 0) return fail(c, DSMGP_E_STATE, "probe block was not positive definite");
     return 0;
 }
 

@@ -696,6 +696,7 @@ struct DiagTask {
 //   P2  all waves: trailing S(I,K) -= S(I,J) S(K,J)^T (I >= K > J), B(I,K) -= S(I,J) B(J,K)     [MFMA]
 // B accumulates L^-1 by forward substitution on the identity, interleaved with the factorisation.
 constexpr int DLD = 144;
+constexpr int DIAG_LDS_BYTES = (TB * DLD + 256 + TB) * (int)sizeof(double);   // image + Winv + rhs block
 
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
@@ -715,173 +716,269 @@ __device__ __forceinline__ d4 blk_mma(const double* pa, int saa, int sak, const 
     return acc;
 }
 
-// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (no division, no sqrt call)
+// 1/sqrt(d) and 1/d to full double precision from the hardware seeds (relative error ~2^-23) with one
+// third-order step each (error ~ e^3): 4 resp. 3 dependent operations after the seed, no division, no sqrt call
 __device__ __forceinline__ double rsqrt_nr(double d) {
-    double y = __builtin_amdgcn_rsq(d);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const double e = fma(-d * y, y, 1.0);
-        y = fma(y * 0.5, e, y);
-    }
-    return y;
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);              // 1 - d y^2
+    return fma(y * e, fma(e, 0.375, 0.5), y);          // y (1 + e/2 + 3e^2/8)
+}
+__device__ __forceinline__ double rcp_nr(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);                  // 1 - d r
+    return fma(r * e, 1.0 + e, r);                     // r (1 + e + e^2)
 }
 
-// potrf + inverse of one 16x16 diagonal block, in registers of one wave: lane c (c = lane & 15; lanes 16..63
-// mirror) owns column c of the symmetric block (a[]) and column c of the identity being forward-substituted
-// (b[]).  Per pivot j: d = A(j,j) by v_readlane, r = 1/sqrt(d), then every l(r,j) is broadcast once and used
-// for both the rank-1 update of the trailing block and the substitution step, so the inverse costs no extra
-// cross-lane traffic.  Returns the 1-based index of the first non-positive pivot (0 = none).
-__device__ __forceinline__ int potrf_inv16(double (&a)[16], double (&b)[16], int c) {
-    int bad = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) b[r] = (r == c) ? 1.0 : 0.0;
+// potrf + inverse of one 16x16 diagonal block, in registers of one wave.  Lanes 0..15 hold column c = lane & 15 of
+// the symmetric block, lanes 16..31 column c of the identity that is forward-substituted into L^-1 (lanes 32..63
+// mirror), both in x[]: one fma per row and pivot updates the factorisation and the inverse together.
+// Per pivot j: d = A(j,j) by v_readlane; the rank-1 update uses the *unscaled* column j (broadcast by v_readlane)
+// against m = A(j,c)/d resp. X'(j,c)/d, so the chain from one pivot to the next is readlane -> 1/d -> one
+// multiply -> one fma; 1/sqrt(d), which only scales finished values (x_scale for column j, applied once at the
+// end; X(j,c) = X'(j,c)/sqrt(d); the diagonal entry sqrt(d), kept aside in x_diag), runs beside that chain.
+// Lane j and the finished columns see m = 0: the loop body is two readlanes and one fma, no selects.
+// Returns the 1-based index of the first non-positive pivot (0 = none).
+__device__ __forceinline__ int potrf_inv16(double (&x)[16], double& x_scale, double& x_diag, int lane) {
+    const int c = lane & 15;
+    const bool isb = (lane & 16) != 0;
+    unsigned badmask = 0;      // bit j: pivot j was not positive (no dependent chain: the first one is picked at the end)
+    x_scale = 1.0;
+    x_diag = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const double d = readlane_f64(a[j], j);
-        if (!(d > 0.0) && bad == 0) bad = j + 1;
+        const double d = readlane_f64(x[j], j);
+        badmask |= (d > 0.0) ? 0u : (1u << j);
+        const double xsel = (!isb && c <= j) ? 0.0 : x[j];
+        const double m = xsel * rcp_nr(d);
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) x[r] = fma(-readlane_f64(x[r], j), m, x[r]);
         const double inv = rsqrt_nr(d);
         double sd = d * inv;
         sd = fma(fma(-sd, sd, d), 0.5 * inv, sd);
-        const double lc = a[j] * inv;          // L(c,j) for c > j
-        const double xj = b[j] * inv;          // X(j,c)
-        b[j] = xj;
-#pragma unroll
-        for (int r = j + 1; r < 16; ++r) {
-            const double lr = readlane_f64(a[r], j) * inv;   // L(r,j), wave-uniform
-            if (c > j) a[r] = fma(-lr, lc, a[r]);
-            b[r] = fma(-lr, xj, b[r]);
-        }
-        if (c == j) {
-            a[j] = sd;
-#pragma unroll
-            for (int r = j + 1; r < 16; ++r) a[r] *= inv;
+        if (isb) x[j] *= inv;                 // X(j,c), final
+        if (!isb && c == j) {
+            x_scale = inv;
+            x_diag = sd;
         }
     }
-    return bad;
+    return badmask ? __builtin_ctz(badmask) + 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restrict__ tasks) {
-    extern __shared__ __attribute__((aligned(16))) double S[];   // [128 cols][DLD rows] + Winv[256]
+// STAMP: thread 0 records wall_clock64() (100 MHz) after every phase (tools/probe_diag.py)
+template <bool STAMP>
+__device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, unsigned long long* stamps) {
     double* Winv = S + TB * DLD;                                  // Linv of the current step, col-major ld 16
-    const DiagTask tk = tasks[blockIdx.x];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    auto stamp = [&](int i) {
+        if (STAMP && t == 0) stamps[i] = wall_clock64();
+    };
+    stamp(0);
     const int l15 = lane & 15, l4 = lane >> 4;
     auto offS = [](int I, int K) { return (K * 16) * DLD + I * 16; };
     auto offB = [](int I, int K) { return (I == K) ? (I * 16) * DLD + TB : (I * 16) * DLD + K * 16; };
 
-    for (int e = t; e < TB * TB; e += 256) {
-        const int r = e % TB, c = e / TB;
-        S[c * DLD + r] = ((r >> 4) >= (c >> 4)) ? tk.T[r + (size_t)c * tk.ld] : 0.0;
+    {
+        // lower block triangle of the tile -> LDS, upper blocks zero; wave w takes columns 32w..32w+31, lanes
+        // two rows each, eight columns' loads in flight (the tile comes from HBM / a remote L2: latency-bound)
+        const gd2_cptr Tg = AS_GLOBAL_D2(tk.T + 2 * lane);
+#pragma unroll 1
+        for (int c0 = w * 32; c0 < w * 32 + 32; c0 += 8) {
+            d2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = Tg[((size_t)(c0 + j) * tk.ld) >> 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const d2 zero = {0.0, 0.0};
+                *reinterpret_cast<d2*>(S + (c0 + j) * DLD + 2 * lane) = ((lane >> 3) >= ((c0 + j) >> 4)) ? v[j] : zero;
+            }
+        }
     }
     for (int e = t; e < TB * 16; e += 256) S[(e >> 4) * DLD + TB + (e & 15)] = 0.0;
+    double* wl = Winv + 256;                                      // right-hand side block of the fused forward solve
+    if (tk.wk != nullptr && t < TB) wl[t] = tk.wk[t];
     __syncthreads();
+    stamp(1);
 
     int bad = 0;
     // diagonal block J on wave 0: S(J,J) <- L_JJ (upper part zeroed), B(J,J) and Winv <- L_JJ^-1
     auto diag_block = [&](int J) {
         const int c = l15;
-        double a[16], b[16];
-        const double* src = S + offS(J, J) + c * DLD;
+        const bool isb = (lane & 16) != 0;
+        double x[16], xs, xd;
+        const d2* src = reinterpret_cast<const d2*>(S + offS(J, J) + c * DLD);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = src[r];
-        const int bj = potrf_inv16(a, b, c);
+        for (int r = 0; r < 16; r += 2) {
+            const d2 v = src[r >> 1];
+            x[r] = isb ? ((r == c) ? 1.0 : 0.0) : v[0];
+            x[r + 1] = isb ? ((r + 1 == c) ? 1.0 : 0.0) : v[1];
+        }
+        if (J == 4) stamp(21);
+        const int bj = potrf_inv16(x, xs, xd, lane);
+        if (J == 4) stamp(22);
         if (bj != 0 && bad == 0) bad = J * 16 + bj;
-        if (lane < 16) {
-            double* dS = S + offS(J, J) + c * DLD;
-            double* dB = S + offB(J, J) + c * DLD;
+        // lanes 0..15 write column c of L (strict lower part scaled by 1/sqrt(d_c), diagonal from xd, zeros
+        // above), lanes 16..31 column c of L^-1 (to B(J,J) and to Winv): one instruction stream for both groups
+        if (lane < 32) {
+            const int thr = isb ? c : c + 1;
+            const double mul = isb ? 1.0 : xs;
+            d2* dst = reinterpret_cast<d2*>((isb ? S + offB(J, J) : S + offS(J, J)) + c * DLD);
+            d2* dw = reinterpret_cast<d2*>(Winv + c * 16);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dS[r] = (r >= c) ? a[r] : 0.0;
-                const double x = (r >= c) ? b[r] : 0.0;
-                dB[r] = x;
-                Winv[c * 16 + r] = x;
+            for (int r = 0; r < 16; r += 2) {
+                d2 v;
+                v[0] = (r >= thr) ? x[r] * mul : ((r == c) ? xd : 0.0);
+                v[1] = (r + 1 >= thr) ? x[r + 1] * mul : ((r + 1 == c) ? xd : 0.0);
+                dst[r >> 1] = v;
+                if (isb) dw[r >> 1] = v;
             }
         }
     };
-    auto trailing_task = [&](int J, int I, int K) {   // S(I,K) -= S(I,J) S(K,J)^T
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        double* dst = S + offS(I, K);
-        acc = blk_mma(S + offS(K, J), 1, DLD, S + offS(I, J), DLD, acc, lane);
+    // One 16x16 block product on this wave: dst (-)= Aop Bop (operand addressing as in blk_mma)
+    struct BlkOp {
+        const double* pa; int saa, sak;
+        const double* pb; int sbk;
+        double* dst;
+    };
+    auto op_trailing = [&](int J, int I, int K) {   // S(I,K) -= S(I,J) S(K,J)^T
+        return BlkOp{S + offS(K, J), 1, DLD, S + offS(I, J), DLD, S + offS(I, K)};
+    };
+    auto op_inverse = [&](int J, int I, int K) {    // B(I,K) -= S(I,J) B(J,K)
+        return BlkOp{S + offB(J, K), DLD, 1, S + offS(I, J), DLD, S + offB(I, K)};
+    };
+    // two independent block products at once: all 16 operand reads are issued before the first MFMA, and the two
+    // accumulation chains interleave (a single chain leaves the wave waiting on LDS and MFMA latency)
+    auto run_pair = [&](const BlkOp& o0, const BlkOp& o1, bool two, bool subtract) {
+        double a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] -= acc[r];
+        for (int q = 0; q < 4; ++q) {
+            const int kk = 4 * q + l4;
+            a0[q] = o0.pa[l15 * o0.saa + kk * o0.sak];
+            b0[q] = o0.pb[l15 + kk * o0.sbk];
+            a1[q] = o1.pa[l15 * o1.saa + kk * o1.sak];
+            b1[q] = o1.pb[l15 + kk * o1.sbk];
+        }
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        double c0[4], c1[4];
+        if (subtract) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                c0[r] = o0.dst[(l4 + 4 * r) * DLD + l15];
+                c1[r] = o1.dst[(l4 + 4 * r) * DLD + l15];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o0.dst[(l4 + 4 * r) * DLD + l15] = subtract ? c0[r] - acc0[r] : acc0[r];
+        if (two) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o1.dst[(l4 + 4 * r) * DLD + l15] = subtract ? c1[r] - acc1[r] : acc1[r];
+        }
     };
 
     if (w == 0) diag_block(0);
     __syncthreads();
     for (int J = 0; J < 8; ++J) {
-        // ---- P1: panel solve S(I,J) <- S(I,J) Linv^T (I > J) and the inverse's row J: B(J,K) <- Linv B(J,K) (K < J)
-        for (int task = w; task < 7; task += 4) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            double* dst;
-            if (task < 7 - J) {
-                const int I = J + 1 + task;
-                dst = S + offS(I, J);
-                acc = blk_mma(Winv, 1, 16, dst, DLD, acc, lane);
-            } else {
-                const int K = task - (7 - J);
-                dst = S + offB(J, K);
-                acc = blk_mma(dst, DLD, 1, Winv, 16, acc, lane);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] = acc[r];
+        // ---- P1: panel solve S(I,J) <- S(I,J) Linv^T (I > J) and the inverse's row J: B(J,K) <- Linv B(J,K) (K < J);
+        //      7 block products, wave w takes w and w + 4 as a pair
+        {
+            auto op_p1 = [&](int task) {
+                if (task < 7 - J) {
+                    double* dst = S + offS(J + 1 + task, J);
+                    return BlkOp{Winv, 1, 16, dst, DLD, dst};
+                }
+                double* dst = S + offB(J, task - (7 - J));
+                return BlkOp{dst, DLD, 1, Winv, 16, dst};
+            };
+            const bool two = w + 4 < 7;
+            const BlkOp o0 = op_p1(w);
+            run_pair(o0, two ? op_p1(w + 4) : o0, two, false);
         }
         __syncthreads();
+        stamp(2 + 2 * J);
         // ---- P2 with lookahead: wave 0 updates the next diagonal block and factorises it at once
         //      (nothing else in P2 touches S(J+1,J+1), B(J+1,J+1) or Winv), waves 1..3 do the rest of the
-        //      trailing update S(I,K) -= S(I,J) S(K,J)^T and of B(I,K) -= S(I,J) B(J,K).
+        //      trailing update S(I,K) -= S(I,J) S(K,J)^T and of B(I,K) -= S(I,J) B(J,K), two products at a time.
         const int m = 7 - J;
         if (w == 0) {
             if (m > 0) {
-                trailing_task(J, J + 1, J + 1);
+                const BlkOp o = op_trailing(J, J + 1, J + 1);
+                run_pair(o, o, false, true);
+                if (J == 3) stamp(20);
                 diag_block(J + 1);
+                if (J == 3) stamp(23);
             }
         } else {
             const int ntrail = m * (m + 1) / 2;
             const int ninv = m * (J + 1);
-            for (int task = 1 + (w - 1); task < ntrail + ninv; task += 3) {   // task 0 = (J+1,J+1): wave 0
+            auto op_p2 = [&](int task) {
                 if (task < ntrail) {
                     int q = task, Kk = 0;
                     while (q >= m - Kk) { q -= m - Kk; ++Kk; }
-                    const int K = J + 1 + Kk, I = K + q;
-                    trailing_task(J, I, K);
-                } else {
-                    const int q = task - ntrail;
-                    const int I = J + 1 + q / (J + 1), K = q % (J + 1);
-                    d4 acc = {0.0, 0.0, 0.0, 0.0};
-                    double* dst = S + offB(I, K);
-                    acc = blk_mma(S + offB(J, K), DLD, 1, S + offS(I, J), DLD, acc, lane);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * DLD + l15] -= acc[r];
+                    const int K = J + 1 + Kk;
+                    return op_trailing(J, K + q, K);
                 }
+                const int q = task - ntrail;
+                return op_inverse(J, J + 1 + q / (J + 1), q % (J + 1));
+            };
+            for (int task = 1 + (w - 1); task < ntrail + ninv; task += 6) {   // task 0 = (J+1,J+1): wave 0
+                const bool two = task + 3 < ntrail + ninv;
+                const BlkOp o0 = op_p2(task);
+                run_pair(o0, two ? op_p2(task + 3) : o0, two, true);
             }
         }
         __syncthreads();
+        stamp(3 + 2 * J);
     }
     bad = __shfl(bad, 0);   // wave 0 holds it; the info store below runs on (w == 0, lane == 0)
-    // ---- write L back to the tile (upper blocks and upper parts of diagonal blocks are zero) and L^-1 to Dinv
-    for (int e = t; e < TB * TB; e += 256) {
-        const int r = e % TB, c = e / TB;
-        const int R = r >> 4, Cb = c >> 4;
-        double l = 0.0, xinv = 0.0;
-        if (R >= Cb) {
-            l = S[c * DLD + r];
-            xinv = (R == Cb) ? S[(R * 16 + (c & 15)) * DLD + TB + (r & 15)] : S[(R * 16 + (c & 15)) * DLD + Cb * 16 + (r & 15)];
+    // ---- write L back to the tile (upper blocks and upper parts of diagonal blocks are zero) and L^-1 to Dinv:
+    //      wave w takes columns 32w.., lanes two rows each (16 B LDS reads, 1 KiB contiguous global stores)
+    {
+        const int R = lane >> 3, ri = 2 * (lane & 7);
+        const d2 zero = {0.0, 0.0};
+#pragma unroll 4
+        for (int c = w * 32; c < w * 32 + 32; ++c) {
+            const int Cb = c >> 4, ci = c & 15;
+            const d2 l = *reinterpret_cast<const d2*>(S + c * DLD + 2 * lane);
+            const d2 x = *reinterpret_cast<const d2*>(S + (R * 16 + ci) * DLD + ((R == Cb) ? TB : Cb * 16) + ri);
+            *reinterpret_cast<d2*>(tk.T + 2 * lane + (size_t)c * tk.ld) = (R >= Cb) ? l : zero;
+            *reinterpret_cast<d2*>(tk.Dinv + 2 * lane + (size_t)c * TB) = (R >= Cb) ? x : zero;
         }
-        tk.T[r + (size_t)c * tk.ld] = l;
-        tk.Dinv[r + (size_t)c * TB] = xinv;
     }
     if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
-    if (tk.wk != nullptr && t < TB) {
-        // z_k = L_kk^-1 w_k from the inverse blocks still in LDS (row t of the lower-triangular inverse)
-        const int R = t >> 4, ri = t & 15;
+    stamp(18);
+    if (tk.wk != nullptr) {
+        // z_k = L_kk^-1 w_k from the inverse blocks still in LDS: thread (r = t >> 1, h = t & 1) sums the columns
+        // [64h, 64h+64) of row r of the lower-triangular inverse; no barrier, so the stores above keep draining
+        const int r = t >> 1, h = t & 1;
+        const int R = r >> 4, ri = r & 15;
         double s = 0.0;
-        for (int c = 0; c <= t; ++c) {
+        const int cend = min(r, 64 * h + 63);
+        for (int c = 64 * h; c <= cend; ++c) {
             const int Cb = c >> 4, ci = c & 15;
             const double x = (R == Cb) ? S[(R * 16 + ci) * DLD + TB + ri] : S[(R * 16 + ci) * DLD + Cb * 16 + ri];
-            s = fma(x, tk.wk[c], s);
+            s = fma(x, wl[c], s);
         }
-        tk.zk[t] = s;
+        s += __shfl_xor(s, 1);
+        if (h == 0) tk.zk[r] = s;
     }
+    stamp(19);
+}
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restrict__ tasks) {
+    extern __shared__ __attribute__((aligned(16))) double S[];   // [128 cols][DLD rows] + Winv[256] + rhs[128]
+    const DiagTask tk = tasks[blockIdx.x];
+    chol_diag_body<false>(tk, S, nullptr);
+}
+
+__global__ __launch_bounds__(256) void chol_diag_stamp_kernel(const DiagTask* __restrict__ tasks,
+                                                              unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) double S[];
+    const DiagTask tk = tasks[blockIdx.x];
+    chol_diag_body<true>(tk, S, stamps + 24 * (size_t)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -935,11 +1032,26 @@ __global__ __launch_bounds__(256) void solve_fwd_kernel(const SolveTask* __restr
 //   reads each off-diagonal tile once and each inverse block once.
 __device__ __forceinline__ void matvec_t128(const double* __restrict__ M, int ld, const double* __restrict__ x /* LDS, 128 */,
                                             double* __restrict__ y /* LDS, 128 */, int lane, int w) {
-    // y = M^T x for a 128x128 column-major block: one column per wave iteration, lanes over rows
-    for (int c = w; c < TB; c += 4) {
-        double s = M[lane + (size_t)c * ld] * x[lane] + M[lane + 64 + (size_t)c * ld] * x[lane + 64];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (lane == 0) y[c] = s;
+    // y = M^T x for a 128x128 column-major block: lanes over rows, 8 columns per wave in flight (the loads of a
+    // group are issued together; the sweep is a chain of dependent launches, so latency is what it pays for)
+    const double x0 = x[lane], x1 = x[lane + 64];
+    const gf64_ptr Mg = AS_GLOBAL_F64(M);
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        double p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = w + 4 * (g * 8 + j);
+            p[j] = Mg[lane + (size_t)c * ld] * x0 + Mg[lane + 64 + (size_t)c * ld] * x1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] += __shfl_down(p[j], o);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[w + 4 * (g * 8 + j)] = p[j];
+        }
     }
 }
 
