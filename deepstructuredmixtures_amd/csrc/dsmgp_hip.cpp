@@ -862,7 +862,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
             pt.begin(1);
             launch_tiles(c, S.upd.p + S.upd_off[k], nu);
             const int nr = S.red_off[k + 1] - S.red_off[k];
-            if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
+            if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
             pt.note(k, nu, S.step_tiles[k]);
             pt.end();
             if (count_launches) c->n_update_launches++;
@@ -1377,7 +1377,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
                     pt.begin(7);
                     launch_tiles(c, c->pupd.p + c->pupd_off[k], nu);
                     const int nr = c->pred_off[k + 1] - c->pred_off[k];
-                    if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->pred.p + c->pred_off[k]);
+                    if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(c->pred.p + c->pred_off[k]);
                     pt.end();
                 }
                 const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
@@ -1608,7 +1608,7 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
         if (nu > 0) {
             launch_tiles(c, c->gupd.p + c->gupd_off[k], nu);
             const int nr = c->gred_off[k + 1] - c->gred_off[k];
-            if (nr > 0) tile_reduce_kernel<<<nr, 256, 0, c->stream>>>(c->gred.p + c->gred_off[k]);
+            if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(c->gred.p + c->gred_off[k]);
         }
         const int ns = c->gtrsm_off[k + 1] - c->gtrsm_off[k];
         if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns);
@@ -2013,7 +2013,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     const int nt_ = (int)tasks.size();
     auto run = [&]() {
         launch_tiles(c, dt.p, nt_);
-        if (dr.count) tile_reduce_kernel<<<(int)dr.count, 256, 0, c->stream>>>(dr.p);
+        if (dr.count) tile_reduce_kernel<<<(int)dr.count * REDUCE_WGS, 256, 0, c->stream>>>(dr.p);
     };
     hipEvent_t t0, t1;
     HIPCHK(c, hipEventCreate(&t0));

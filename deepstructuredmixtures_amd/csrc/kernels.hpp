@@ -187,16 +187,39 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 __device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4], double* red /* >= 512 doubles of LDS */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
+    // element (cm, rn, r) of this lane sits at C[lofs + 16 rn + (16 cm + 4 r) ldc]: uniform column base + 32-bit lane
+    // offset.  C -= acc reads the tile in four quarters of 16 values per lane, all loads of a quarter in flight
+    // before its first store: a load placed after a store to the same array waits for the whole round trip, and
+    // 64 of those in a row cost ~20 us per task.
+    const unsigned lofs = (unsigned)(wr * 64 + l15) + (unsigned)(wc * 64 + l4) * (unsigned)tk.ldc;
+    const size_t ldc = (size_t)tk.ldc;
+    if (tk.update == 1) {
 #pragma unroll
-    for (int cm = 0; cm < 4; ++cm)
-#pragma unroll
-        for (int rn = 0; rn < 4; ++rn)
+        for (int cm = 0; cm < 4; ++cm) {
+            double cv[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                gf64_ptr pc = AS_GLOBAL_F64(tk.C + (wr * 64 + 16 * rn + l15) + (size_t)(wc * 64 + 16 * cm + l4 + 4 * r) * tk.ldc);
-                if (tk.update == 1) *pc = *pc - acc[cm][rn][r];
-                else *pc = acc[cm][rn][r];
+                const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cm + 4 * r) * ldc);
+#pragma unroll
+                for (int rn = 0; rn < 4; ++rn) cv[rn][r] = col[lofs + 16 * rn];
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cm + 4 * r) * ldc);
+#pragma unroll
+                for (int rn = 0; rn < 4; ++rn) col[lofs + 16 * rn] = cv[rn][r] - acc[cm][rn][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cm + 4 * r) * ldc);
+#pragma unroll
+                for (int rn = 0; rn < 4; ++rn) col[lofs + 16 * rn] = acc[cm][rn][r];
+            }
+    }
     if (tk.wi != nullptr) {
         double p[4] = {0.0, 0.0, 0.0, 0.0}, q2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -656,17 +679,28 @@ struct ReduceTask {
     int nsplit;
 };
 
+// REDUCE_WGS workgroups per tile (16 columns each); a thread owns two rows of four columns and keeps the loads of
+// two slabs (eight 16 B loads) in flight -- steps with few tiles and many slabs (the last block steps, multi-GPU
+// shards) are a chain of dependent launches, and this kernel's latency is on it.
+constexpr int REDUCE_WGS = 8;
 __global__ __launch_bounds__(256) void tile_reduce_kernel(const ReduceTask* __restrict__ tasks) {
-    const ReduceTask tk = tasks[blockIdx.x];
+    const ReduceTask tk = tasks[blockIdx.x / REDUCE_WGS];
     const int t = threadIdx.x;
     const int r = (t & 63) * 2;
-#pragma unroll 4
-    for (int c = t >> 6; c < TB; c += 4) {
-        d2 s = {0.0, 0.0};
-        for (int q = 0; q < tk.nsplit; ++q) s += *reinterpret_cast<const d2*>(tk.slabs + (size_t)q * TB * TB + r + c * TB);
-        d2* pc = reinterpret_cast<d2*>(tk.C + r + (size_t)c * tk.ldc);
-        *pc = *pc - s;
-    }
+    const int c0 = (blockIdx.x % REDUCE_WGS) * (TB / REDUCE_WGS) + (t >> 6);   // columns c0, c0+4, c0+8, c0+12
+    const gd2_cptr sl = AS_GLOBAL_D2(tk.slabs + r + (size_t)c0 * TB);
+    d2 s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = d2{0.0, 0.0};
+#pragma unroll 2
+    for (int q = 0; q < tk.nsplit; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] += sl[((size_t)q * TB * TB + (size_t)(4 * i) * TB) >> 1];
+    d2 cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cv[i] = *reinterpret_cast<const d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc) = cv[i] - s[i];
 }
 
 // ---------------------------------------------------------------------------------------------
