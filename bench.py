@@ -30,6 +30,7 @@ CONFIGS = {
     "dsmgp_n100k_d8": dict(N=100_000, D=8, K=3, V=4, M=200, depth=2),
     "dsmgp_n20k_d8": dict(N=20_000, D=8, K=3, V=4, M=200, depth=2),
     "dsmgp_n100k_d8_depth3": dict(N=100_000, D=8, K=3, V=4, M=200, depth=3),
+    "dsmgp_n100k_d8_depth4": dict(N=100_000, D=8, K=3, V=4, M=200, depth=4),   # 18,461 leaves, n = 103..2668
 }
 
 

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import hipabi
 from .kernels import IsoSE, ConstMean, KIND_ISO_SE, KIND_ARD_SE, KIND_ISO_LINEAR
-from .tree import (DSMGPConfig, build_tree, get_leaves, get_overlap, share_schedule, route, route_all,
+from .tree import (DSMGPConfig, GPSumNode, build_tree, get_leaves, get_overlap, share_schedule, route, route_all,
                    get_child, ordered_nodes, SHARE_COPY, SHARE_FULL, SHARE_PREFIX)
 from . import dist as _dist
 
@@ -30,6 +30,104 @@ def _logsumexp(a, axis=None):
     m = np.max(a, axis=axis, keepdims=True)
     m = np.where(np.isfinite(m), m, 0.0)
     return np.squeeze(np.log(np.sum(np.exp(a - m), axis=axis, keepdims=True)) + m, axis=axis)
+
+
+class TreeIndex:
+    """Level-order index of the sum/split tree so that the bottom-up passes of `update!`/`infer!`/`mll`
+    (`src/common.jl:323-355`, `src/optimize.jl:18-25`) and the top-down product of sum-node weights on a leaf's path
+    run as one vector operation per tree level instead of a Python recursion per node (18k leaves at depth 4).
+    Every sum node's `logweights` becomes a view into one flat edge array, so in-place updates are seen by the
+    literal recursions too."""
+
+    def __init__(self, root):
+        nodes, depth, parent_edge = [root], [0], [-1]
+        levels = []            # per depth d: internal nodes at d and their child edges (children sit at d + 1)
+        frontier = [0]
+        edge_child, edge_parent = [], []
+        d = 0
+        while frontier:
+            par, seg, cnt, nxt = [], [], [], []
+            e0 = len(edge_child)
+            for ni in frontier:
+                nd = nodes[ni]
+                if nd.kind == "gp":
+                    continue
+                par.append(ni)
+                seg.append(len(edge_child) - e0)
+                cnt.append(len(nd.children))
+                for c in nd.children:
+                    nodes.append(c)
+                    depth.append(d + 1)
+                    parent_edge.append(len(edge_child))
+                    edge_child.append(len(nodes) - 1)
+                    edge_parent.append(ni)
+                    nxt.append(len(nodes) - 1)
+            if par:
+                levels.append(dict(parent=np.array(par), seg=np.array(seg), cnt=np.array(cnt), e0=e0,
+                                   e1=len(edge_child)))
+            frontier = nxt
+            d += 1
+        self.nodes = nodes
+        self.n = len(nodes)
+        self.edge_child = np.array(edge_child, dtype=np.int64)
+        self.edge_parent = np.array(edge_parent, dtype=np.int64)
+        self.parent_edge = np.array(parent_edge, dtype=np.int64)
+        is_sum = np.array([nd.kind == "sum" for nd in nodes])
+        of_gps = np.array([nd.kind == "sum" and nd.of_gps for nd in nodes])
+        nch = np.array([0 if nd.kind == "gp" else len(nd.children) for nd in nodes], dtype=np.float64)
+        self.edge_is_sum = is_sum[self.edge_parent] if self.edge_parent.size else np.zeros(0, bool)
+        self.edge_of_gps = of_gps[self.edge_parent] if self.edge_parent.size else np.zeros(0, bool)
+        self.edge_prior = np.where(self.edge_is_sum, -np.log(np.maximum(nch[self.edge_parent], 1.0)), 0.0) \
+            if self.edge_parent.size else np.zeros(0)
+        self.leaf_node = np.array([i for i, nd in enumerate(nodes) if nd.kind == "gp"], dtype=np.int64)
+        self.leaf_id = np.array([nodes[i].leaf for i in self.leaf_node], dtype=np.int64)
+        for lv in levels:
+            lv["parent_is_sum"] = is_sum[lv["parent"]]
+        self.levels = levels
+        self.lw = np.zeros(self.edge_child.size)       # log weight per edge (0 under split nodes)
+        self.bind()
+
+    def bind(self):
+        """(Re)attach every sum node's logweights to the flat edge array, keeping the current values."""
+        for lv in self.levels:
+            for ni, a, k in zip(lv["parent"], lv["seg"] + lv["e0"], lv["cnt"]):
+                nd = self.nodes[ni]
+                if nd.kind == "sum":
+                    self.lw[a:a + k] = nd._lw
+                    nd._lw = self.lw[a:a + k]
+        self.version = GPSumNode.assignments
+
+    def bound(self):
+        return self.version == GPSumNode.assignments
+
+    def bottom_up(self, leaf_values, posterior="all"):
+        """Node values of the mll recursion; posterior: "all" = update!, "gps" = infer!, None = leave weights."""
+        val = np.empty(self.n)
+        val[self.leaf_node] = leaf_values[self.leaf_id]
+        for lv in reversed(self.levels):
+            sl = slice(lv["e0"], lv["e1"])
+            v = val[self.edge_child[sl]] + self.edge_prior[sl]
+            m = np.maximum.reduceat(v, lv["seg"])
+            m = np.where(np.isfinite(m), m, 0.0)
+            z = m + np.log(np.add.reduceat(np.exp(v - np.repeat(m, lv["cnt"])), lv["seg"]))
+            tot = np.add.reduceat(v, lv["seg"])
+            val[lv["parent"]] = np.where(lv["parent_is_sum"], z, tot)
+            if posterior is not None:
+                post = v - np.repeat(z, lv["cnt"])
+                if posterior == "gps":
+                    post = np.where(self.edge_of_gps[sl], post, self.edge_prior[sl])
+                self.lw[sl] = np.where(self.edge_is_sum[sl], post, 0.0)
+        return val
+
+    def leaf_path_logweights(self):
+        """log of the product of sum-node weights on every leaf's path, indexed by leaf id."""
+        acc = np.zeros(self.n)
+        for lv in self.levels:
+            sl = slice(lv["e0"], lv["e1"])
+            acc[self.edge_child[sl]] = acc[self.edge_parent[sl]] + self.lw[sl]
+        out = np.zeros(self.leaf_id.size)
+        out[self.leaf_id] = acc[self.leaf_node]
+        return out
 
 
 class Model:
@@ -55,6 +153,15 @@ class Model:
         self._uploaded = False
         self._schedule = None
         self._route_cache = None
+        self._tindex = None
+
+    @property
+    def tindex(self):
+        if self._tindex is None:
+            self._tindex = TreeIndex(self.root)
+        elif not self._tindex.bound():      # somebody assigned fresh logweights arrays: take them over
+            self._tindex.bind()
+        return self._tindex
 
     @property
     def ctx(self):
@@ -73,10 +180,12 @@ class Model:
     def kernel_table(self):
         """One (kernel, logNoise) per kernel id, taken from the first leaf carrying that id: the
         reference sets every leaf of an id to the same vector (`src/optimize.jl:188-198`)."""
-        tab = {}
-        for lf in self.leaves:
-            tab.setdefault(lf.kernelid, lf)
-        return [tab[k] for k in sorted(tab)]
+        if getattr(self, "_ktab", None) is None:      # which leaf carries an id first is structural: cache it
+            tab = {}
+            for lf in self.leaves:
+                tab.setdefault(lf.kernelid, lf)
+            self._ktab = [tab[k] for k in sorted(tab)]
+        return self._ktab
 
     def _push_hyper(self):
         for lf in self.kernel_table():
@@ -253,6 +362,11 @@ def mll(model):
     """Tree log marginal likelihood (`src/optimize.jl:18-25`)."""
     if isinstance(model, GaussianProcess):
         return float(model.model.leaf_mll[0])
+    return float(model.tindex.bottom_up(model.leaf_mll, posterior=None)[0])
+
+
+def _mll_recursive(model):
+    """The literal recursion of `src/optimize.jl:18-25` (cross-check of TreeIndex.bottom_up in the CPU tests)."""
 
     def rec(node):
         if node.kind == "gp":
@@ -286,6 +400,11 @@ def mll_table(model):
 
 def update(model):
     """`update!(model)`: posterior sum-node weights (`src/common.jl:323-334`). Returns the root value."""
+    return float(model.tindex.bottom_up(model.leaf_mll, posterior="all")[0])
+
+
+def _update_recursive(model):
+    """The literal recursion of `src/common.jl:323-334` (cross-check of the level-order pass in the CPU tests)."""
 
     def rec(node):
         if node.kind == "gp":
@@ -303,26 +422,14 @@ def update(model):
 
 def infer(model):
     """`infer!(model)` (`src/common.jl:336-355`): only sums over GPs keep posterior weights."""
-
-    def rec(node):
-        if node.kind == "gp":
-            return float(model.leaf_mll[node.leaf])
-        if node.kind == "split":
-            return sum(rec(c) for c in node.children)
-        K = len(node.children)
-        lw = np.array([-np.log(K) + rec(c) for c in node.children])
-        z = float(_logsumexp(lw))
-        node.logweights = (lw - z) if node.of_gps else np.full(K, -np.log(K))
-        return z
-
-    return rec(model.root)
+    return float(model.tindex.bottom_up(model.leaf_mll, posterior="gps")[0])
 
 
 def reset_weights(model):
     """`reset_weights!` (`src/common.jl:357-363`)."""
     for n in ordered_nodes(model.root):
         if n.kind == "sum":
-            n.logweights = np.full(len(n.children), -np.log(len(n.children)))
+            n.logweights[:] = -np.log(len(n.children))
 
 
 # ------------------------------------------------------------------------------------ parameters
@@ -518,19 +625,7 @@ def _aggregate_dsmgp_flat(model, n_t, rc, mu, var):
         mu = sum_l W_l mu_l,   v = sum_l W_l sigma2_l + sum_l W_l mu_l^2 - mu^2
     in three weighted bincounts over the (leaf, row) entries.  `_aggregate_dsmgp` below is the literal recursion,
     kept as the cross-check (tests/test_host_cpu.py)."""
-    logW = np.zeros(model.L)
-
-    def rec(node, lw):
-        if node.kind == "gp":
-            logW[node.leaf] = lw
-        elif node.kind == "sum":
-            for k, c in enumerate(node.children):
-                rec(c, lw + node.logweights[k])
-        else:
-            for c in node.children:
-                rec(c, lw)
-
-    rec(model.root, 0.0)
+    logW = model.tindex.leaf_path_logweights()
     ptr, idx = rc["ptr"], rc["idx"]
     w = np.repeat(np.exp(logW), np.diff(ptr))
     s2 = np.where(var <= 0, EPS, var)                       # src/common.jl:137

@@ -58,12 +58,25 @@ class GPSumNode:
     def __init__(self, of_gps=False):
         self.id = _gensym("sum")
         self.children = []
-        self.logweights = np.zeros(0)
+        self._lw = np.zeros(0)
         self.of_gps = of_gps
+
+    # Assigning a fresh array is counted, so that a level-order index holding views of the weights
+    # (model.TreeIndex) knows when to re-attach them; in-place writes need no bookkeeping.
+    assignments = 0
+
+    @property
+    def logweights(self):
+        return self._lw
+
+    @logweights.setter
+    def logweights(self, v):
+        self._lw = np.asarray(v, dtype=np.float64)
+        GPSumNode.assignments += 1
 
     def add(self, child, logw):
         self.children.append(child)
-        self.logweights = np.append(self.logweights, logw)
+        self.logweights = np.append(self._lw, logw)
 
 
 class DSMGPConfig:
@@ -214,6 +227,66 @@ def build_tree(X, y, config, seed=7):
 
 # ----------------------------------------------------------------------------- overlap + schedule
 
+def _membership(leaves):
+    """Sparse leaf-membership matrix M (L x N, int32 ones) and the leaf sizes."""
+    import scipy.sparse as sp
+    L = len(leaves)
+    nobs = np.array([lf.nobs for lf in leaves], dtype=np.int64)
+    rows = np.repeat(np.arange(L), nobs)
+    cols = np.concatenate([lf.obs for lf in leaves]) if L else np.zeros(0, np.int64)
+    N = int(cols.max()) + 1 if cols.size else 1
+    return sp.csr_matrix((np.ones(rows.size, dtype=np.int32), (rows, cols)), shape=(L, N)), nobs
+
+
+class LeafOverlap:
+    """The leaf-overlap matrix of `src/fit.jl:12-39` kept as the sparse intersection counts C = M M^T
+    (one kernel id; see get_overlap).  D[n,m] = 1 - (|n| - C[n,m]) / |n| where C > 0 and n != m, else 0 --
+    at depth 4 the headline model has 18k leaves and 5.6e7 overlapping pairs: the dense L x L matrix of the
+    reference and its O(L^2) bitset loops are what SURVEY 8(f).1 asks to remove."""
+
+    def __init__(self, leaves):
+        M, self.nobs = _membership(leaves)
+        C = (M @ M.T).tocsr()
+        C.sort_indices()
+        self.C = C
+        self.shape = (len(leaves), len(leaves))
+        self._pairs = None
+
+    def todense(self):
+        C = np.asarray(self.C.todense(), dtype=np.float64)
+        n = self.nobs
+        Dm = np.where(C > 0, 1.0 - (n[:, None] - C) / n[:, None], 0.0)
+        np.fill_diagonal(Dm, 0.0)
+        return Dm
+
+    def main_pairs(self):
+        """For every leaf j: main[j] = argmax_i D[i,j] D[j,i] (first maximum, 0 when the leaf overlaps nothing, like
+        argmax of the dense all-zero column) and the two factors D[main,j], D[j,main]."""
+        if self._pairs is not None:
+            return self._pairs
+        C, n = self.C, self.nobs.astype(np.float64)
+        L = self.shape[0]
+        indptr, col = C.indptr, C.indices
+        c = C.data.astype(np.float64)
+        row = np.repeat(np.arange(L), np.diff(indptr))
+        off = col != row
+        d_rc = 1.0 - (n[row] - c) / n[row]          # D[row, col]
+        d_cr = 1.0 - (n[col] - c) / n[col]          # D[col, row]
+        prod = np.where(off, d_cr * d_rc, 0.0)
+        rowmax = np.maximum.reduceat(prod, indptr[:-1])        # every row holds its diagonal entry
+        pos = np.where((prod == rowmax[row]) & off, np.arange(col.size), col.size)
+        first = np.minimum.reduceat(pos, indptr[:-1])
+        has = (rowmax > 0.0) & (first < col.size)
+        firstc = np.where(has, first, 0)
+        main = np.where(has, col[firstc], 0).astype(np.int64)
+        d_ij = np.where(has, d_cr[firstc], 0.0)                # D[main, j]
+        d_ji = np.where(has, d_rc[firstc], 0.0)                # D[j, main]
+        # a leaf without overlap points at leaf 0: D[0, j] and D[j, 0] are 0 unless j shares data with leaf 0,
+        # in which case it has overlap and does not get here
+        self._pairs = (main, d_ij, d_ji)
+        return self._pairs
+
+
 def get_overlap(root, L):
     """Leaf-overlap matrix (`src/fit.jl:12-39`): D[n,m] = 1 - |n \\ m| / |n| for leaves under different
     children of a common sum node, forced to 1 when kernel ids differ.
@@ -221,17 +294,15 @@ def get_overlap(root, L):
     Two leaves that share an observation always hang under different children of some sum node (split nodes
     partition), and leaves that share none get 1 - |n|/|n| = 0, the default.  With a single kernel id the whole
     matrix therefore follows from the intersection counts C = M M^T of the sparse leaf-membership matrix M
-    (L x N) -- one sparse product instead of the reference's O(L^2) bitset loops.  Kernel vectors (ids differ,
-    forced ones also for disjoint pairs) take the literal pairwise recursion."""
+    (L x N) -- one sparse product instead of the reference's O(L^2) bitset loops; beyond 8192 leaves the result
+    stays sparse (LeafOverlap).  Kernel vectors (ids differ, forced ones also for disjoint pairs) take the
+    literal pairwise recursion."""
     leaves = get_leaves(root)
-    if len({lf.kernelid for lf in leaves}) > 1 or L > 8192:
+    if len({lf.kernelid for lf in leaves}) > 1:
         return _get_overlap_pairwise(root, L)
-    import scipy.sparse as sp
-    nobs = np.array([lf.nobs for lf in leaves], dtype=np.int64)
-    rows = np.repeat(np.arange(L), nobs)
-    cols = np.concatenate([lf.obs for lf in leaves]) if L else np.zeros(0, np.int64)
-    N = int(cols.max()) + 1 if cols.size else 1
-    M = sp.csr_matrix((np.ones(rows.size, dtype=np.int32), (rows, cols)), shape=(L, N))
+    if L > 8192:
+        return LeafOverlap(leaves)
+    M, nobs = _membership(leaves)
     C = np.asarray((M @ M.T).todense(), dtype=np.float64)
     Dm = np.where(C > 0, 1.0 - (nobs[:, None] - C) / nobs[:, None], 0.0)   # same expression as src/fit.jl:30
     np.fill_diagonal(Dm, 0.0)
@@ -291,12 +362,15 @@ def share_schedule(leaves, Dm, tau=0.05):
     plen = np.zeros(L, dtype=np.int64)
     if L == 0:
         return op, src, plen
-    main = np.empty(L, dtype=np.int64)
-    counts = np.zeros(L, dtype=np.int64)
-    for j in range(L):
-        i = int(np.argmax(Dm[:, j] * Dm[j, :]))
-        main[j] = i
-        counts[i] += 1
+    if isinstance(Dm, LeafOverlap):
+        main, d_ij, d_ji = Dm.main_pairs()
+    else:
+        main = np.empty(L, dtype=np.int64)
+        for j in range(L):
+            main[j] = int(np.argmax(Dm[:, j] * Dm[j, :]))
+        d_ij = Dm[main, np.arange(L)]
+        d_ji = Dm[np.arange(L), main]
+    counts = np.bincount(main, minlength=L)
     order = sorted(range(L), key=lambda j: counts[j])  # stable, like Julia's sort! on objects
     processed = np.zeros(L, dtype=bool)
     for j in order:
@@ -311,8 +385,8 @@ def share_schedule(leaves, Dm, tau=0.05):
         lj, li = leaves[j], leaves[i]
         if li.kernelid != lj.kernelid or lj.obs[0] < li.obs[0]:
             continue
-        ione = Dm[i, j] == 1.0
-        jone = Dm[j, i] == 1.0
+        ione = d_ij[j] == 1.0
+        jone = d_ji[j] == 1.0
         if ione and jone:
             if op[i] == SHARE_FULL:
                 op[j], src[j] = SHARE_COPY, i

@@ -269,3 +269,55 @@ def test_product_fails_loudly_without_a_gpu():
         if fn.endswith(".py"):
             src = open(os.path.join(ROOT, "deepstructuredmixtures_amd", fn)).read()
             assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_sparse_overlap_and_level_order_tree_passes_match_the_recursions():
+    """The large-L paths: LeafOverlap (sparse intersection counts) gives the same matrix and the same
+    sharing schedule as the dense path, and the level-order update!/infer!/mll/path-weight passes equal the literal
+    recursions of src/common.jl:323-355 and src/optimize.jl:18-25."""
+    from deepstructuredmixtures_amd import model as pmodel
+    rng = np.random.default_rng(5)
+    cases = [dict(N=3000, D=3, depth=3, M=20, kernel=dsm.IsoSE(0.0, 0.0)),
+             dict(N=2500, D=2, depth=2, M=15, kernel=[dsm.IsoSE(0.0, 0.0), dsm.IsoLinear(0.0)]),
+             dict(N=2000, D=4, depth=3, M=12, kernel=dsm.IsoSE(0.0, 0.0))]
+    for i, c in enumerate(cases):
+        X, y = _small_problem(c["N"], c["D"], seed=40 + i)
+        m = dsm.buildDSMGP(X, y, 3, 4, M=c["M"], D=c["depth"], kernel=c["kernel"], fit_now=False, seed=3 + i)
+        if not isinstance(c["kernel"], list):
+            ov = ptree.LeafOverlap(m.leaves)
+            assert np.array_equal(ov.todense(), m.D)
+            for tau in (0.05, 0.0):
+                a = ptree.share_schedule(m.leaves, m.D, tau)
+                b = ptree.share_schedule(m.leaves, ov, tau)
+                assert all(np.array_equal(u, v) for u, v in zip(a, b))
+        m.leaf_mll = -50.0 * rng.random(m.L) - 5.0
+        z_vec = dsm.update(m)
+        w_vec = [n.logweights.copy() for n in ptree.ordered_nodes(m.root) if n.kind == "sum"]
+        logW = m.tindex.leaf_path_logweights()
+        z_rec = pmodel._update_recursive(m)          # assigns fresh arrays: the index must notice and re-attach
+        w_rec = [n.logweights.copy() for n in ptree.ordered_nodes(m.root) if n.kind == "sum"]
+        assert abs(z_vec - z_rec) <= 1e-12 * abs(z_rec)
+        assert all(np.allclose(u, v, rtol=0, atol=1e-12) for u, v in zip(w_vec, w_rec))
+        assert abs(dsm.mll(m) - pmodel._mll_recursive(m)) <= 1e-12 * abs(z_rec)
+        # path weights: product of the sum-node weights above each leaf
+        ref = np.zeros(m.L)
+
+        def rec(node, lw):
+            if node.kind == "gp":
+                ref[node.leaf] = lw
+            else:
+                for k, ch in enumerate(node.children):
+                    rec(ch, lw + (node.logweights[k] if node.kind == "sum" else 0.0))
+        rec(m.root, 0.0)
+        assert np.allclose(m.tindex.leaf_path_logweights(), ref, rtol=0, atol=1e-12)
+        assert np.allclose(logW, ref, rtol=0, atol=1e-12)
+        # infer!: only sums over GPs keep posterior weights; reset_weights writes in place
+        dsm.infer(m)
+        for n in ptree.ordered_nodes(m.root):
+            if n.kind == "sum" and not n.of_gps:
+                assert np.allclose(n.logweights, -np.log(len(n.children)))
+            if n.kind == "sum":
+                assert abs(np.exp(n.logweights).sum() - 1.0) < 1e-12
+        dsm.reset_weights(m)
+        assert all(np.allclose(n.logweights, -np.log(len(n.children)))
+                   for n in ptree.ordered_nodes(m.root) if n.kind == "sum")
