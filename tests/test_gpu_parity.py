@@ -284,6 +284,28 @@ def test_models_vs_oracle(family):
     assert np.allclose(var, vo, rtol=RTOL, atol=1e-10), float(np.max(np.abs(var - vo) / vo))
 
 
+def test_depth4_many_small_leaves_vs_oracle():
+    """The small-M panel regime of SURVEY 8(a) (config 4'': depth 4, thousands of leaves of a few blocks at most):
+    more than 8192 leaves, so the overlap matrix stays sparse (tree.LeafOverlap) and update!/predict run their
+    level-order passes; leaf log-marginals, the sharing census, update! and predict against the oracle."""
+    N, D = 12000, 3
+    X, y, Xt = regression_data(N, D, n_test=300, seed=77)
+    m = dsm.buildDSMGP(X, y, 2, 5, M=8, D=4, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=9)
+    assert m.L > 8192 and isinstance(m.D, ptree.LeafOverlap)
+    gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+    census = ospn.fit(m.root, gps, m.D.todense(), 0.05)
+    assert np.count_nonzero(m.share_op == ptree.SHARE_COPY) == census["copy"] > 0
+    assert np.count_nonzero(m.share_op == ptree.SHARE_PREFIX) == census["prefix"] > 0
+    lo = np.array([g.mll() for g in gps])
+    assert np.allclose(m.leaf_mll, lo, rtol=RTOL, atol=1e-8)
+    z, zo = dsm.update(m), ospn.update(m.root, gps)
+    assert abs(z - zo) <= RTOL * max(1.0, abs(zo))
+    mo, vo = ospn.predict(m.root, gps, Xt)
+    mu, var = dsm.predict(m, Xt)
+    assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9), float(np.max(np.abs(mu - mo)))
+    assert np.allclose(var, vo, rtol=RTOL, atol=1e-10), float(np.max(np.abs(var - vo) / vo))
+
+
 @pytest.mark.parametrize("kind,n,D", [(0, 300, 2), (0, 1111, 5), (1, 400, 3), (2, 333, 2)])
 def test_gradients_vs_oracle(ctx, kind, n, D):
     """updategradients!(gp): [dl..., ds, dnoise] with the reference's scaling and ArdSE dl == 0 (F6)."""
