@@ -30,14 +30,22 @@ class Shard:
     def single(L):
         return Shard(np.zeros(L, dtype=np.int64), 0, 1)
 
+    # time model of one rank: flops at the sustained rate of the tile kernel + a serial term per block step of its
+    # largest leaf (diagonal block + panel solve + split-K reduce + launch gaps sit on the chain of every step)
+    RATE_FLOPS = 58e12
+    STEP_SECONDS = 120e-6
+
     @staticmethod
     def lpt(nobs, op, src, rank, world, n_test=None):
-        """Longest-processing-time greedy on cost n^3/3 + n^2 * n_t,leaf; COPY/PREFIX leaves follow
-        their source so shared factors stay on one GPU."""
+        """Longest-processing-time greedy on cost n^3/3 + n^2 * n_t,leaf, where a rank's load also counts the
+        block steps of its largest leaf (the batched factorisation runs max_leaf(n/128) dependent steps, so the
+        rank holding the largest leaf gets a little less arithmetic); COPY/PREFIX leaves follow their source so
+        shared factors stay on one GPU."""
         nobs = np.asarray(nobs, dtype=np.float64)
         L = nobs.size
         nt = np.zeros(L) if n_test is None else np.asarray(n_test, dtype=np.float64)
         cost = nobs ** 3 / 3.0 + nobs ** 2 * nt
+        steps = np.ceil(nobs / 128.0)
         group = np.arange(L)
         for j in range(L):
             if op[j] != 0 and src[j] >= 0:
@@ -49,12 +57,18 @@ class Shard:
             gcost[group[j]] += cost[j] if op[j] == 0 else 2.0 * nobs[j] ** 2
         roots = [g for g in range(L) if group[g] == g]
         roots.sort(key=lambda g: (-gcost[g], g))
+        gsteps = np.zeros(L)
+        for j in range(L):
+            gsteps[group[j]] = max(gsteps[group[j]], steps[j])
         load = np.zeros(world)
+        maxsteps = np.zeros(world)
         owner_of_root = {}
         for g in roots:
-            r = int(np.argmin(load))
+            t = (load + gcost[g]) / Shard.RATE_FLOPS + Shard.STEP_SECONDS * np.maximum(maxsteps, gsteps[g])
+            r = int(np.argmin(t))
             owner_of_root[g] = r
             load[r] += gcost[g]
+            maxsteps[r] = max(maxsteps[r], gsteps[g])
         owner = np.array([owner_of_root[group[j]] for j in range(L)], dtype=np.int64)
         return Shard(owner, rank, world)
 
