@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <array>
+#include <chrono>
 #include <vector>
 
 using namespace dsmgp;
@@ -43,6 +44,19 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t count = 0;
+};
+
+// DSMGP_HOSTLOG=1: wall time of the host-side phases of plan building to stderr (diagnostic)
+struct HostLog {
+    const char* what;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostLog(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~HostLog() {
+        static const bool on = std::getenv("DSMGP_HOSTLOG") != nullptr;
+        if (on)
+            std::fprintf(stderr, "hostlog %-28s %.3f s\n", what,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
 };
 
 struct StepLists {
@@ -213,6 +227,11 @@ struct dsmgp_ctx {
 
     DevBuf<GramTask> gram;
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
+    // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
+    // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
+    // allocation (5 s per 230 GB group measured), which dominated the streaming mode's wall time.
+    char* pool_base = nullptr;
+    size_t pool_cap = 0, pool_top = 0, pool_mark_plan = 0;
     double* slabF = nullptr;        // split-K workspace of the factorisation
     StepLists phaseJ[2];            // the same with the resident test rows riding along (built by set_test)
     double* slabJ = nullptr;
@@ -310,9 +329,32 @@ void dev_free(T*& p) {
     p = nullptr;
 }
 
+bool in_pool(const dsmgp_ctx* c, const void* p) {
+    return c->pool_base && (const char*)p >= c->pool_base && (const char*)p < c->pool_base + c->pool_cap;
+}
+// `count` doubles for one of the large arenas: from the pool when there is one, else its own allocation
+int arena_get(dsmgp_ctx* c, double*& p, size_t count) {
+    const size_t bytes = std::max<size_t>(1, count) * sizeof(double);
+    if (c->pool_base) {
+        const size_t off = (c->pool_top + 255) & ~size_t(255);
+        if (off + bytes > c->pool_cap)
+            return fail(c, DSMGP_E_NOMEM, "reserved device pool too small: need " + std::to_string((off + bytes) >> 20) +
+                                              " MiB, pool has " + std::to_string(c->pool_cap >> 20) + " MiB");
+        p = reinterpret_cast<double*>(c->pool_base + off);
+        c->pool_top = off + bytes;
+        return 0;
+    }
+    HIPCHK(c, hipMalloc(&p, bytes));
+    return 0;
+}
+void arena_put(dsmgp_ctx* c, double*& p) {
+    if (p && !in_pool(c, p)) (void)hipFree(p);
+    p = nullptr;
+}
+
 void free_grad(dsmgp_ctx* c) {
-    dev_free(c->arenaX);
-    dev_free(c->slabG);
+    arena_put(c, c->arenaX);
+    arena_put(c, c->slabG);
     dev_free(c->gtrans.p);
     dev_free(c->gupd.p);
     dev_free(c->gtrsm.p);
@@ -323,11 +365,17 @@ void free_grad(dsmgp_ctx* c) {
     c->grad_ready = false;
 }
 
+void free_test(dsmgp_ctx* c);
 void free_plan(dsmgp_ctx* c) {
-    dev_free(c->arenaF);
-    dev_free(c->arenaDinv);
-    dev_free(c->arenaVec);
-    dev_free(c->arenaXg);
+    if (c->pool_base) {      // stack order: everything above the plan goes with it
+        free_test(c);
+        c->pool_top = 0;
+        c->pool_mark_plan = 0;
+    }
+    arena_put(c, c->arenaF);
+    arena_put(c, c->arenaDinv);
+    arena_put(c, c->arenaVec);
+    arena_put(c, c->arenaXg);
     dev_free(c->d_info);
     dev_free(c->d_mll);
     dev_free(c->d_leaves);
@@ -338,7 +386,7 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.red.p);
         dev_free(ph.diag.p);
     }
-    dev_free(c->slabF);
+    arena_put(c, c->slabF);
     dev_free(c->fwd.p);
     dev_free(c->bwd.p);
     free_grad(c);
@@ -347,26 +395,30 @@ void free_plan(dsmgp_ctx* c) {
 }
 
 void free_test(dsmgp_ctx* c) {
+    if (c->pool_base) {      // the gradient arenas sit above (or would be clobbered below) the test arenas
+        free_grad(c);
+        c->pool_top = c->pool_mark_plan;
+    }
     dev_free(c->dXt);
     dev_free(c->d_route_ptr);
     dev_free(c->d_route_idx);
-    dev_free(c->arenaVt);
-    dev_free(c->arenaXt);
-    dev_free(c->arenaPV);
+    arena_put(c, c->arenaVt);
+    arena_put(c, c->arenaXt);
+    arena_put(c, c->arenaPV);
     dev_free(c->pgram.p);
     dev_free(c->ptasks.p);
     dev_free(c->ptasks_slow.p);
     dev_free(c->pupd.p);
     dev_free(c->ptrsm.p);
     dev_free(c->pred.p);
-    dev_free(c->slabP);
+    arena_put(c, c->slabP);
     for (auto& ph : c->phaseJ) {
         dev_free(ph.upd.p);
         dev_free(ph.trsm.p);
         dev_free(ph.red.p);
         dev_free(ph.diag.p);
     }
-    dev_free(c->slabJ);
+    arena_put(c, c->slabJ);
     c->joint_ready = false;
     c->vt_valid = false;
     c->test_ready = false;
@@ -592,8 +644,9 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
     }
     {
         const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
-        dev_free(slab_ws);
-        if (slabs) HIPCHK(c, hipMalloc(&slab_ws, slabs * TB * TB * sizeof(double)));
+        arena_put(c, slab_ws);
+        if (slabs)
+            if (int rc = arena_get(c, slab_ws, slabs * TB * TB)) return rc;
         for (int ph = 0; ph < 2; ++ph) {
             split[ph].bind(slab_ws);
             if (int rc = dev_upload(c, phase[ph].upd, split[ph].upd)) return rc;
@@ -610,7 +663,11 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
 
 // Build arenas, the LeafDev table and every task list for the current leaf table + sharing schedule.
 int build_plan(dsmgp_ctx* c) {
-    free_plan(c);
+    HostLog hl_total("build_plan");
+    {
+        HostLog hl("build_plan: free_plan");
+        free_plan(c);
+    }
     const int L = c->L;
     if (L == 0) return fail(c, DSMGP_E_STATE, "no leaves set");
     size_t fTot = 0, dTot = 0, vTot = 0, xTot = 0;
@@ -646,13 +703,16 @@ int build_plan(dsmgp_ctx* c) {
     c->bytes_needed = (fTot + dTot + vTot + xTot) * sizeof(double);
     size_t freeB = 0, totalB = 0;
     HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
-    if (c->bytes_needed + (size_t(1) << 30) > freeB)
+    if (!c->pool_base && c->bytes_needed + (size_t(1) << 30) > freeB)
         return fail(c, DSMGP_E_NOMEM, "leaf table needs " + std::to_string(c->bytes_needed >> 20) + " MiB, device has " +
                                           std::to_string(freeB >> 20) + " MiB free");
-    HIPCHK(c, hipMalloc(&c->arenaF, std::max<size_t>(1, fTot) * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->arenaDinv, std::max<size_t>(1, dTot) * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->arenaVec, std::max<size_t>(1, vTot) * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->arenaXg, std::max<size_t>(1, xTot) * sizeof(double)));
+    {
+        HostLog hl("build_plan: arenas");
+        if (int rc = arena_get(c, c->arenaF, fTot)) return rc;
+        if (int rc = arena_get(c, c->arenaDinv, dTot)) return rc;
+        if (int rc = arena_get(c, c->arenaVec, vTot)) return rc;
+        if (int rc = arena_get(c, c->arenaXg, xTot)) return rc;
+    }
     HIPCHK(c, hipMalloc(&c->d_info, L * sizeof(int)));
     HIPCHK(c, hipMalloc(&c->d_mll, L * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_leaves, L * sizeof(LeafDev)));
@@ -715,7 +775,10 @@ int build_plan(dsmgp_ctx* c) {
     if (int rc = dev_upload(c, c->gram, gram)) return rc;
 
     // factorisation phases (train rows only; set_test adds a second set with the test rows riding along)
-    if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update)) return rc;
+    {
+        HostLog hl("build_plan: factor steps");
+        if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update)) return rc;
+    }
 
     // solve sweeps.  Forward: only leaves whose factor came from elsewhere (COPY, PREFIX) -- leaves factorised
     // in full get z = L^-1 y from the factorisation itself (chol_diag_kernel + the panel-solve epilogue).
@@ -791,6 +854,7 @@ int build_plan(dsmgp_ctx* c) {
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->plan_ready = true;
+    c->pool_mark_plan = c->pool_top;
     return 0;
 }
 
@@ -926,6 +990,8 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     (void)hipSetDevice(c->device);
     free_plan(c);
     free_test(c);
+    if (c->pool_base) (void)hipFree(c->pool_base);
+    c->pool_base = nullptr;
     dev_free(c->dX);
     dev_free(c->dy);
     dev_free(c->d_obs_ptr);
@@ -1177,6 +1243,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_test before set_leaves");
     if (!Xt || n_t <= 0 || !route_ptr) return fail(c, DSMGP_E_ARG, "set_test: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    HostLog hl_total("set_test");
     if (!c->plan_ready)
         if (int rc = build_plan(c)) return rc;
     free_test(c);
@@ -1209,7 +1276,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     size_t freeB = 0, totalB = 0;
     HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
     const size_t need = (vTot + xTot + pTot) * sizeof(double) + (size_t)n_t * c->D * sizeof(double);
-    if (need + (size_t(1) << 30) > freeB)
+    if (!c->pool_base && need + (size_t(1) << 30) > freeB)
         return fail(c, DSMGP_E_NOMEM, "test set needs " + std::to_string(need >> 20) + " MiB, device has " +
                                           std::to_string(freeB >> 20) + " MiB free");
     HIPCHK(c, hipMalloc(&c->dXt, (size_t)n_t * c->D * sizeof(double)));
@@ -1218,9 +1285,9 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     HIPCHK(c, hipMemcpy(c->d_route_ptr, route_ptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_route_idx, std::max<int64_t>(1, total) * sizeof(int64_t)));
     if (total) HIPCHK(c, hipMemcpy(c->d_route_idx, route_idx, total * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMalloc(&c->arenaVt, std::max<size_t>(1, vTot) * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->arenaXt, std::max<size_t>(1, xTot) * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->arenaPV, std::max<size_t>(1, pTot) * sizeof(double)));
+    if (int rc = arena_get(c, c->arenaVt, vTot)) return rc;
+    if (int rc = arena_get(c, c->arenaXt, xTot)) return rc;
+    if (int rc = arena_get(c, c->arenaPV, pTot)) return rc;
     int maxpad = 0;
     size_t accOff = 0;
     c->acc_off = 2 * (size_t)total;
@@ -1333,7 +1400,8 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     c->pupd_off[nsteps] = (int)U.upd.size();
     c->pred_off[nsteps] = (int)U.red.size();
     c->ptrsm_off[nsteps] = (int)trsm.size();
-    if (U.max_slabs) HIPCHK(c, hipMalloc(&c->slabP, U.max_slabs * TB * TB * sizeof(double)));
+    if (U.max_slabs)
+        if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
     U.bind(c->slabP);
     if (int rc = dev_upload(c, c->pupd, U.upd)) return rc;
     if (int rc = dev_upload(c, c->pred, U.red)) return rc;
@@ -1342,7 +1410,10 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
     if (int rc = dev_upload(c, c->ptasks_slow, ptk_slow)) return rc;
     // the same test rows as riders of the factorisation launches (used by fit while this test set is resident)
-    if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint)) return rc;
+    {
+        HostLog hl("set_test: joint factor steps");
+        if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint)) return rc;
+    }
     c->joint_ready = true;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->test_ready = true;
@@ -1448,10 +1519,10 @@ int build_grad_plan(dsmgp_ctx* c) {
         }
     size_t freeB = 0, totalB = 0;
     HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
-    if (xTot * sizeof(double) + (size_t(2) << 30) > freeB)
+    if (!c->pool_base && xTot * sizeof(double) + (size_t(2) << 30) > freeB)
         return fail(c, DSMGP_E_NOMEM, "gradients need " + std::to_string((xTot * 8) >> 20) + " MiB for L^-1, device has " +
                                           std::to_string(freeB >> 20) + " MiB free");
-    HIPCHK(c, hipMalloc(&c->arenaX, std::max<size_t>(1, xTot) * sizeof(double)));
+    if (int rc = arena_get(c, c->arenaX, xTot)) return rc;
     c->arenaX_count = xTot;
     auto Xt = [&](int l) { return c->arenaX + xoff[c->leaves[l].owner]; };
 
@@ -1535,7 +1606,8 @@ int build_grad_plan(dsmgp_ctx* c) {
         c->gred_off[nsteps] = (int)U.red.size();
         c->gtrsm_off[nsteps] = (int)trsm.size();
     }
-    if (U.max_slabs) HIPCHK(c, hipMalloc(&c->slabG, U.max_slabs * TB * TB * sizeof(double)));
+    if (U.max_slabs)
+        if (int rc = arena_get(c, c->slabG, U.max_slabs * TB * TB)) return rc;
     U.bind(c->slabG);
 
     // contraction tiles: every IsoSE leaf (COPY leaves too: their alpha is their own)
@@ -1746,10 +1818,31 @@ int dsmgp_work(dsmgp_ctx* c, double* alg_flops_update, int32_t* n_update_launche
 // Free every device buffer that scales with the leaf sizes (factors, inverse blocks, K_tn rows, L^-1, task lists),
 // keeping the training data, the leaf table, the sharing schedule and the hyper-parameters: the next fit rebuilds
 // them.  This is the "discard" half of the factor-and-discard streaming mode (hipabi.StreamingContext).
+int dsmgp_reserve(dsmgp_ctx* c, int64_t bytes) {
+    if (!c || bytes < 0) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_plan(c);
+    free_test(c);
+    if (c->pool_base) (void)hipFree(c->pool_base);
+    c->pool_base = nullptr;
+    c->pool_cap = c->pool_top = c->pool_mark_plan = 0;
+    if (bytes == 0) return 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, DSMGP_E_NOMEM, "cannot reserve " + std::to_string(bytes >> 20) + " MiB of device memory");
+    }
+    c->pool_base = static_cast<char*>(p);
+    c->pool_cap = (size_t)bytes;
+    return 0;
+}
+
 int dsmgp_release(dsmgp_ctx* c) {
     if (!c) return DSMGP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HostLog hl("release");
     free_plan(c);
     free_test(c);
     return 0;

@@ -41,6 +41,7 @@ SIGNATURES = {
     "dsmgp_timings": (C.c_int, [_ctx, _dp]),
     "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
     "dsmgp_release": (C.c_int, [_ctx]),
+    "dsmgp_reserve": (C.c_int, [_ctx, C.c_int64]),
     "dsmgp_estimate_bytes": (C.c_int64, [C.c_int32, _lp, _lp, C.c_int32, C.c_int32]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
@@ -216,6 +217,10 @@ class Context:
     def release(self):
         """Free the factors and everything else that scales with the leaf sizes (streaming mode)."""
         self._chk(self.lib.dsmgp_release(self.h))
+
+    def reserve(self, nbytes):
+        """One device pool for the large arenas of all following leaf tables (0 drops it)."""
+        self._chk(self.lib.dsmgp_reserve(self.h, int(nbytes)))
 
     def set_profile(self, level):
         """0/False: totals only; 1: update launches only; 2/True: every kernel category."""
@@ -475,6 +480,8 @@ class StreamingContext:
         self.groups = None
         self._res = None               # results of the last pass
         self.passes = 0
+        self._pool_bytes = 0
+        self._auto_budget = None
 
     def close(self):
         self.ctx.close()
@@ -530,7 +537,10 @@ class StreamingContext:
                     unit[j] = src[j]           # leaves sharing a factor travel together
         budget = self.budget
         if budget is None:
-            budget = int(self.ctx.memory()[1] * self.headroom)
+            if self._pool_bytes:               # the pool holds the memory: keep the budget it was sized for
+                budget = self._auto_budget
+            else:
+                budget = self._auto_budget = int(self.ctx.memory()[1] * self.headroom)
         units = {}
         for j in range(self.L):
             units.setdefault(int(unit[j]), []).append(j)
@@ -558,6 +568,12 @@ class StreamingContext:
                 groups.append(list(members))
                 loads.append(b)
         self.groups = [np.array(sorted(g)) for g in groups]
+        # one pool for all groups (several of them: the arenas would otherwise be allocated and freed per group,
+        # and the driver clears memory on allocation); sized for the fullest group plus the split-K workspaces
+        want = 0 if len(self.groups) < 2 else int(max(loads)) + (3 << 30)
+        if want != self._pool_bytes:
+            self.ctx.reserve(want)
+            self._pool_bytes = want
 
     def _pass(self):
         """One sweep over the groups; fills self._res."""
@@ -573,20 +589,30 @@ class StreamingContext:
         seconds, tpred = 0.0, 0.0
         tsum = {}
         flops, launches = 0.0, 0
+        import time as _time
+        host = {"set_leaves": 0.0, "set_sharing": 0.0, "set_test": 0.0, "fit": 0.0, "release": 0.0}   # wall seconds
+
+        def timed(key, fn, *a):
+            t0 = _time.perf_counter()
+            r = fn(*a)
+            host[key] += _time.perf_counter() - t0
+            return r
+
         for loc in self.groups:
             c = self.ctx
             lptr = np.concatenate([[0], np.cumsum(ptr[loc + 1] - ptr[loc])])
-            c.set_leaves(lptr, np.concatenate([idx[ptr[g]:ptr[g + 1]] for g in loc]), kid[loc], mean[loc])
+            timed("set_leaves", c.set_leaves, lptr, np.concatenate([idx[ptr[g]:ptr[g + 1]] for g in loc]), kid[loc], mean[loc])
             if op is None:
-                c.set_sharing(None, None, None)
+                timed("set_sharing", c.set_sharing, None, None, None)
             else:
                 g2l = {int(g): i for i, g in enumerate(loc)}
-                c.set_sharing(op[loc], np.array([g2l.get(int(src[g]), -1) for g in loc], dtype=np.int32), plen[loc])
+                timed("set_sharing", c.set_sharing, op[loc],
+                      np.array([g2l.get(int(src[g]), -1) for g in loc], dtype=np.int32), plen[loc])
             if self._test is not None:
                 Xt, rptr, ridx = self._test
                 tptr = np.concatenate([[0], np.cumsum(rptr[loc + 1] - rptr[loc])])
-                c.set_test(Xt, tptr, np.concatenate([ridx[rptr[g]:rptr[g + 1]] for g in loc]))
-            m, i, s = c.fit()
+                timed("set_test", c.set_test, Xt, tptr, np.concatenate([ridx[rptr[g]:rptr[g + 1]] for g in loc]))
+            m, i, s = timed("fit", c.fit)
             mll[loc], info[loc] = m, i
             seconds += s
             if self._test is not None:
@@ -605,8 +631,9 @@ class StreamingContext:
             f_, n_ = c.work()
             flops += f_
             launches += n_
-            c.release()
+            timed("release", c.release)
         self.passes += 1
+        self.host_seconds = host
         self._res = dict(mll=mll, info=info, mu=mu, var=var, grads=grads, seconds=seconds, tpred=tpred, timings=tsum,
                          work=(flops, launches), has_test=self._test is not None)
 

@@ -602,6 +602,22 @@ def _leaf_moments(model, xt, rc):
     return model.shard.gather_ragged(mu_l, counts), model.shard.gather_ragged(var_l, counts)
 
 
+def resident_test(model, xtest, tau=0.05):
+    """Register `xtest` as the resident test set BEFORE the next fit (no reference counterpart): that fit then
+    carries the test rows through its factorisation launches and the following `predict(model, xtest)` only
+    finishes the moments.  `predict` registers its argument by itself, which pays off from the second fit on;
+    this call is for evaluation loops that know their test set up front and for the streaming context, where a
+    prediction after an unprepared fit costs a second pass over all leaf groups."""
+    xt = np.asfortranarray(xtest, dtype=np.float64)
+    if xt.ndim == 1:
+        xt = xt.reshape(-1, 1)
+    model._upload(tau)
+    rc = _routing(model, xt)
+    if not rc["uploaded"]:
+        model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
+        rc["uploaded"] = True
+
+
 def predict(model, xtest):
     """`predict(model, x)` -> (mu, var) of length n_t (`src/common.jl:294-307`)."""
     if isinstance(model, GaussianProcess):

@@ -118,6 +118,12 @@ int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the
  * all its launches (2*K per lower-triangle element of every block column, unpadded sizes) and the
  * number of launches */
 int dsmgp_work(dsmgp_ctx* ctx, double* alg_flops_update, int32_t* n_update_launches);
+/* Reserve one device pool of `bytes` (0 = drop it): while a pool exists, the large arenas of every following leaf
+ * table (factors, inverse blocks, K_tn rows, L^-1 for gradients, split-K slabs) are carved out of it instead of being
+ * allocated and freed per table -- the driver clears memory on allocation, ~5 s per 230 GB.  Used by the
+ * factor-and-discard mode (hipabi.StreamingContext).  Drops the current leaf table's device state. */
+int dsmgp_reserve(dsmgp_ctx* ctx, int64_t bytes);
+
 /* streaming ("factor and discard"): drop every buffer that scales with the leaf sizes, keep data, leaf table,
  * schedule and hyper-parameters; the next dsmgp_fit rebuilds.  dsmgp_estimate_bytes sizes a leaf group beforehand. */
 int dsmgp_release(dsmgp_ctx* ctx);
