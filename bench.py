@@ -31,6 +31,9 @@ CONFIGS = {
     "dsmgp_n20k_d8": dict(N=20_000, D=8, K=3, V=4, M=200, depth=2),
     "dsmgp_n100k_d8_depth3": dict(N=100_000, D=8, K=3, V=4, M=200, depth=3),
     "dsmgp_n100k_d8_depth4": dict(N=100_000, D=8, K=3, V=4, M=200, depth=4),   # 18,461 leaves, n = 103..2668
+    # BASELINE config 5: kernel vector [IsoSE, IsoLinear], 288 leaves up to n = 83k, 2.8 TB of factors: every rank
+    # streams its leaf groups through HBM (hipabi.StreamingContext); ~112 s per step on one GPU
+    "dsmgp_n500k_d16_kvec": dict(N=500_000, D=16, K=3, V=4, M=500, depth=2, kvec=True, stream="auto"),
 }
 
 
@@ -39,8 +42,12 @@ def build_model(cfg, rank, world, device, n_sub=1):
     from deepstructuredmixtures_amd import dist as pdist, tree as ptree
     c = CONFIGS[cfg]
     X, y, Xt = dsm.regression_data(c["N"], c["D"], seed=20204)
-    model = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=dsm.IsoSE(np.log(0.3), 0.0),
-                           logNoise=np.log(0.1), seed=20204, fit_now=False, device=device, n_sub=n_sub)
+    kern = dsm.IsoSE(np.log(0.3), 0.0)
+    if c.get("kvec"):
+        kern = [kern, dsm.IsoLinear(np.log(1.5))]
+    model = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=kern,
+                           logNoise=np.log(0.1), seed=20204, fit_now=False, device=device, n_sub=n_sub,
+                           stream_budget=c.get("stream"))
     ptr, idx = ptree.route(model.root, Xt)
     if world > 1:
         op, src, _ = ptree.share_schedule(model.leaves, model.D, 0.05)
@@ -65,7 +72,7 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
                 continue
             lf = model.leaves[j]
             t0 = time.perf_counter()
-            g = ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(0, lf.kernel.loghyp()),
+            g = ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(lf.kernel.kind, lf.kernel.loghyp()),
                                     lf.logNoise, exact_dist=False).update_cholesky()
             g.mll()
             rows = idx[ptr[j]:ptr[j + 1]]
@@ -91,7 +98,7 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
     for j in sample[:3]:
         lf = model.leaves[j]
         rows = idx[ptr[j]:ptr[j + 1]]
-        mk = lambda: ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(0, lf.kernel.loghyp()),  # noqa: E731
+        mk = lambda: ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(lf.kernel.kind, lf.kernel.loghyp()),  # noqa: E731
                                          lf.logNoise, exact_dist=False)
         t0 = time.perf_counter()
         g = mk().update_cholesky()
@@ -246,7 +253,8 @@ def main():
             "value": per_step, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"buildDSMGP K=4 splits V=3 sum children M={c['M']} N={c['N']} D={c['D']} IsoSE "
+            "config": {"workload": f"buildDSMGP K=4 splits V=3 sum children M={c['M']} N={c['N']} D={c['D']} "
+                                   f"{'[IsoSE, IsoLinear]' if c.get('kvec') else 'IsoSE'} "
                                    f"depth {c['depth']}: {model.L} leaf GPs n={int(nobs.min())}..{int(nobs.max())}, "
                                    f"n_t={Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; "
                                    f"fit! (Gram+Cholesky+alpha+mll) + update! + predict",

@@ -4,6 +4,7 @@ The GP-expert path has no CPU fallback: `Context()` raises when the library or a
 """
 import ctypes as C
 import os
+import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -482,6 +483,7 @@ class StreamingContext:
         self.passes = 0
         self._pool_bytes = 0
         self._auto_budget = None
+        self.verbose = bool(os.environ.get("DSMGP_STREAM_VERBOSE"))   # one progress line per leaf group on stderr
 
     def close(self):
         self.ctx.close()
@@ -598,7 +600,11 @@ class StreamingContext:
             host[key] += _time.perf_counter() - t0
             return r
 
-        for loc in self.groups:
+        t_pass = _time.perf_counter()
+        for gi, loc in enumerate(self.groups):
+            if self.verbose:
+                print(f"# streaming pass {self.passes + 1}: group {gi + 1}/{len(self.groups)} ({len(loc)} leaves) at "
+                      f"{_time.perf_counter() - t_pass:.1f} s", file=sys.stderr, flush=True)
             c = self.ctx
             lptr = np.concatenate([[0], np.cumsum(ptr[loc + 1] - ptr[loc])])
             timed("set_leaves", c.set_leaves, lptr, np.concatenate([idx[ptr[g]:ptr[g + 1]] for g in loc]), kid[loc], mean[loc])
