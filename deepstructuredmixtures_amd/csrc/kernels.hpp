@@ -724,11 +724,14 @@ struct DiagTask {
 //   inverse blocks B(I,K), K <  I : stored in the unused upper triangle at rows 16K.., cols 16I..
 //                  B(I,I)         : spare block row 128..143, cols 16I..
 // Blocked right-looking Cholesky on 16x16 sub-blocks.  Per block step J:
-//   P0  wave 0: potrf + inverse of the 16x16 diagonal block, one column per lane, all in registers,
-//       cross-lane traffic by v_readlane broadcasts (no LDS, no barrier inside)
+//   P0  wave 0: potrf + inverse of the 16x16 diagonal block in registers (potrf_inv16: lanes 0..15 a column of
+//       the block, lanes 16..31 a column of the identity), cross-lane traffic by v_readlane broadcasts (no LDS, no
+//       barrier inside); for J > 0 it runs inside P2 of step J-1, right after wave 0 has updated that block
 //   P1  all waves: panel S(I,J) = S(I,J) Linv^T (I > J) and B(J,K) = Linv B(J,K) (K < J)        [MFMA]
-//   P2  all waves: trailing S(I,K) -= S(I,J) S(K,J)^T (I >= K > J), B(I,K) -= S(I,J) B(J,K)     [MFMA]
+//   P2  waves 1..3: trailing S(I,K) -= S(I,J) S(K,J)^T (I >= K > J), B(I,K) -= S(I,J) B(J,K)    [MFMA, two
+//       independent 16x16 products in flight per wave]
 // B accumulates L^-1 by forward substitution on the identity, interleaved with the factorisation.
+// tools/probe_diag.py prints the time of every phase (in-kernel stamps of chol_diag_stamp_kernel).
 constexpr int DLD = 144;
 constexpr int DIAG_LDS_BYTES = (TB * DLD + 256 + TB) * (int)sizeof(double);   // image + Winv + rhs block
 

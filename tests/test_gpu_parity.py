@@ -218,6 +218,16 @@ def test_resident_test_rows_riding_through_fit_equal_the_standalone_predict():
         mu2, v2 = dsm.predict(m, xt)
         assert np.array_equal(mu2, mu0) and np.array_equal(v2, v0)   # same path as the first time: same bits
         m.ctx.set_joint(True)
+    # a test set announced before the very first fit rides along from the start
+    m3 = dsm.buildDSMGP(X, y, 3, 4, M=100, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=8, fit_now=False)
+    dsm.resident_test(m3, Xt)
+    m3.ctx.set_profile(True)
+    dsm.fit(m3)
+    mu3, v3 = dsm.predict(m3, Xt)
+    t = m3.ctx.timings()
+    assert t["predict_update"] == 0.0 and t["predict_trsm"] == 0.0
+    mref, vref = dsm.predict(cases[0](), Xt)
+    assert np.allclose(mu3, mref, rtol=1e-11, atol=1e-12) and np.allclose(v3, vref, rtol=1e-10, atol=1e-13)
 
 
 def test_prefix_continue_equals_full_factorisation(ctx):
