@@ -133,6 +133,25 @@ def test_single_gp_vs_oracle(ctx, n, D, kind):
     assert np.allclose(var, vo, rtol=RTOL, atol=1e-10)
 
 
+@pytest.mark.parametrize("n,D,logl,lognoise", [(128, 2, np.log(0.3), np.log(0.1)), (777, 3, np.log(0.5), np.log(0.01)),
+                                               (2000, 2, np.log(0.8), np.log(0.003))])
+def test_cholesky_backward_error(ctx, n, D, logl, lognoise):
+    """||K_y - L L^T||_F <= a few ulps of ||K_y||_F with K_y from the device's own Gram kernel: only the factorisation
+    (reciprocal-based pivots of the register-level potrf, MFMA trailing updates, split-K) is measured; cond(K_y) up to 1e8."""
+    rng = np.random.default_rng(n)
+    X = np.asfortranarray(rng.random((n, D)))
+    ctx.set_train(X, rng.standard_normal(n))
+    ctx.set_leaves(np.array([0, n]), np.arange(n), [0], [0.0])
+    ctx.set_sharing(None, None, None)
+    ctx.set_hyper(0, 0, [logl, 0.0, lognoise])
+    _, info, _ = ctx.fit()
+    assert info[0] == 0
+    F, _ = ctx.download_factor(0, n)
+    L = np.tril(F)
+    K = ctx.kernel_matrix(0, X, X) + (np.exp(2 * lognoise) + 1e-8) * np.eye(n)
+    assert np.linalg.norm(K - L @ L.T) <= 4e-15 * np.linalg.norm(K)
+
+
 def test_not_positive_definite_is_reported(ctx):
     """LAPACK-style info: a rank-1 linear-kernel Gram of size 1e16 leaves only rounding noise (+-1) in the
     Schur complement, far above noise + eps, so some pivot goes non-positive -- in LAPACK and here."""
