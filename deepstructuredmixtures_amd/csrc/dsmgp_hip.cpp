@@ -2153,4 +2153,58 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     return 0;
 }
 
+// Host-only helper of the sharing schedule (src/fit.jl:12-39,78-86) for leaf tables too large for the dense L x L
+// overlap matrix: for every leaf j, main[j] = argmax_i D[i,j] D[j,i] with D[a,b] = 1 - (|a| - |a n b|) / |a| for
+// overlapping a != b and 0 otherwise (first maximum; 0 when the leaf overlaps nothing, like argmax of a zero column),
+// and c_main[j] = |j n main[j]|.  Intersection counts come from an inverted index (point -> leaves), one leaf at a
+// time: O(sum_p deg(p)^2) work, O(L + sum n) memory, no L x L array.  No device is touched.
+int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx, int64_t N, int64_t* main_out,
+                       int64_t* c_main_out) {
+    if (L < 0 || !obs_ptr || (!obs_idx && L > 0 && obs_ptr[L] > 0) || N <= 0 || !main_out || !c_main_out) return DSMGP_E_ARG;
+    const int64_t total = L ? obs_ptr[L] : 0;
+    for (int64_t e = 0; e < total; ++e)
+        if (obs_idx[e] < 0 || obs_idx[e] >= N) return DSMGP_E_ARG;
+    // inverted index: leaves of every point, ascending leaf order
+    std::vector<int64_t> pptr(N + 1, 0);
+    for (int64_t e = 0; e < total; ++e) pptr[obs_idx[e] + 1]++;
+    for (int64_t p = 0; p < N; ++p) pptr[p + 1] += pptr[p];
+    std::vector<int32_t> pleaf(total);
+    {
+        std::vector<int64_t> fill(pptr.begin(), pptr.end() - 1);
+        for (int32_t l = 0; l < L; ++l)
+            for (int64_t e = obs_ptr[l]; e < obs_ptr[l + 1]; ++e) pleaf[fill[obs_idx[e]]++] = l;
+    }
+    std::vector<int32_t> cnt(L, 0), touched;
+    for (int32_t j = 0; j < L; ++j) {
+        touched.clear();
+        for (int64_t e = obs_ptr[j]; e < obs_ptr[j + 1]; ++e) {
+            const int64_t p = obs_idx[e];
+            for (int64_t q = pptr[p]; q < pptr[p + 1]; ++q) {
+                const int32_t l = pleaf[q];
+                if (cnt[l]++ == 0) touched.push_back(l);
+            }
+        }
+        const double nj = (double)(obs_ptr[j + 1] - obs_ptr[j]);
+        double best = 0.0;
+        int64_t bi = 0, bc = 0;
+        for (int32_t l : touched) {
+            const int32_t c = cnt[l];
+            cnt[l] = 0;
+            if (l == j) continue;
+            const double nl = (double)(obs_ptr[l + 1] - obs_ptr[l]);
+            const double d_jl = 1.0 - (nj - (double)c) / nj;      // D[j, l]
+            const double d_lj = 1.0 - (nl - (double)c) / nl;      // D[l, j]
+            const double prod = d_lj * d_jl;
+            if (prod > best || (prod == best && best > 0.0 && l < bi)) {
+                best = prod;
+                bi = l;
+                bc = c;
+            }
+        }
+        main_out[j] = best > 0.0 ? bi : 0;
+        c_main_out[j] = best > 0.0 ? bc : 0;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -43,6 +43,7 @@ SIGNATURES = {
     "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
     "dsmgp_release": (C.c_int, [_ctx]),
     "dsmgp_reserve": (C.c_int, [_ctx, C.c_int64]),
+    "dsmgp_overlap_main": (C.c_int, [C.c_int32, _lp, _lp, C.c_int64, _lp, _lp]),
     "dsmgp_estimate_bytes": (C.c_int64, [C.c_int32, _lp, _lp, C.c_int32, C.c_int32]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
@@ -456,6 +457,22 @@ def estimate_bytes(n, n_test, D, with_gradients=False):
     nt = None if n_test is None else np.ascontiguousarray(n_test, dtype=np.int64)
     return int(lib.dsmgp_estimate_bytes(len(n), n.ctypes.data_as(_lp), None if nt is None else nt.ctypes.data_as(_lp),
                                         int(D), 1 if with_gradients else 0))
+
+
+def overlap_main(obs_ptr, obs_idx, N):
+    """(main, c_main) of the sharing schedule for a leaf table in CSR form (host routine of the library, no device):
+    main[j] = argmax_i D[i,j] D[j,i], c_main[j] = |obs_j n obs_main[j]|."""
+    lib = load_library()
+    ptr = np.ascontiguousarray(obs_ptr, dtype=np.int64)
+    idx = np.ascontiguousarray(obs_idx, dtype=np.int64)
+    L = ptr.size - 1
+    main = np.zeros(L, dtype=np.int64)
+    cm = np.zeros(L, dtype=np.int64)
+    rc = lib.dsmgp_overlap_main(L, ptr.ctypes.data_as(_lp), idx.ctypes.data_as(_lp), int(N), main.ctypes.data_as(_lp),
+                                cm.ctypes.data_as(_lp))
+    if rc != 0:
+        raise DsmgpError(rc, "dsmgp_overlap_main: bad leaf table")
+    return main, cm
 
 
 class StreamingContext:

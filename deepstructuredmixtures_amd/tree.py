@@ -245,12 +245,22 @@ class LeafOverlap:
     reference and its O(L^2) bitset loops are what SURVEY 8(f).1 asks to remove."""
 
     def __init__(self, leaves):
-        M, self.nobs = _membership(leaves)
-        C = (M @ M.T).tocsr()
-        C.sort_indices()
-        self.C = C
+        self._leaves = leaves
+        self.nobs = np.array([lf.nobs for lf in leaves], dtype=np.int64)
         self.shape = (len(leaves), len(leaves))
+        self._C = None
         self._pairs = None
+
+    @property
+    def C(self):
+        """Sparse intersection counts M M^T (built on demand: the schedule itself uses the library's inverted-index
+        routine and never needs them)."""
+        if self._C is None:
+            M, _ = _membership(self._leaves)
+            C = (M @ M.T).tocsr()
+            C.sort_indices()
+            self._C = C
+        return self._C
 
     def todense(self):
         C = np.asarray(self.C.todense(), dtype=np.float64)
@@ -259,10 +269,23 @@ class LeafOverlap:
         np.fill_diagonal(Dm, 0.0)
         return Dm
 
-    def main_pairs(self):
+    def main_pairs(self, native=True):
         """For every leaf j: main[j] = argmax_i D[i,j] D[j,i] (first maximum, 0 when the leaf overlaps nothing, like
         argmax of the dense all-zero column) and the two factors D[main,j], D[j,main]."""
         if self._pairs is not None:
+            return self._pairs
+        if native:
+            # host routine of libdsmgp_hip.so (inverted index, one leaf at a time; include/dsmgp_hip.h)
+            from . import hipabi
+            ptr = np.concatenate([[0], np.cumsum(self.nobs)])
+            idx = np.concatenate([lf.obs for lf in self._leaves])
+            main, c = hipabi.overlap_main(ptr, idx, int(idx.max()) + 1)
+            n = self.nobs.astype(np.float64)
+            cf = c.astype(np.float64)
+            has = c > 0
+            d_ij = np.where(has, 1.0 - (n[main] - cf) / n[main], 0.0)      # D[main, j]
+            d_ji = np.where(has, 1.0 - (n - cf) / n, 0.0)                  # D[j, main]
+            self._pairs = (main, d_ij, d_ji)
             return self._pairs
         C, n = self.C, self.nobs.astype(np.float64)
         L = self.shape[0]

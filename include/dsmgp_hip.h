@@ -152,6 +152,13 @@ int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, in
  * (block product, LDS reads, potrf_inv16 in registers, LDS writes) */
 int dsmgp_probe_diag(dsmgp_ctx* ctx, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us);
 
+/* Host-only (no device): per leaf j the "main" leaf of the sharing schedule of src/fit.jl:78-86,
+ * main[j] = argmax_i D[i,j] D[j,i] over the overlap matrix D of src/fit.jl:12-39 (first maximum, 0 if leaf j overlaps
+ * no other leaf), and c_main[j] = number of observations leaf j shares with it -- computed from an inverted index
+ * instead of the dense L x L matrix (18k leaves at depth 4).  Leaves as in dsmgp_set_leaves; one kernel id. */
+int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx, int64_t N, int64_t* main_out,
+                       int64_t* c_main_out);
+
 #ifdef __cplusplus
 }
 #endif

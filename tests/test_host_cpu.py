@@ -286,6 +286,9 @@ def test_sparse_overlap_and_level_order_tree_passes_match_the_recursions():
         if not isinstance(c["kernel"], list):
             ov = ptree.LeafOverlap(m.leaves)
             assert np.array_equal(ov.todense(), m.D)
+            # the library's inverted-index routine (dsmgp_overlap_main) == the sparse-product evaluation, bit for bit
+            nat, ref = ov.main_pairs(native=True), ptree.LeafOverlap(m.leaves).main_pairs(native=False)
+            assert all(np.array_equal(u, v) for u, v in zip(nat, ref))
             for tau in (0.05, 0.0):
                 a = ptree.share_schedule(m.leaves, m.D, tau)
                 b = ptree.share_schedule(m.leaves, ov, tau)
