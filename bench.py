@@ -55,6 +55,14 @@ def build_model(cfg, rank, world, device, n_sub=1):
     return model, X, y, Xt, ptr, idx
 
 
+def default_sub(world):
+    """Concurrent contexts per GPU (hipabi.MultiContext): with the leaves of a multi-GPU shard split over 2-3 contexts
+    driven from host threads, one context's dependent chain of diagonal block / panel solve / reduce launches runs
+    under another's update launches (measured on one GPU with --simulate-shard: 8 ranks 0.0651 -> 0.0614 s with 3,
+    4 ranks 0.1159 -> 0.1129 s with 2, 2 ranks 0.2176 -> 0.2137 s with 2; nothing to gain on a full GPU)."""
+    return 3 if world >= 8 else (2 if world >= 2 else 1)
+
+
 def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
     """Oracle ("port" of the reference's per-leaf arithmetic, LAPACK via SciPy) on a bounded sample of
     the same workload: whole leaves, lean form (one potrf per leaf, diag-only variance), timed on the
@@ -158,7 +166,7 @@ def main():
     if args.simulate_shard:
         from deepstructuredmixtures_amd import dist as pdist
         r_, w_ = map(int, args.simulate_shard.split("/"))
-        n_sub = args.sub if args.sub is not None else 1
+        n_sub = args.sub if args.sub is not None else default_sub(w_)
         model, X, y, Xt, ptr, idx = build_model(args.config, r_, w_, local_rank, n_sub)
         own = model.shard.owner
         loc = np.flatnonzero(own == r_)
@@ -181,7 +189,7 @@ def main():
         n3 = np.array([lf.nobs for lf in model.leaves], dtype=float) ** 3
         print(f"# shard {r_}/{w_}: {loc.size} leaves, {n3[loc].sum() / n3.sum():.3f} of the Cholesky flops", file=sys.stderr)
     else:
-        n_sub = args.sub if args.sub is not None else 1
+        n_sub = args.sub if args.sub is not None else default_sub(world)
         model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
     ctx = model.ctx
     ctx.set_profile(0 if args.no_profile else 1)   # timed region: events around the update launches only
@@ -258,7 +266,8 @@ def main():
                                    f"depth {c['depth']}: {model.L} leaf GPs n={int(nobs.min())}..{int(nobs.max())}, "
                                    f"n_t={Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; "
                                    f"fit! (Gram+Cholesky+alpha+mll) + update! + predict",
-                       "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and (mu, var)"},
+                       "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and (mu, var)"
+                                      + (f"; {n_sub} concurrent contexts per GPU" if n_sub > 1 else "")},
             "matrix_tflops_fit_predict": matrix_flops_total / ((cats.get("total_fit", 0.0) + cats.get("total_predict", 0.0))
                                                                / args.steps) / 1e12 if world == 1 else None,
             "device_seconds_per_step": {k: v / args.steps for k, v in cats.items() if v > 0},
