@@ -296,6 +296,7 @@ class MultiContext:
         self._test = None
         self._test_dirty = False
         self.part = None
+        self.act = self.subs          # contexts that hold leaves (all of them unless there are fewer leaf groups)
 
     def close(self):
         for s in self.subs:
@@ -306,7 +307,7 @@ class MultiContext:
         return self.subs[0].device_name()
 
     def _each(self, fn):
-        return list(self.pool.map(fn, self.subs))
+        return list(self.pool.map(fn, self.act))
 
     def set_train(self, X, y):
         for s in self.subs:
@@ -364,8 +365,10 @@ class MultiContext:
             return
         ptr, idx, kid, mean = self._leaves
         op, src, plen = self._sharing
-        self.part = self._partition()
-        for s, loc in zip(self.subs, self.part):
+        parts = self._partition()
+        self.act = [s for s, loc in zip(self.subs, parts) if len(loc)]
+        self.part = [loc for loc in parts if len(loc)]
+        for s, loc in zip(self.act, self.part):
             lptr = np.concatenate([[0], np.cumsum(ptr[loc + 1] - ptr[loc])])
             lidx = np.concatenate([idx[ptr[g]:ptr[g + 1]] for g in loc]) if len(loc) else np.zeros(0, np.int64)
             s.set_leaves(lptr, lidx, kid[loc], mean[loc])
@@ -381,7 +384,7 @@ class MultiContext:
         if not self._test_dirty:
             return
         Xt, rptr, ridx = self._test
-        for s, loc in zip(self.subs, self.part):
+        for s, loc in zip(self.act, self.part):
             lptr = np.concatenate([[0], np.cumsum(rptr[loc + 1] - rptr[loc])])
             lidx = np.concatenate([ridx[rptr[g]:rptr[g + 1]] for g in loc]) if len(loc) else np.zeros(0, np.int64)
             s.set_test(Xt, lptr, lidx)
@@ -415,7 +418,7 @@ class MultiContext:
         _, rptr, _ = self._test
         mu = np.empty(self.route_total)
         var = np.empty(self.route_total)
-        for s, loc in zip(self.subs, self.part):
+        for s, loc in zip(self.act, self.part):
             m, v = s.predict_fetch()
             pos = 0
             for g in loc:
@@ -439,11 +442,11 @@ class MultiContext:
         return g
 
     def timings(self):
-        ts = [s.timings() for s in self.subs]
+        ts = [s.timings() for s in self.act]
         return {k: max(t[k] for t in ts) for k in ts[0]}
 
     def work(self):
-        ws = [s.work() for s in self.subs]
+        ws = [s.work() for s in self.act]
         return sum(w[0] for w in ws), max(w[1] for w in ws)
 
     def probe_f64_mfma(self):

@@ -582,6 +582,17 @@ def test_concurrent_sub_contexts_give_the_single_context_result():
     dsm.updategradients(m1)
     dsm.updategradients(m2)
     assert np.allclose(dsm.grad_mll(m1), dsm.grad_mll(m2), rtol=1e-9, atol=1e-10)
+    # more contexts than leaves: the spare ones stay idle
+    g = dsm.GaussianProcess(X[:500], y[:500], kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1))
+    mc = hipabi.MultiContext(0, 3)
+    mc.set_train(X[:500], y[:500])
+    mc.set_leaves(np.array([0, 500]), np.arange(500), [0], [float(np.mean(y[:500]))])
+    mc.set_hyper(0, 0, [np.log(0.3), 0.0, np.log(0.1)])
+    mll, info, _ = mc.fit()
+    assert len(mc.act) == 1 and info[0] == 0
+    dsm.update_cholesky(g)
+    assert abs(mll[0] - dsm.mll(g)) <= 1e-10 * abs(mll[0])
+    mc.close()
 
 
 def test_streaming_factor_and_discard_equals_resident():
