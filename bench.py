@@ -177,6 +177,11 @@ def main():
                 out[self.local] = v
                 return out
 
+            def gather_leaf_columns(self, v):
+                out = np.zeros((self.owner.size, v.shape[1]))
+                out[self.local] = v
+                return out
+
             def gather_ragged(self, flat, counts):
                 out = np.ones(int(np.sum(counts)))
                 p = np.concatenate([[0], np.cumsum(counts)])

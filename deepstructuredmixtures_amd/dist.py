@@ -101,6 +101,28 @@ class Shard:
             out[idx] = parts[r][: idx.size]
         return out
 
+    def gather_leaf_columns(self, local_cols):
+        """Several per-leaf quantities in ONE collective: local_cols is (n_local_leaves, k); returns (L, k)."""
+        local_cols = np.ascontiguousarray(local_cols, dtype=np.float64)
+        k = local_cols.shape[1]
+        if self.world == 1:
+            return local_cols.copy()
+        counts = np.bincount(self.owner, minlength=self.world)
+        parts = self._all_gather_padded(local_cols.reshape(-1), int(counts.max()) * k)
+        out = np.empty((self.owner.size, k))
+        for r in range(self.world):
+            idx = np.flatnonzero(self.owner == r)
+            out[idx] = parts[r][: idx.size * k].reshape(idx.size, k)
+        return out
+
+    def gather_ragged_pair(self, a_flat, b_flat, counts):
+        """gather_ragged of two vectors with the same ragged layout (mu and var) in ONE collective."""
+        if self.world == 1:
+            return np.asarray(a_flat, dtype=np.float64).copy(), np.asarray(b_flat, dtype=np.float64).copy()
+        both = self.gather_ragged(np.stack([a_flat, b_flat], axis=1).reshape(-1), 2 * np.asarray(counts, dtype=np.int64))
+        both = both.reshape(-1, 2)
+        return np.ascontiguousarray(both[:, 0]), np.ascontiguousarray(both[:, 1])
+
     def gather_ragged(self, local_flat, counts):
         """local_flat = concatenation over this rank's leaves (in leaf order) of counts[leaf] values;
         returns the concatenation over ALL leaves in leaf order."""

@@ -334,8 +334,9 @@ def _fit(model, tau):
     model._upload(tau)
     model._push_hyper()
     mll_loc, info_loc, sec = model.ctx.fit()
-    model.leaf_mll = model.shard.gather_leaf_values(mll_loc)
-    model.leaf_info = model.shard.gather_leaf_values(info_loc.astype(np.float64)).astype(np.int32)
+    both = model.shard.gather_leaf_columns(np.stack([mll_loc, info_loc.astype(np.float64)], axis=1))   # one collective
+    model.leaf_mll = np.ascontiguousarray(both[:, 0])
+    model.leaf_info = both[:, 1].astype(np.int32)
     model.last_fit_seconds = sec
     bad = np.flatnonzero(model.leaf_info != 0)
     if bad.size:
@@ -466,7 +467,7 @@ def updategradients(model):
     target = model.model if isinstance(model, GaussianProcess) else model
     stride = max(lf.kernel.nparams() + 1 for lf in target.leaves)
     g_loc = target.ctx.gradients(stride)
-    g = np.stack([target.shard.gather_leaf_values(g_loc[:, j]) for j in range(stride)], axis=1)
+    g = target.shard.gather_leaf_columns(g_loc[:, :stride])
     for lf, row in zip(target.leaves, g):
         n = lf.kernel.nparams()
         if lf.kernel.kind == KIND_ISO_LINEAR:
@@ -599,7 +600,7 @@ def _leaf_moments(model, xt, rc):
     model.last_predict_seconds = model.ctx.predict_run()
     mu_l, var_l = model.ctx.predict_fetch()
     counts = np.diff(rc["ptr"])
-    return model.shard.gather_ragged(mu_l, counts), model.shard.gather_ragged(var_l, counts)
+    return model.shard.gather_ragged_pair(mu_l, var_l, counts)
 
 
 def resident_test(model, xtest, tau=0.05):
