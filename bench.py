@@ -198,6 +198,9 @@ def main():
         model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
     ctx = model.ctx
     ctx.set_profile(0 if args.no_profile else 1)   # timed region: events around the update launches only
+    # the evaluation loop knows its test set: register it before the first fit, so that warm-up and timed steps run
+    # the same launches (and a process-wide rocprofv3 --stats average of the update kernel is the timed-region average)
+    dsm.resident_test(model, Xt)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -253,7 +256,8 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "tile_gemm_kernel_v2 (update launches of the factorisation, test rows riding along)",
+                "kernel": "tile_gemm_kernel_v2<false, 0, 0> (update launches of the factorisation, test rows riding along; "
+                          "panel solves run as <false, 0, 1>, split-K reduces as tile_reduce_kernel)",
                 "avg_launch_ms": avg_launch * 1e3, "launches_per_step": upd_launches // args.steps,
                 "alg_flops_per_step": alg_flops}
     nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)

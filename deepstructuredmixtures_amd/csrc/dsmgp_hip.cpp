@@ -858,7 +858,7 @@ int build_plan(dsmgp_ctx* c) {
     return 0;
 }
 
-void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n) {
+void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */) {
     if (c->tile_variant >= 100) {   // ablation builds, micro-benchmark only
         switch (c->tile_variant - 100) {
             case 1: tile_gemm_kernel_v2<false, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
@@ -873,7 +873,8 @@ void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n) {
         return;
     }
     if (c->tile_variant == 3) tile_gemm_kernel_v3<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
-    else tile_gemm_kernel_v2<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    else if (role == 1) tile_gemm_kernel_v2<false, 0, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    else tile_gemm_kernel_v2<false, 0, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr);
 }
 
 struct PhaseTimer {
@@ -925,10 +926,14 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         if (nu > 0) {
             pt.begin(1);
             launch_tiles(c, S.upd.p + S.upd_off[k], nu);
-            const int nr = S.red_off[k + 1] - S.red_off[k];
-            if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
             pt.note(k, nu, S.step_tiles[k]);
             pt.end();
+            const int nr = S.red_off[k + 1] - S.red_off[k];
+            if (nr > 0) {
+                pt.begin(13);
+                tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
+                pt.end();
+            }
             if (count_launches) c->n_update_launches++;
         }
         const int nd = S.diag_off[k + 1] - S.diag_off[k];
@@ -941,7 +946,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
         if (ns > 0) {
             pt.begin(3);
-            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns);
+            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns, 1);
             pt.note(k, ns, 0);
             pt.end();
         }
@@ -1148,6 +1153,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     const int L = c->L;
     for (int i = 0; i < 6; ++i) c->timings[i] = 0.0;
     c->timings[11] = 0.0;
+    c->timings[13] = 0.0;
     c->n_update_launches = 0;
     PhaseTimer pt(c);
     hipEvent_t t0, t1;
@@ -1454,7 +1460,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
                 const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
                 if (ns > 0) {
                     pt.begin(8);
-                    launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns);
+                    launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns, 1);
                     pt.end();
                 }
             }
@@ -1683,7 +1689,7 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
             if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(c->gred.p + c->gred_off[k]);
         }
         const int ns = c->gtrsm_off[k + 1] - c->gtrsm_off[k];
-        if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns);
+        if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns, 1);
     }
     double* pfrob = c->d_gpart;
     double* pdot = pfrob + c->gfrob.count;

@@ -10,9 +10,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 
-N_TIMINGS = 13
+N_TIMINGS = 14
 TIMING_NAMES = ("gram", "chol_update", "chol_diag", "chol_trsm", "solve", "mll", "predict_gram",
-                "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict")
+                "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -46,9 +46,10 @@ typedef struct dsmgp_ctx dsmgp_ctx;
 #define DSMGP_E_NOMEM      -4
 #define DSMGP_E_NODEVICE   -5
 
-/* number of doubles dsmgp_timings() fills: gram, chol_update, chol_diag, chol_trsm, solve, mll,
- * predict_gram, predict_update, predict_trsm, predict_var, gradients, total_fit, total_predict */
-#define DSMGP_N_TIMINGS 13
+/* number of doubles dsmgp_timings() fills: gram, chol_update (the update launches of the tile kernel alone),
+ * chol_diag, chol_trsm, solve, mll, predict_gram, predict_update, predict_trsm, predict_var, gradients, total_fit,
+ * total_predict, chol_reduce (split-K reduce launches of the factorisation) */
+#define DSMGP_N_TIMINGS 14
 
 /* ---- context ---------------------------------------------------------------------------------- */
 int dsmgp_create(int32_t device_id, dsmgp_ctx** out);
