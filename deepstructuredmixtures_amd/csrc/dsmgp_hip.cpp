@@ -873,6 +873,7 @@ void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 
         return;
     }
     if (c->tile_variant == 3) tile_gemm_kernel_v3<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    else if (c->tile_variant == 4) tile_gemm_kernel_v2<false, 0, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr);
     else if (role == 1) tile_gemm_kernel_v2<false, 0, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr);
     else tile_gemm_kernel_v2<false, 0, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr);
 }

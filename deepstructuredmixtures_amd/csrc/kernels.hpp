@@ -273,7 +273,9 @@ constexpr int NRING = 4;
 // ABL is an ablation mask for tools/bench_tile.py only (results are wrong when it is non-zero):
 //   1 = no global loads / LDS writes in the loop, 2 = no barrier in the loop, 4 = no fragment reads in the loop,
 //   8 = global loads kept but their LDS writes dropped
-template <bool STAMP, int ABL>
+// SETS = number of register sets the global loads rotate through: 2 = a chunk's loads have one chunk time to arrive
+// before their LDS write, 3 = two chunk times (16 more VGPRs).
+template <bool STAMP, int ABL, int SETS = 2>
 __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4][4], double (*sA)[KC2 * LDP],
                                                  double (*sB)[KC2 * LDP], unsigned long long* __restrict__ stamps) {
     const int t = threadIdx.x;
@@ -292,7 +294,7 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     const double* gA = tk.A + srow + (size_t)(tk.k0 + scol) * tk.lda;
     const double* gB = tk.B + srow + (size_t)(tk.k0 + scol) * tk.ldb;
     const int sOff = scol * LDP + srow;
-    d2 ra0[2], rb0[2], ra1[2], rb1[2];
+    d2 ra0[2], rb0[2], ra1[2], rb1[2], ra2[2], rb2[2];
 
 #define GLOAD(RA, RB, CH)                                                                        \
     do {                                                                                         \
@@ -329,13 +331,24 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     // prologue: chunks 0..2 into the ring with the loads overlapped (two memory latencies, not three),
     // chunk 3 in flight in set 1
     if (nch > 0) {
-        GLOAD(ra0, rb0, 0);
-        GLOAD(ra1, rb1, min(1, nch - 1));
-        SWRITE(ra0, rb0, 0);
-        GLOAD(ra0, rb0, min(2, nch - 1));
-        SWRITE(ra1, rb1, 1);
-        GLOAD(ra1, rb1, min(3, nch - 1));
-        SWRITE(ra0, rb0, 2);
+        if (SETS == 2) {
+            GLOAD(ra0, rb0, 0);
+            GLOAD(ra1, rb1, min(1, nch - 1));
+            SWRITE(ra0, rb0, 0);
+            GLOAD(ra0, rb0, min(2, nch - 1));
+            SWRITE(ra1, rb1, 1);
+            GLOAD(ra1, rb1, min(3, nch - 1));
+            SWRITE(ra0, rb0, 2);
+        } else {   // ring <- chunks 0..2, set 1 <- chunk 3, set 2 <- chunk 4 (set 0 takes chunk 5 in the first chunk)
+            GLOAD(ra0, rb0, 0);
+            GLOAD(ra1, rb1, min(1, nch - 1));
+            GLOAD(ra2, rb2, min(2, nch - 1));
+            SWRITE(ra0, rb0, 0);
+            SWRITE(ra1, rb1, 1);
+            GLOAD(ra1, rb1, min(3, nch - 1));
+            SWRITE(ra2, rb2, 2);
+            GLOAD(ra2, rb2, min(4, nch - 1));
+        }
     }
     __syncthreads();
 
@@ -368,7 +381,7 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
         const int buf_ = c_ & (NRING - 1);                                                       \
         if (STAMP) { __builtin_amdgcn_sched_barrier(0); ta = stamp_now(); }                      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (!(ABL & 1)) GLOAD(LRA, LRB, min(c_ + 4, nch - 1)); /* clamped: static vmcnt counts */ \
+        if (!(ABL & 1)) GLOAD(LRA, LRB, min(c_ + 2 + SETS, nch - 1)); /* clamped: static vmcnt counts */ \
         if (!(ABL & 4)) FRAGS(fa1, fb1, buf_, 1);                                                \
         MFMA16(fa0, fb0);                                                                        \
         if (!ABL) INTERLEAVE(0x020, 0x100);                                                      \
@@ -385,11 +398,21 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     } while (0)
 
     int c = 0;
-    for (; c + 1 < nch; c += 2) {
-        CHUNK(c, ra0, rb0, ra1, rb1);
-        CHUNK(c + 1, ra1, rb1, ra0, rb0);
+    if (SETS == 2) {
+        for (; c + 1 < nch; c += 2) {
+            CHUNK(c, ra0, rb0, ra1, rb1);
+            CHUNK(c + 1, ra1, rb1, ra0, rb0);
+        }
+        if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
+    } else {   // chunk c loads into set c % 3 (chunk c+5) and writes set (c+1) % 3 (chunk c+3, loaded two chunks ago)
+        for (; c + 2 < nch; c += 3) {
+            CHUNK(c, ra0, rb0, ra1, rb1);
+            CHUNK(c + 1, ra1, rb1, ra2, rb2);
+            CHUNK(c + 2, ra2, rb2, ra0, rb0);
+        }
+        if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
+        if (c + 1 < nch) CHUNK(c + 1, ra1, rb1, ra2, rb2);
     }
-    if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
 #undef CHUNK
 #undef INTERLEAVE
 #undef MFMA16
@@ -548,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
     __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
     const TileTask tk = tasks[blockIdx.x];
     d4 acc[4][4];
-    gemm_mainloop_v2<STAMP, ABL>(tk, acc, sA, sB, stamps);
+    gemm_mainloop_v2<STAMP, ABL, (ROLE >= 2 ? 3 : 2)>(tk, acc, sA, sB, stamps);   // ROLE 2: three load sets (DSMGP_TILE_V=4)
     tile_epilogue(tk, acc, &sA[0][0]);
 }
 
