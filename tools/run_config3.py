@@ -1,0 +1,30 @@
+"""BASELINE configs 2 and 3 timed on one GPU: single exact GP N=4096 D=4 IsoSE, and buildPoE K=8 M=200 N=50k D=8 ArdSE
+(128 independent experts).  fit! + predict per step after warm-up (diagnostic; parity is in tests/test_gpu_parity.py)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deepstructuredmixtures_amd as dsm
+
+def timeit(f, n=5):
+    f(); f()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        f()
+    return (time.perf_counter() - t0) / n
+
+X, y, Xt = dsm.regression_data(4096, 4, seed=20202)
+gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1))
+def step2():
+    dsm.update_cholesky(gp); return dsm.prediction(gp, Xt)
+print(f"config 2 (single GP n=4096, n_t={Xt.shape[0]}): {timeit(step2) * 1e3:.2f} ms per update_cholesky! + prediction")
+
+X, y, Xt = dsm.regression_data(50_000, 8, seed=20203)
+m = dsm.buildPoE(X, y, 8, M=200, kernel=dsm.ArdSE(np.log(np.full(8, 0.3)), 0.0), logNoise=np.log(0.1),
+                 meanFun=dsm.ConstMean(float(np.mean(y))), seed=20203)
+n = np.array([lf.nobs for lf in m.leaves])
+def step3():
+    dsm.fit(m); return dsm.predict(m, Xt)
+t = timeit(step3)
+m.ctx.set_profile(2); step3(); tm = m.ctx.timings()
+print(f"config 3 (PoE ArdSE, {m.L} experts n={n.min()}..{n.max()}, n_t={Xt.shape[0]} x {m.L}): {t * 1e3:.2f} ms per fit! + predict; "
+      f"device: " + ", ".join(f"{k} {v * 1e3:.2f}" for k, v in tm.items() if v > 5e-5))
