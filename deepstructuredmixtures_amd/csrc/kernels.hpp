@@ -827,11 +827,33 @@ __device__ __forceinline__ int potrf_inv16(double (&x)[16], double& x_scale, dou
     return badmask ? __builtin_ctz(badmask) + 1 : 0;
 }
 
+// P2 task list of every block step J of chol_diag_kernel, fixed at compile time: first the trailing products
+// S(I,K) -= S(I,J) S(K,J)^T (K = J+1.., I = K..7; task 0 = (J+1,J+1) belongs to wave 0), then the inverse products
+// B(I,K) -= S(I,J) B(J,K) (I = J+1..7, K = 0..J).  Entry = kind << 8 | I << 4 | K.  Looked up with scalar loads; the
+// closed forms (a search loop and an integer division per task) cost more than the product itself.
+struct DiagTaskTable {
+    unsigned short e[8][36];
+    unsigned char ntrail[8], ntotal[8];
+    constexpr DiagTaskTable() : e{}, ntrail{}, ntotal{} {
+        for (int J = 0; J < 8; ++J) {
+            int n = 0;
+            for (int K = J + 1; K < 8; ++K)
+                for (int I = K; I < 8; ++I) e[J][n++] = (unsigned short)(I << 4 | K);
+            ntrail[J] = (unsigned char)n;
+            for (int I = J + 1; I < 8; ++I)
+                for (int K = 0; K <= J; ++K) e[J][n++] = (unsigned short)(1 << 8 | I << 4 | K);
+            ntotal[J] = (unsigned char)n;
+        }
+    }
+};
+__constant__ const DiagTaskTable DIAG_TASKS{};
+
 // STAMP: thread 0 records wall_clock64() (100 MHz) after every phase (tools/probe_diag.py)
 template <bool STAMP>
 __device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, unsigned long long* stamps) {
-    double* Winv = S + TB * DLD;                                  // Linv of the current step, col-major ld 16
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    double* Winv = S + TB * DLD;                                  // 256 spare doubles (the panel steps read L_JJ^-1 from B(J,J))
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: task indices and block offsets stay scalar
     auto stamp = [&](int i) {
         if (STAMP && t == 0) stamps[i] = wall_clock64();
     };
@@ -863,7 +885,7 @@ __device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, un
     stamp(1);
 
     int bad = 0;
-    // diagonal block J on wave 0: S(J,J) <- L_JJ (upper part zeroed), B(J,J) and Winv <- L_JJ^-1
+    // diagonal block J on wave 0: S(J,J) <- L_JJ (upper part zeroed), B(J,J) <- L_JJ^-1
     auto diag_block = [&](int J) {
         const int c = l15;
         const bool isb = (lane & 16) != 0;
@@ -880,19 +902,17 @@ __device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, un
         if (J == 4) stamp(22);
         if (bj != 0 && bad == 0) bad = J * 16 + bj;
         // lanes 0..15 write column c of L (strict lower part scaled by 1/sqrt(d_c), diagonal from xd, zeros
-        // above), lanes 16..31 column c of L^-1 (to B(J,J) and to Winv): one instruction stream for both groups
+        // above), lanes 16..31 column c of L^-1 (to B(J,J)): one instruction stream for both groups
         if (lane < 32) {
             const int thr = isb ? c : c + 1;
             const double mul = isb ? 1.0 : xs;
             d2* dst = reinterpret_cast<d2*>((isb ? S + offB(J, J) : S + offS(J, J)) + c * DLD);
-            d2* dw = reinterpret_cast<d2*>(Winv + c * 16);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 d2 v;
                 v[0] = (r >= thr) ? x[r] * mul : ((r == c) ? xd : 0.0);
                 v[1] = (r + 1 >= thr) ? x[r + 1] * mul : ((r + 1 == c) ? xd : 0.0);
                 dst[r >> 1] = v;
-                if (isb) dw[r >> 1] = v;
             }
         }
     };
@@ -945,16 +965,19 @@ __device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, un
     if (w == 0) diag_block(0);
     __syncthreads();
     for (int J = 0; J < 8; ++J) {
+        // this step's P2 task list, one entry per lane (read back with v_readlane: a scalar load per task would put
+        // its latency on every pair of products); issued here so that it arrives during P1
+        const int mytask = DIAG_TASKS.e[J][lane < 36 ? lane : 0];
         // ---- P1: panel solve S(I,J) <- S(I,J) Linv^T (I > J) and the inverse's row J: B(J,K) <- Linv B(J,K) (K < J);
         //      7 block products, wave w takes w and w + 4 as a pair
         {
             auto op_p1 = [&](int task) {
                 if (task < 7 - J) {
                     double* dst = S + offS(J + 1 + task, J);
-                    return BlkOp{Winv, 1, 16, dst, DLD, dst};
+                    return BlkOp{S + offB(J, J), 1, DLD, dst, DLD, dst};
                 }
                 double* dst = S + offB(J, task - (7 - J));
-                return BlkOp{dst, DLD, 1, Winv, 16, dst};
+                return BlkOp{dst, DLD, 1, S + offB(J, J), DLD, dst};
             };
             const bool two = w + 4 < 7;
             const BlkOp o0 = op_p1(w);
@@ -963,7 +986,7 @@ __device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, un
         __syncthreads();
         stamp(2 + 2 * J);
         // ---- P2 with lookahead: wave 0 updates the next diagonal block and factorises it at once
-        //      (nothing else in P2 touches S(J+1,J+1), B(J+1,J+1) or Winv), waves 1..3 do the rest of the
+        //      (nothing else in P2 touches S(J+1,J+1) or B(J+1,J+1)), waves 1..3 do the rest of the
         //      trailing update S(I,K) -= S(I,J) S(K,J)^T and of B(I,K) -= S(I,J) B(J,K), two products at a time.
         const int m = 7 - J;
         if (w == 0) {
@@ -975,20 +998,14 @@ __device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, un
                 if (J == 3) stamp(23);
             }
         } else {
-            const int ntrail = m * (m + 1) / 2;
-            const int ninv = m * (J + 1);
+            const int total = DIAG_TASKS.ntotal[J];
             auto op_p2 = [&](int task) {
-                if (task < ntrail) {
-                    int q = task, Kk = 0;
-                    while (q >= m - Kk) { q -= m - Kk; ++Kk; }
-                    const int K = J + 1 + Kk;
-                    return op_trailing(J, K + q, K);
-                }
-                const int q = task - ntrail;
-                return op_inverse(J, J + 1 + q / (J + 1), q % (J + 1));
+                const int e = __builtin_amdgcn_readlane(mytask, task);
+                const int I = (e >> 4) & 15, K = e & 15;
+                return (e >> 8) ? op_inverse(J, I, K) : op_trailing(J, I, K);
             };
-            for (int task = 1 + (w - 1); task < ntrail + ninv; task += 6) {   // task 0 = (J+1,J+1): wave 0
-                const bool two = task + 3 < ntrail + ninv;
+            for (int task = 1 + (w - 1); task < total; task += 6) {   // task 0 = (J+1,J+1): wave 0
+                const bool two = task + 3 < total;
                 const BlkOp o0 = op_p2(task);
                 run_pair(o0, two ? op_p2(task + 3) : o0, two, true);
             }
