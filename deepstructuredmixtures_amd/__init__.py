@@ -7,11 +7,11 @@ from .kernels import IsoSE, ArdSE, IsoLinear, ConstMean, KernelFunction
 from .model import (DSMGP, PoE, gPoE, rBCM, GaussianProcess, build, buildDSMGP, buildPoE, buildBCM, fit,
                     fit_naive, predict, prediction, update_cholesky, update, infer, mll, mll_table,
                     reset_weights, getparams, setparams, mse, mae, nlpd, updategradients, grad_mll, train, ADAM,
-                    resident_test)
+                    resident_test, finetune)
 from .tree import get_leaves, get_overlap, share_schedule, route
 from .datagen import regression_data
 
 # reference (Julia) spelling -> function here
 JULIA_NAMES = {"fit!": fit, "fit_naive!": fit_naive, "update!": update, "infer!": infer,
                "update_cholesky!": update_cholesky, "setparams!": setparams, "reset_weights!": reset_weights, "updategradients!": updategradients,
-               "train!": train, "∇mll!": grad_mll}
+               "train!": train, "∇mll!": grad_mll, "finetune!": finetune}

@@ -480,9 +480,10 @@ def updategradients(model):
     return g
 
 
-def grad_mll(model):
+def grad_mll(model, leaf_weights=None):
     """`∇mll!(spn, 0.0, 0.0, L, L[root], grad)` (`src/optimize.jl:42-89`): gradient of the tree log marginal
-    w.r.t. the shared hyper-vector (concatenated per kernel id under sums over GPs)."""
+    w.r.t. the shared hyper-vector (concatenated per kernel id under sums over GPs).  With `leaf_weights` (one factor
+    per leaf: a row of the overlap matrix) it is the `finetune!` variant, `src/optimize.jl:91-150`."""
     if isinstance(model, GaussianProcess):
         return model.model.leaf_grad[0][: model.node.kernel.nparams() + 1].copy()
     tab = mll_table(model)
@@ -493,6 +494,8 @@ def grad_mll(model):
     def rec(node, dparent, lrho, g):
         if node.kind == "gp":
             w = np.exp(-logS + lrho + tab[node.id] + dparent)                 # :48
+            if leaf_weights is not None:
+                w = w * leaf_weights[node.leaf]                               # :101
             g += model.leaf_grad[node.leaf][: g.size] * w                     # :49
         elif node.kind == "split":
             for c in node.children:
@@ -568,6 +571,57 @@ def _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, ver
         hyp = hyp + optim.apply(hyp, g)                                       # :78-79 (ascent)
     setparams(model, hyp)
     fit(model, tau=tau)
+    return model, np.array(hist)
+
+
+def _overlap_row(D, j):
+    return D.row(j) if hasattr(D, "row") else np.asarray(D[j, :], dtype=np.float64)
+
+
+def finetune(model, optim=None, *, iterations=1000, lam=0.5, tau=0.05, verbose=False):
+    """`finetune!(model, optim; iterations, λ)` (`src/finetuning.jl:3-87`): one hyper-vector PER LEAF.  Every
+    iteration visits every leaf j: all leaves are set to leaf j's vector, the whole tree is refitted, and leaf j's
+    vector takes an ascent step along the tree gradient in which leaf l's contribution is weighted by the overlap
+    D[j, l] (`src/optimize.jl:91-150`; the diagonal of D is zero, so the leaf's own term does not enter -- the
+    reference passes `D` at `:54`, not the `Dd` it prepares at `:30-31`).  That is L whole-tree fit! +
+    updategradients! passes per iteration, each one batched call here.  The history is the sum over leaves of each
+    leaf's own log marginal at its own vector (`:51,59`); early stopping as `:61-79`.  At the end every leaf keeps
+    its own vector: the leaves get kernel ids of their own and are refactorised (`:74-77,82-85`).  One kernel id only: the reference's
+    `setparams!(spn, hyp_)` with a single leaf's vector is ill-formed for kernel vectors."""
+    if len(model.kernel_table()) != 1:
+        raise NotImplementedError("finetune: models with a kernel vector are not supported (ill-formed in the reference)")
+    optim = ADAM() if optim is None else optim
+    L = model.L
+    hyp = [np.concatenate([lf.kernel.loghyp(), [lf.logNoise]]) for lf in model.leaves]
+    rows = [_overlap_row(model.D, j) for j in range(L)]
+    hist, c = [], 0
+    model.ctx.set_joint(False)
+    try:
+        for it in range(1, iterations + 1):
+            ell = 0.0
+            for j, lf in enumerate(model.leaves):
+                setparams(model, hyp[j])
+                fit(model, tau=tau)
+                updategradients(model)
+                ell += float(model.leaf_mll[lf.leaf])                             # :51
+                hyp[j] = hyp[j] + optim.apply(hyp[j], grad_mll(model, leaf_weights=rows[j]))   # :54-56
+            hist.append(ell)
+            delta = abs(ell - np.mean(hist[-10:-1])) if it > 10 else np.inf          # :61
+            c = c + 1 if delta < lam else 0
+            if verbose:
+                print(f"iter {it}: sum of leaf mll {ell:.6f} delta {delta:.3g}")
+            if c >= 10:
+                break
+    finally:
+        model.ctx.set_joint(True)
+    # every leaf keeps its own hyper-parameters: a kernel id per leaf, then one factorisation each (:74-77, :82-85)
+    for j, lf in enumerate(model.leaves):
+        lf.kernelid = j
+        lf.logNoise = float(hyp[j][-1])
+        lf.kernel.set_loghyp(hyp[j][:-1])
+    model._ktab = None
+    model._uploaded = False
+    fit_naive(model)
     return model, np.array(hist)
 
 

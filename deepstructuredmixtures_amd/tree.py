@@ -262,6 +262,17 @@ class LeafOverlap:
             self._C = C
         return self._C
 
+    def row(self, j):
+        """Row j of the dense matrix: D[j, m] for every leaf m."""
+        C = self.C
+        out = np.zeros(self.shape[0])
+        lo, hi = C.indptr[j], C.indptr[j + 1]
+        cols, c = C.indices[lo:hi], C.data[lo:hi].astype(np.float64)
+        nj = float(self.nobs[j])
+        out[cols] = 1.0 - (nj - c) / nj
+        out[j] = 0.0
+        return out
+
     def todense(self):
         C = np.asarray(self.C.todense(), dtype=np.float64)
         n = self.nobs

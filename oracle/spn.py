@@ -376,9 +376,11 @@ def predict_rbcm(root, gps, x):
 
 # ------------------------------------------------------------------------------- gradients
 
-def grad_tree(root, gps, n_hyp):
+def grad_tree(root, gps, n_hyp, leaf_weights=None):
     """updategradients!(spn) + ∇mll!(spn, 0, 0, L, L[root], grad): src/fit.jl:306-311,
-    src/optimize.jl:42-89.  One shared hyper-vector (per kernel id for sums over GPs)."""
+    src/optimize.jl:42-89.  One shared hyper-vector (per kernel id for sums over GPs).
+    leaf_weights (a row of the overlap matrix, indexed by leaf): the finetune! methods, src/optimize.jl:91-150,
+    which multiply every leaf's term by D[gpmap.x[node.id]] (:101)."""
     tab = {}
     mll_table(root, gps, tab)
     logS = tab[root.id]
@@ -387,6 +389,8 @@ def grad_tree(root, gps, n_hyp):
     def rec(node, dparent, lrho, g):
         if node.kind == "gp":
             w = np.exp(-logS + lrho + tab[node.id] + dparent)    # :48
+            if leaf_weights is not None:
+                w = w * leaf_weights[node.leaf]                  # :101
             g += gps[node.leaf].grad() * w                       # :49
         elif node.kind == "split":
             for c in node.children:
@@ -405,3 +409,35 @@ def grad_tree(root, gps, n_hyp):
 
     rec(root, 0.0, 0.0, grad)
     return grad
+
+
+def finetune(root, gps, D, step, iterations, lam=0.5, tau=0.05):
+    """finetune!(spn, D, gpmap, optim; iterations, λ): src/finetuning.jl:8-87, restated with the oracle's pieces.
+    `step(hyp, grad)` is the optimiser's increment (Flux.Optimise.apply!, :55), added to the leaf's vector (:56).
+    Returns (per-leaf hyper-vectors, history).  One kernel id."""
+    leaves = get_leaves(root)
+    hyp = [np.concatenate([lf.kernel.loghyp(), [lf.logNoise]]) for lf in leaves]       # :22
+    n_hyp = hyp[0].size
+    hist, c = [], 0
+    for it in range(1, iterations + 1):
+        ell = 0.0
+        for j, lf in enumerate(leaves):
+            for l2, g in zip(leaves, gps):                                             # setparams!(spn, hyp_) :41
+                g.kernel = ogp.make_kernel(l2.kernel.kind, hyp[j][:-1])
+                g.logNoise = float(hyp[j][-1])
+            fit(root, gps, D, tau)                                                     # :44
+            tab = {}
+            mll_table(root, gps, tab)                                                  # :47-48
+            ell += tab[lf.id]                                                          # :51
+            grad = grad_tree(root, gps, n_hyp, leaf_weights=D[j, :])                   # :50,54
+            hyp[j] = hyp[j] + step(hyp[j], grad)                                       # :55-56
+        hist.append(ell)
+        delta = abs(ell - np.mean(hist[-10:-1])) if it > 10 else np.inf                # :61
+        c = c + 1 if delta < lam else 0                                                # :65-69
+        if c >= 10:
+            break
+    for j, g in enumerate(gps):                                                        # :74-77 / :82-85
+        g.kernel = ogp.make_kernel(leaves[j].kernel.kind, hyp[j][:-1])
+        g.logNoise = float(hyp[j][-1])
+        g.update_cholesky()
+    return hyp, np.array(hist)

@@ -374,6 +374,31 @@ def test_train_loop_follows_the_oracle_trajectory():
     assert hist[-1] > hist[0]
 
 
+def test_finetune_follows_the_oracle_loop():
+    """finetune! (src/finetuning.jl:8-87): L whole-tree fit! + updategradients! passes per iteration on the device,
+    per-leaf hyper-vectors at the end (a kernel id per leaf); same history and vectors as the oracle's loop."""
+    X, y, Xt = regression_data(900, 2, n_test=50, seed=77)
+    kw = dict(M=60, kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.3), seed=6)
+    m = dsm.buildDSMGP(X, y, 2, 3, **kw)
+    ref = dsm.buildDSMGP(X, y, 2, 3, fit_now=False, **kw)
+    _, hist = dsm.finetune(m, dsm.ADAM(eta=0.03), iterations=2)
+    gps = ospn.make_leaf_gps(ref.root, X, y, exact_dist=True)
+    hyp, hist_ref = ospn.finetune(ref.root, gps, ospn.get_overlap(ref.root, ref.L), dsm.ADAM(eta=0.03).apply, 2)
+    assert np.allclose(hist, hist_ref, rtol=1e-8)
+    got = np.array([np.concatenate([lf.kernel.loghyp(), [lf.logNoise]]) for lf in m.leaves])
+    assert np.allclose(got, np.array(hyp), rtol=1e-7, atol=1e-10)
+    assert np.allclose(m.leaf_mll, [g.mll() for g in gps], rtol=RTOL, atol=1e-8)
+    # the model with per-leaf hyper-parameters still predicts (leaves now carry kernel ids of their own)
+    for lf, hv in zip(ref.leaves, hyp):
+        lf.kernel.set_loghyp(hv[:-1])
+        lf.logNoise = float(hv[-1])
+    dsm.update(m)
+    mu, var = dsm.predict(m, Xt)
+    ospn.update(ref.root, gps)
+    mo, vo = ospn.predict(ref.root, gps, Xt)
+    assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9) and np.allclose(var, vo, rtol=RTOL, atol=1e-10)
+
+
 def test_full_size_properties_single_large_gp(ctx):
     """Config 2 (single exact GP N=4096, D=4, IsoSE) -- too large to compare entry by entry quickly,
     checked through size-independent properties: L L^T = K, K alpha = y, mll consistency,

@@ -324,3 +324,28 @@ def test_sparse_overlap_and_level_order_tree_passes_match_the_recursions():
         dsm.reset_weights(m)
         assert all(np.allclose(n.logweights, -np.log(len(n.children)))
                    for n in ptree.ordered_nodes(m.root) if n.kind == "sum")
+
+
+def test_finetune_follows_the_reference_loop():
+    """finetune! (src/finetuning.jl:8-87): per-leaf hyper-vectors, each updated from a whole-tree
+    refit at its own vector with the overlap-weighted gradient of src/optimize.jl:91-150.  The mirror (host logic
+    over the oracle-backed context) against the oracle's own restatement of the loop."""
+    X, y = _small_problem(500, 2, seed=17)
+    kw = dict(M=40, kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.3), seed=6, fit_now=False)
+    m = dsm.buildDSMGP(X, y, 2, 3, ctx=OracleContext(), **kw)
+    ref = dsm.buildDSMGP(X, y, 2, 3, ctx=OracleContext(), **kw)
+    assert m.L >= 6 and np.count_nonzero(m.D) > 0
+    _, hist = dsm.finetune(m, dsm.ADAM(eta=0.03), iterations=3)
+    gps = ospn.make_leaf_gps(ref.root, X, y, exact_dist=True)
+    opt = dsm.ADAM(eta=0.03)
+    hyp, hist_ref = ospn.finetune(ref.root, gps, ospn.get_overlap(ref.root, ref.L), opt.apply, 3)
+    assert np.allclose(hist, hist_ref, rtol=1e-9)
+    got = np.array([np.concatenate([lf.kernel.loghyp(), [lf.logNoise]]) for lf in m.leaves])
+    assert np.allclose(got, np.array(hyp), rtol=1e-9, atol=1e-12)
+    assert len({lf.kernelid for lf in m.leaves}) == m.L                     # every leaf keeps its own vector
+    assert np.std(got[:, 0]) > 0                                            # and they did move apart
+    assert np.allclose(m.leaf_mll, [g.mll() for g in gps], rtol=1e-9)       # final per-leaf factorisations
+    with pytest.raises(NotImplementedError):
+        kv = dsm.buildDSMGP(X, y, 2, 3, M=40, kernel=[dsm.IsoSE(0.0, 0.0), dsm.IsoLinear(0.0)], fit_now=False,
+                            ctx=OracleContext(), seed=6)
+        dsm.finetune(kv, iterations=1)
