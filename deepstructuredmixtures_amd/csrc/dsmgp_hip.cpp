@@ -2,6 +2,9 @@
 // The host builds, once per leaf table, flat task lists for every block step of the batched
 // left-looking Cholesky; fit!/predict then replay them as a fixed launch sequence on one stream.
 #include "../../include/dsmgp_hip.h"
+#ifdef DSMGP_DIAG
+#include "../../include/dsmgp_hip_diag.h"
+#endif
 #include "kernels.hpp"
 
 #include <algorithm>
@@ -242,7 +245,6 @@ struct dsmgp_ctx {
     bool last_fit_joint = false;
     double* slabP = nullptr;        // ... of the prediction sweep
     int ncu = 256;
-    int tile_variant = 2;           // 1: two-buffer kernel, 2: software-pipelined ring kernel
     bool xcd_order = true;          // XCD-aware task order (speed only)
     int tail_split = 4, tail_rounds = 1;
     std::vector<int> fwd_off, bwd_off;
@@ -289,6 +291,7 @@ struct dsmgp_ctx {
     size_t gpart_count = 0;
 
     double timings[DSMGP_N_TIMINGS] = {0};
+    std::vector<hipEvent_t> event_pool;   // PhaseTimer's events, reused across calls
     double alg_flops_update = 0.0;  // algorithmic flops of the Cholesky update launches
     int n_update_launches = 0;
 };
@@ -488,12 +491,16 @@ int check_hyper(dsmgp_ctx* c) {
 
 // Algorithmic flops of the left-looking update of a leaf of (unpadded) size n: for every block column k,
 // 2*K flops (K = 128k) per lower-triangle element of that block column.
-double update_flops(int n) {
+// A PREFIX leaf keeps the leading kb x kb blocks of its source: in block columns k < kb only the rows >= 128 kb are
+// updated (they are the launches of build_factor_steps), the copied part costs nothing.
+double update_flops(int n, int kb = 0) {
     double f = 0.0;
     for (int k = 1; k * TB < n; ++k) {
         const int c0 = k * TB, c1 = std::min(n, c0 + TB);
         double elems = 0.0;
-        for (int c = c0; c < c1; ++c) elems += (double)(n - c);
+        if (k < kb) elems = (double)(c1 - c0) * (double)std::max(0, n - kb * TB);
+        else
+            for (int c = c0; c < c1; ++c) elems += (double)(n - c);
         f += 2.0 * (double)c0 * elems;
     }
     return f;
@@ -655,7 +662,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
     }
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
-        if (lf.owner == l) alg_flops += update_flops(lf.n);
+        if (lf.owner == l) alg_flops += update_flops(lf.n, lf.kb);
         if (with_test && lf.nt > 0) alg_flops += predict_update_flops(lf.n, lf.nt);
     }
     return 0;
@@ -859,64 +866,73 @@ int build_plan(dsmgp_ctx* c) {
 }
 
 void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */) {
-    if (c->tile_variant >= 100) {   // ablation builds, micro-benchmark only
-        switch (c->tile_variant - 100) {
-            case 1: tile_gemm_kernel_v2<false, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-            case 2: tile_gemm_kernel_v2<false, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-            case 3: tile_gemm_kernel_v2<false, 3><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-            case 4: tile_gemm_kernel_v2<false, 4><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-            case 5: tile_gemm_kernel_v2<false, 5><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-            case 6: tile_gemm_kernel_v2<false, 6><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-            case 8: tile_gemm_kernel_v2<false, 8><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-            default: tile_gemm_kernel_v2<false, 7><<<n, 256, 0, c->stream>>>(tasks, nullptr); break;
-        }
-        return;
-    }
-    if (c->tile_variant == 3) tile_gemm_kernel_v3<false><<<n, 256, 0, c->stream>>>(tasks, nullptr);
-    else if (c->tile_variant == 4) tile_gemm_kernel_v2<false, 0, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr);
-    else if (role == 1) tile_gemm_kernel_v2<false, 0, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr);
-    else tile_gemm_kernel_v2<false, 0, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    if (role == 1) tile_gemm_kernel_v2<false, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    else tile_gemm_kernel_v2<false, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr);
 }
 
+// Two events bracketing a call on the context's stream; destroyed on every exit path.
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t init() {
+        hipError_t e = hipEventCreate(&a);
+        return e != hipSuccess ? e : hipEventCreate(&b);
+    }
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+// hipEvent spans per kernel category.  The events come from a pool owned by the context (created once, reused by
+// every fit/predict), so the timed region neither creates nor destroys events.
 struct PhaseTimer {
     dsmgp_ctx* c;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;
-    std::vector<std::array<int, 3>> notes;   // per span: (step, tasks, reduce tasks), for DSMGP_STEPLOG
+    struct Span { int slot; int e0, e1; int step, tasks, red; };
+    std::vector<Span> spans;
+    size_t used = 0;
     explicit PhaseTimer(dsmgp_ctx* c_) : c(c_) {}
     bool on = false;
+    int take() {
+        if (used == c->event_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            c->event_pool.push_back(e);
+        }
+        return (int)used++;
+    }
     void begin(int slot) {
         on = c->profile >= 2 || (c->profile == 1 && slot == 1);
         if (!on) return;
-        hipEvent_t a, b;
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, c->stream);
-        spans.push_back({slot, {a, b}});
-        notes.push_back({-1, 0, 0});
+        const int a = take(), b = take();
+        if (a < 0 || b < 0) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(c->event_pool[a], c->stream);
+        spans.push_back({slot, a, b, -1, 0, 0});
     }
     void note(int step, int ntasks, int nred) {
-        if (on) notes.back() = {step, ntasks, nred};
+        if (on) {
+            spans.back().step = step;
+            spans.back().tasks = ntasks;
+            spans.back().red = nred;
+        }
     }
     void end() {
         if (!on) return;
-        (void)hipEventRecord(spans.back().second.second, c->stream);
+        (void)hipEventRecord(c->event_pool[spans.back().e1], c->stream);
     }
     void collect() {
         const bool log = std::getenv("DSMGP_STEPLOG") != nullptr;
-        for (size_t i = 0; i < spans.size(); ++i) {
-            auto& s = spans[i];
+        for (const Span& s : spans) {
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, s.second.first, s.second.second);
-            c->timings[s.first] += ms * 1e-3;
-            if (log && notes[i][0] >= 0)
-                std::fprintf(stderr, "steplog slot %d step %d tasks %d tiles %d ms %.4f\n", s.first, notes[i][0],
-                             notes[i][1], notes[i][2], ms);
-            (void)hipEventDestroy(s.second.first);
-            (void)hipEventDestroy(s.second.second);
+            (void)hipEventElapsedTime(&ms, c->event_pool[s.e0], c->event_pool[s.e1]);
+            c->timings[s.slot] += ms * 1e-3;
+            if (log && s.step >= 0)
+                std::fprintf(stderr, "steplog slot %d step %d tasks %d tiles %d ms %.4f\n", s.slot, s.step, s.tasks, s.red, ms);
         }
         spans.clear();
-        notes.clear();
+        used = 0;
     }
 };
 
@@ -981,10 +997,11 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             c->ncu = prop.multiProcessorCount;
     }
-    if (const char* s = std::getenv("DSMGP_TILE_V")) c->tile_variant = std::atoi(s);
+#ifdef DSMGP_DIAG   // scheduling knobs of the diagnostic build (tools/sweep_env.sh); the product build reads no tuning variables
     if (const char* s = std::getenv("DSMGP_XCD")) c->xcd_order = std::atoi(s) != 0;
     if (const char* s = std::getenv("DSMGP_TAIL_SPLIT")) c->tail_split = std::max(1, std::atoi(s));
     if (const char* s = std::getenv("DSMGP_TAIL_ROUNDS")) c->tail_rounds = std::max(0, std::atoi(s));
+#endif
     const char* p = std::getenv("DSMGP_PROFILE");
     c->profile = p ? std::atoi(p) * 2 : 0;   // DSMGP_PROFILE=1 -> every category
     *out = c;
@@ -1004,6 +1021,7 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->d_obs_idx);
     dev_free(c->d_kp);
     dev_free(c->d_l2);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1068,7 +1086,7 @@ int dsmgp_set_leaves(dsmgp_ctx* c, int32_t L, const int64_t* obs_ptr, const int6
             if (obs_idx[i] < 0 || obs_idx[i] >= c->N) return fail(c, DSMGP_E_ARG, "observation index out of range");
             if (i > a && obs_idx[i] <= obs_idx[i - 1]) return fail(c, DSMGP_E_ARG, "obs lists must be strictly ascending");
         }
-        if (kernel_id[l] < 0 || kernel_id[l] > 4096) return fail(c, DSMGP_E_ARG, "kernel id out of range");
+        if (kernel_id[l] < 0 || kernel_id[l] >= DSMGP_MAX_KERNEL_IDS) return fail(c, DSMGP_E_ARG, "kernel id out of range");
         LeafHost& lf = c->leaves[l];
         lf.n = (int)(b - a);
         lf.npad = round_up(lf.n, TB);
@@ -1093,15 +1111,14 @@ int dsmgp_set_sharing(dsmgp_ctx* c, const int32_t* op, const int32_t* src, const
     if (!c) return DSMGP_E_ARG;
     if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_sharing before set_leaves");
     const int L = c->L;
+    // the whole schedule is validated into temporaries and committed at the end: a rejected schedule leaves the
+    // context (leaf table, task lists of the previous schedule) exactly as it was
+    struct Share { int op; int src; int64_t prefix; };
+    std::vector<Share> sh(L, Share{DSMGP_SHARE_FULL, -1, 0});
     for (int l = 0; l < L; ++l) {
-        LeafHost& lf = c->leaves[l];
+        const LeafHost& lf = c->leaves[l];
         const int o = op ? op[l] : DSMGP_SHARE_FULL;
-        if (o == DSMGP_SHARE_FULL) {
-            lf.op = o;
-            lf.src = -1;
-            lf.prefix = 0;
-            continue;
-        }
+        if (o == DSMGP_SHARE_FULL) continue;
         if (!src || src[l] < 0 || src[l] >= L || src[l] == l) return fail(c, DSMGP_E_ARG, "sharing: bad source leaf");
         const LeafHost& s = c->leaves[src[l]];
         const int so = op[src[l]];
@@ -1112,24 +1129,28 @@ int dsmgp_set_sharing(dsmgp_ctx* c, const int32_t* op, const int32_t* src, const
         if (o == DSMGP_SHARE_COPY) {
             if (s.n != lf.n || std::memcmp(a, b, sizeof(int64_t) * lf.n) != 0)
                 return fail(c, DSMGP_E_ARG, "sharing: COPY needs identical observation lists");
-            lf.prefix = 0;
+            sh[l] = Share{o, src[l], 0};
         } else if (o == DSMGP_SHARE_PREFIX) {
             if (!prefix_len || prefix_len[l] != s.n || s.n >= lf.n || std::memcmp(a, b, sizeof(int64_t) * s.n) != 0)
                 return fail(c, DSMGP_E_ARG, "sharing: PREFIX needs the source's list as a strict prefix");
-            lf.prefix = prefix_len[l];
+            sh[l] = Share{o, src[l], prefix_len[l]};
         } else {
             return fail(c, DSMGP_E_ARG, "sharing: unknown op");
         }
-        lf.op = o;
-        lf.src = src[l];
     }
+    HIPCHK(c, hipSetDevice(c->device));
     free_plan(c);
+    for (int l = 0; l < L; ++l) {
+        c->leaves[l].op = sh[l].op;
+        c->leaves[l].src = sh[l].src;
+        c->leaves[l].prefix = sh[l].prefix;
+    }
     return 0;
 }
 
 int dsmgp_set_hyper(dsmgp_ctx* c, int32_t kernel_id, int32_t kind, const double* loghyp, int32_t n) {
     if (!c) return DSMGP_E_ARG;
-    if (kernel_id < 0 || kernel_id > 4096 || !loghyp || n < 3) return fail(c, DSMGP_E_ARG, "set_hyper: bad arguments");
+    if (kernel_id < 0 || kernel_id >= DSMGP_MAX_KERNEL_IDS || !loghyp || n < 3) return fail(c, DSMGP_E_ARG, "set_hyper: bad arguments");
     if (kind < 0 || kind > 2) return fail(c, DSMGP_E_ARG, "set_hyper: unknown kernel kind");
     for (int i = 0; i < n; ++i)
         if (!std::isfinite(loghyp[i])) return fail(c, DSMGP_E_ARG, "set_hyper: non-finite hyper-parameter");
@@ -1157,9 +1178,9 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     c->timings[13] = 0.0;
     c->n_update_launches = 0;
     PhaseTimer pt(c);
-    hipEvent_t t0, t1;
-    HIPCHK(c, hipEventCreate(&t0));
-    HIPCHK(c, hipEventCreate(&t1));
+    EventPair ev;
+    HIPCHK(c, ev.init());
+    const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
 
     HIPCHK(c, hipMemsetAsync(c->d_info, 0, L * sizeof(int), c->stream));
@@ -1225,8 +1246,6 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     pt.collect();
     c->timings[11] = ms * 1e-3;
     if (seconds) *seconds = ms * 1e-3;
@@ -1436,9 +1455,9 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     for (int i = 6; i < 10; ++i) c->timings[i] = 0.0;
     c->timings[12] = 0.0;
     PhaseTimer pt(c);
-    hipEvent_t t0, t1;
-    HIPCHK(c, hipEventCreate(&t0));
-    HIPCHK(c, hipEventCreate(&t1));
+    EventPair ev;
+    HIPCHK(c, ev.init());
+    const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
     if (c->pgram.count) {
         const bool standalone = !c->vt_valid;
@@ -1483,8 +1502,6 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     pt.collect();
     c->timings[12] = ms * 1e-3;
     if (seconds) *seconds = ms * 1e-3;
@@ -1675,9 +1692,9 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     if (!c->grad_ready)
         if (int rc = build_grad_plan(c)) return rc;
     c->timings[10] = 0.0;
-    hipEvent_t t0, t1;
-    HIPCHK(c, hipEventCreate(&t0));
-    HIPCHK(c, hipEventCreate(&t1));
+    EventPair ev;
+    HIPCHK(c, ev.init());
+    const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
     // Xt = L^-T
     HIPCHK(c, hipMemsetAsync(c->arenaX, 0, c->arenaX_count * sizeof(double), c->stream));
@@ -1703,8 +1720,6 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     c->timings[10] = ms * 1e-3;
     std::vector<double> part(c->gpart_count);
     HIPCHK(c, hipMemcpy(part.data(), c->d_gpart, c->gpart_count * sizeof(double), hipMemcpyDeviceToHost));
@@ -1897,9 +1912,9 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* c, int32_t blocks_per_cu, double* out
     unsigned long long* stamps = nullptr;
     HIPCHK(c, hipMalloc(&sink, (size_t)blocks * 256 * sizeof(double)));
     HIPCHK(c, hipMalloc(&stamps, (size_t)nwaves * 2 * sizeof(unsigned long long)));
-    hipEvent_t t0, t1;
-    HIPCHK(c, hipEventCreate(&t0));
-    HIPCHK(c, hipEventCreate(&t1));
+    EventPair ev;
+    HIPCHK(c, ev.init());
+    const hipEvent_t t0 = ev.a, t1 = ev.b;
     for (int rep = 0; rep < 3; ++rep) mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(sink, stamps, iters);
     HIPCHK(c, hipEventRecord(t0, c->stream));
     mfma_probe_kernel<<<blocks, 256, 0, c->stream>>>(sink, stamps, iters);
@@ -1907,8 +1922,6 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* c, int32_t blocks_per_cu, double* out
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     std::vector<unsigned long long> hs((size_t)nwaves * 2);
     HIPCHK(c, hipMemcpy(hs.data(), stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     dev_free(sink);
@@ -1928,6 +1941,8 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* c, int32_t blocks_per_cu, double* out
     return 0;
 }
 
+#ifdef DSMGP_DIAG
+// ---- diagnostic build only (libdsmgp_hip_diag.so, include/dsmgp_hip_diag.h): never part of the product library ----
 // Diagnostic: f64 MFMA and f64 VALU FMA alone and co-issued (two waves per SIMD).  out[3*mode + {0,1,2}] =
 // {MFMA TFLOP/s, VALU TFLOP/s, wall ms} for mode 0 (MFMA only), 1 (VALU only), 2 (one wave of each per SIMD).
 int dsmgp_probe_coissue(dsmgp_ctx* c, double* out) {
@@ -2133,8 +2148,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     if (std::getenv("DSMGP_STAMPS")) {
         unsigned long long* st = nullptr;
         HIPCHK(c, hipMalloc(&st, (size_t)ntiles * 16 * sizeof(unsigned long long)));
-        if (c->tile_variant == 3) tile_gemm_kernel_v3<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
-        else tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
+        tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<unsigned long long> hs((size_t)ntiles * 16);
         HIPCHK(c, hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -2146,11 +2160,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
             bd += (double)hs[4 * i + 2];
             nchs += (double)hs[4 * i + 3];
         }
-        if (c->tile_variant == 3)
-            std::fprintf(stderr, "  stamps: cycles per 64 MFMA %.0f  mfma-span %.0f  in-kernel clock %.3f GHz\n", tot / nchs,
-                         mf / nchs, tot / bd / 10.0);
-        else
-            std::fprintf(stderr, "  stamps: cycles/chunk total %.0f  mfma-span %.0f  boundary %.0f (per wave, mean)\n",
+        std::fprintf(stderr, "  stamps: cycles/chunk total %.0f  mfma-span %.0f  boundary %.0f (per wave, mean)\n",
                          tot / nchs, mf / nchs, bd / nchs);
     }
     dev_free(dt.p);
@@ -2159,6 +2169,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     dev_free(C);
     return 0;
 }
+#endif  // DSMGP_DIAG
 
 // Host-only helper of the sharing schedule (src/fit.jl:12-39,78-86) for leaf tables too large for the dense L x L
 // overlap matrix: for every leaf j, main[j] = argmax_i D[i,j] D[j,i] with D[a,b] = 1 - (|a| - |a n b|) / |a| for

@@ -174,7 +174,7 @@ struct TileTask {
     int update;         // 0 = store the product, 1 = C - product
 };
 
-// diagnostic builds (tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
+// diagnostic builds (-DDSMGP_DIAG, tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -270,12 +270,9 @@ __device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4
 constexpr int KC2 = 8;
 constexpr int NRING = 4;
 
-// ABL is an ablation mask for tools/bench_tile.py only (results are wrong when it is non-zero):
-//   1 = no global loads / LDS writes in the loop, 2 = no barrier in the loop, 4 = no fragment reads in the loop,
-//   8 = global loads kept but their LDS writes dropped
-// SETS = number of register sets the global loads rotate through: 2 = a chunk's loads have one chunk time to arrive
-// before their LDS write, 3 = two chunk times (16 more VGPRs).
-template <bool STAMP, int ABL, int SETS = 2>
+// STAMP (diagnostic build only, -DDSMGP_DIAG): lane 0 of every wave records shader cycles of the loop, of its MFMA
+// spans and of its chunk boundaries (tools/bench_tile.py).
+template <bool STAMP>
 __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4][4], double (*sA)[KC2 * LDP],
                                                  double (*sB)[KC2 * LDP], unsigned long long* __restrict__ stamps) {
     const int t = threadIdx.x;
@@ -294,7 +291,7 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     const double* gA = tk.A + srow + (size_t)(tk.k0 + scol) * tk.lda;
     const double* gB = tk.B + srow + (size_t)(tk.k0 + scol) * tk.ldb;
     const int sOff = scol * LDP + srow;
-    d2 ra0[2], rb0[2], ra1[2], rb1[2], ra2[2], rb2[2];
+    d2 ra0[2], rb0[2], ra1[2], rb1[2];
 
 #define GLOAD(RA, RB, CH)                                                                        \
     do {                                                                                         \
@@ -331,30 +328,18 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     // prologue: chunks 0..2 into the ring with the loads overlapped (two memory latencies, not three),
     // chunk 3 in flight in set 1
     if (nch > 0) {
-        if (SETS == 2) {
-            GLOAD(ra0, rb0, 0);
-            GLOAD(ra1, rb1, min(1, nch - 1));
-            SWRITE(ra0, rb0, 0);
-            GLOAD(ra0, rb0, min(2, nch - 1));
-            SWRITE(ra1, rb1, 1);
-            GLOAD(ra1, rb1, min(3, nch - 1));
-            SWRITE(ra0, rb0, 2);
-        } else {   // ring <- chunks 0..2, set 1 <- chunk 3, set 2 <- chunk 4 (set 0 takes chunk 5 in the first chunk)
-            GLOAD(ra0, rb0, 0);
-            GLOAD(ra1, rb1, min(1, nch - 1));
-            GLOAD(ra2, rb2, min(2, nch - 1));
-            SWRITE(ra0, rb0, 0);
-            SWRITE(ra1, rb1, 1);
-            GLOAD(ra1, rb1, min(3, nch - 1));
-            SWRITE(ra2, rb2, 2);
-            GLOAD(ra2, rb2, min(4, nch - 1));
-        }
+        GLOAD(ra0, rb0, 0);
+        GLOAD(ra1, rb1, min(1, nch - 1));
+        SWRITE(ra0, rb0, 0);
+        GLOAD(ra0, rb0, min(2, nch - 1));
+        SWRITE(ra1, rb1, 1);
+        GLOAD(ra1, rb1, min(3, nch - 1));
+        SWRITE(ra0, rb0, 2);
     }
     __syncthreads();
 
     double fa0[4], fb0[4], fa1[4], fb1[4];
     if (nch > 0) FRAGS(fa0, fb0, 0, 0);
-    if (ABL & 4) FRAGS(fa1, fb1, 0, 1);
     unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0;
     if (STAMP) tin = stamp_now();
 
@@ -381,38 +366,27 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
         const int buf_ = c_ & (NRING - 1);                                                       \
         if (STAMP) { __builtin_amdgcn_sched_barrier(0); ta = stamp_now(); }                      \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (!(ABL & 1)) GLOAD(LRA, LRB, min(c_ + 2 + SETS, nch - 1)); /* clamped: static vmcnt counts */ \
-        if (!(ABL & 4)) FRAGS(fa1, fb1, buf_, 1);                                                \
+        GLOAD(LRA, LRB, min(c_ + 4, nch - 1)); /* clamped: static vmcnt counts */                \
+        FRAGS(fa1, fb1, buf_, 1);                                                                \
         MFMA16(fa0, fb0);                                                                        \
-        if (!ABL) INTERLEAVE(0x020, 0x100);                                                      \
+        INTERLEAVE(0x020, 0x100);                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (!(ABL & 1) && !(ABL & 8)) SWRITE(WRA, WRB, (c_ + 3) & (NRING - 1)); /* past the end: unread slot */ \
-        if (ABL & 8) { asm volatile("" ::"v"(WRA[0]), "v"(WRA[1]), "v"(WRB[0]), "v"(WRB[1])); }  \
-        if (!(ABL & 4)) FRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                              \
+        SWRITE(WRA, WRB, (c_ + 3) & (NRING - 1)); /* past the end: unread slot */                \
+        FRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                                              \
         MFMA16(fa1, fb1);                                                                        \
-        if (!ABL) INTERLEAVE(0x200, 0x100);                                                      \
+        INTERLEAVE(0x200, 0x100);                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         if (STAMP) { tb = stamp_now(); __builtin_amdgcn_sched_barrier(0); tmf += tb - ta; }      \
-        if (!(ABL & 2)) __syncthreads();                                                         \
+        __syncthreads();                                                                         \
         if (STAMP) { __builtin_amdgcn_sched_barrier(0); tbd += stamp_now() - tb; __builtin_amdgcn_sched_barrier(0); } \
     } while (0)
 
     int c = 0;
-    if (SETS == 2) {
-        for (; c + 1 < nch; c += 2) {
-            CHUNK(c, ra0, rb0, ra1, rb1);
-            CHUNK(c + 1, ra1, rb1, ra0, rb0);
-        }
-        if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
-    } else {   // chunk c loads into set c % 3 (chunk c+5) and writes set (c+1) % 3 (chunk c+3, loaded two chunks ago)
-        for (; c + 2 < nch; c += 3) {
-            CHUNK(c, ra0, rb0, ra1, rb1);
-            CHUNK(c + 1, ra1, rb1, ra2, rb2);
-            CHUNK(c + 2, ra2, rb2, ra0, rb0);
-        }
-        if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
-        if (c + 1 < nch) CHUNK(c + 1, ra1, rb1, ra2, rb2);
+    for (; c + 1 < nch; c += 2) {
+        CHUNK(c, ra0, rb0, ra1, rb1);
+        CHUNK(c + 1, ra1, rb1, ra0, rb0);
     }
+    if (c < nch) CHUNK(c, ra0, rb0, ra1, rb1);
 #undef CHUNK
 #undef INTERLEAVE
 #undef MFMA16
@@ -430,148 +404,17 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Same pipeline with LDS-DMA staging (global_load_lds_dwordx4): operands go HBM/L2 -> LDS without passing
-// through VGPRs, so the loop has no ds_write and no load-return traffic into the register file.
-// One wave instruction moves one 1 KiB column (128 rows) of a chunk; the LDS destination is wave-uniform
-// base + 16 B * lane, which is exactly a column of the padded [8][144] image.  A wave's DMAs are counted in
-// vmcnt: before the barrier that ends chunk c every wave waits until only its 4 newest DMAs (chunk c+3)
-// are in flight, so chunk c+2 is complete and visible one full chunk before its first fragment read.
-// All LDS lives in ONE array (a second __shared__ object makes hipcc drain vmcnt in the loop).
-constexpr int SLOT_DOUBLES = 2 * KC2 * LDP;
-
-template <bool STAMP>
-__device__ __forceinline__ void gemm_mainloop_v3(const TileTask& tk, d4 (&acc)[4][4], double* smem,
-                                                 unsigned long long* __restrict__ stamps) {
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wr = w & 1, wc = w >> 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-#pragma unroll
-    for (int cm = 0; cm < 4; ++cm)
-#pragma unroll
-        for (int rn = 0; rn < 4; ++rn) acc[cm][rn] = (d4){0.0, 0.0, 0.0, 0.0};
-
-    typedef const __attribute__((address_space(1))) void* gvp;
-    typedef __attribute__((address_space(3))) void* lvp;
-    const double* gA = tk.A + 2 * lane + (size_t)(tk.k0 + w) * tk.lda;
-    const double* gB = tk.B + 2 * lane + (size_t)(tk.k0 + w) * tk.ldb;
-    const size_t a4 = (size_t)4 * tk.lda, b4 = (size_t)4 * tk.ldb;
-
-#define DMA(CH, SLOT)                                                                            \
-    do {                                                                                         \
-        const size_t oa_ = (size_t)(CH) * KC2 * tk.lda, ob_ = (size_t)(CH) * KC2 * tk.ldb;       \
-        double* sa_ = smem + (SLOT) * SLOT_DOUBLES + w * LDP;                                    \
-        double* sb_ = sa_ + KC2 * LDP;                                                           \
-        __builtin_amdgcn_global_load_lds((gvp)(gA + oa_), (lvp)sa_, 16, 0, 0);                   \
-        __builtin_amdgcn_global_load_lds((gvp)(gA + oa_ + a4), (lvp)(sa_ + 4 * LDP), 16, 0, 0);  \
-        __builtin_amdgcn_global_load_lds((gvp)(gB + ob_), (lvp)sb_, 16, 0, 0);                   \
-        __builtin_amdgcn_global_load_lds((gvp)(gB + ob_ + b4), (lvp)(sb_ + 4 * LDP), 16, 0, 0);  \
-    } while (0)
-#define FRAGS(FA, FB, SLOT, G)                                                                   \
-    do {                                                                                         \
-        const double* pb_ = smem + (SLOT) * SLOT_DOUBLES + ((G) * 4 + l4) * LDP + wr * 64 + l15; \
-        const double* pa_ = smem + (SLOT) * SLOT_DOUBLES + KC2 * LDP + ((G) * 4 + l4) * LDP + wc * 64 + l15; \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
-            FA[i_] = pa_[16 * i_];                                                               \
-            FB[i_] = pb_[16 * i_];                                                               \
-        }                                                                                        \
-    } while (0)
-#define MFMA16(FA, FB)                                                                           \
-    do {                                                                                         \
-        _Pragma("unroll") for (int cm_ = 0; cm_ < 4; ++cm_)                                      \
-            _Pragma("unroll") for (int rn_ = 0; rn_ < 4; ++rn_)                                  \
-                acc[cm_][rn_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[cm_], FB[rn_], acc[cm_][rn_], 0, 0, 0); \
-    } while (0)
-
-    const int nch = (tk.k1 - tk.k0) / KC2;
-    if (nch > 0) {
-        DMA(0, 0);
-        DMA(min(1, nch - 1), 1);
-        DMA(min(2, nch - 1), 2);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    double fa0[4], fb0[4], fa1[4], fb1[4];
-    if (nch > 0) FRAGS(fa0, fb0, 0, 0);
-    unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0, rin = 0;
-    if (STAMP) {
-        tin = stamp_now();
-        rin = __builtin_amdgcn_s_memrealtime();
-    }
-
-    for (int c = 0; c < nch; ++c) {
-        const int slot = c & (NRING - 1);
-        if (STAMP) { __builtin_amdgcn_sched_barrier(0); ta = stamp_now(); }
-        __builtin_amdgcn_sched_barrier(0);
-        DMA(min(c + 3, nch - 1), (c + 3) & (NRING - 1));   // clamped: past the end it refills an unread slot
-        FRAGS(fa1, fb1, slot, 1);
-        MFMA16(fa0, fb0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAGS(fa0, fb0, (c + 1) & (NRING - 1), 0);
-        MFMA16(fa1, fb1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { tb = stamp_now(); __builtin_amdgcn_sched_barrier(0); tmf += tb - ta; }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (STAMP) { tbd += stamp_now() - tb; __builtin_amdgcn_sched_barrier(0); }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef MFMA16
-#undef FRAGS
-#undef DMA
-    if (STAMP && (t & 63) == 0) {
-        const unsigned long long tout = stamp_now();
-        const unsigned long long rout = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + w) * 4;
-        s[0] = tout - tin;
-        s[1] = tmf;
-        (void)tbd;
-        s[2] = rout - rin;      // 100 MHz ticks: clock = s[0] / s[2] / 10 GHz (v3 reports this instead of the boundary span)
-        s[3] = nch / 2;
-    }
-}
-
-template <bool STAMP>
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v3(const TileTask* __restrict__ tasks,
-                                                              unsigned long long* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) double smem[NRING * SLOT_DOUBLES];
-    const TileTask tk = tasks[blockIdx.x];
-    d4 acc[4][4];
-    gemm_mainloop_v3<STAMP>(tk, acc, smem, stamps);
-    tile_epilogue(tk, acc, smem);
-}
-
 // ROLE only names the instantiation (same code): 0 = update launches (whole tiles and split-K pieces), 1 = panel
 // solves (K = 128), so that profilers report the two populations as two kernels
-// (tile_gemm_kernel_v2<false, 0, 0> is the dominant kernel of bench.py's roofline).
-template <bool STAMP, int ABL = 0, int ROLE = 0>
+// (tile_gemm_kernel_v2<false, 0> is the dominant kernel of bench.py's roofline).
+template <bool STAMP, int ROLE = 0>
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
                                                               unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
     __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
     const TileTask tk = tasks[blockIdx.x];
     d4 acc[4][4];
-    gemm_mainloop_v2<STAMP, ABL, (ROLE >= 2 ? 3 : 2)>(tk, acc, sA, sB, stamps);   // ROLE 2: three load sets (DSMGP_TILE_V=4)
+    gemm_mainloop_v2<STAMP>(tk, acc, sA, sB, stamps);
     tile_epilogue(tk, acc, &sA[0][0]);
 }
 
@@ -604,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __
     const GradTask g = tasks[blockIdx.x];
     const KParam p = kp[g.kid];
     d4 acc[4][4];
-    gemm_mainloop_v2<false, 0>(g.gemm, acc, sA, sB, nullptr);
+    gemm_mainloop_v2<false>(g.gemm, acc, sA, sB, nullptr);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
     const double l2 = p.l2[0];
@@ -1054,12 +897,14 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restri
     chol_diag_body<false>(tk, S, nullptr);
 }
 
+#ifdef DSMGP_DIAG
 __global__ __launch_bounds__(256) void chol_diag_stamp_kernel(const DiagTask* __restrict__ tasks,
                                                               unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) double S[];
     const DiagTask tk = tasks[blockIdx.x];
     chol_diag_body<true>(tk, S, stamps + 24 * (size_t)blockIdx.x);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Triangular solves alpha = L^-T (L^-1 y) (src/gaussianprocess.jl:105) as block sweeps that reuse
@@ -1386,6 +1231,7 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned l
     }
 }
 
+#ifdef DSMGP_DIAG
 // Co-issue probe: do the f64 matrix pipe and the f64 vector pipe run at the same time?  mode 0: every wave
 // issues MFMAs; mode 1: every wave issues v_fma_f64; mode 2: even waves MFMA, odd waves v_fma_f64 (two waves per
 // SIMD: one of each).  out[wave] = {cycles, ticks}; flops are counted by the host.
@@ -1429,5 +1275,6 @@ __global__ __launch_bounds__(512) void coissue_probe_kernel(double* out, unsigne
         stamps[2 * wv + 1] = r1 - r0;
     }
 }
+#endif
 
 }  // namespace dsmgp

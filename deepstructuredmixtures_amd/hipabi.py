@@ -48,18 +48,39 @@ SIGNATURES = {
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
     "dsmgp_probe_f64_mfma_detail": (C.c_int, [_ctx, C.c_int32, _dp]),
+}
+
+# include/dsmgp_hip_diag.h: only in libdsmgp_hip_diag.so (csrc/build.sh diag), used by tools/ for kernel tuning
+DIAG_SIGNATURES = {
     "dsmgp_probe_coissue": (C.c_int, [_ctx, _dp]),
     "dsmgp_bench_tile": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "dsmgp_probe_diag": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
 }
+DIAG_LIB_PATH = os.path.join(_HERE, "libdsmgp_hip_diag.so")
 
 _lib = None
+_diag_lib = None
 
 
 class DsmgpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"dsmgp error {code}: {msg}")
         self.code = code
+
+
+def load_diag_library():
+    """The diagnostic build (tools/ only): same ABI plus the entry points of include/dsmgp_hip_diag.h."""
+    global _diag_lib
+    if _diag_lib is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise RuntimeError(f"{DIAG_LIB_PATH} is missing: build it with deepstructuredmixtures_amd/csrc/build.sh diag")
+        lib = C.CDLL(DIAG_LIB_PATH)
+        for name, (res, args) in {**SIGNATURES, **DIAG_SIGNATURES}.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _diag_lib = lib
+    return _diag_lib
 
 
 def load_library():
@@ -102,8 +123,8 @@ def _i32(a):
 class Context:
     """One GPU context (dsmgp_ctx)."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, diag=False):
+        self.lib = load_diag_library() if diag else load_library()
         self.h = _ctx()
         rc = self.lib.dsmgp_create(int(device), C.byref(self.h))
         if rc != 0:

@@ -198,6 +198,15 @@ class Model:
         key = ("sched", None if tau is None else float(tau))
         if self._uploaded and self._schedule == key:
             return
+        if len(loc) == 0:
+            # a rank without leaves (fewer sharing groups than ranks, e.g. a small PoE on 8 GPUs) makes no device
+            # call at all; it still joins every collective with empty contributions (_fit, _leaf_moments, ...)
+            self._uploaded = True
+            self._schedule = key
+            self._route_cache = None
+            if self.D is not None and tau is not None:
+                self.share_op = share_schedule(self.leaves, self.D, tau)[0]
+            return
         if not self._uploaded:
             self.ctx.set_train(self.x, self.y)
         lv = [self.leaves[i] for i in loc]
@@ -332,8 +341,11 @@ def prediction(gp, xtest):
 
 def _fit(model, tau):
     model._upload(tau)
-    model._push_hyper()
-    mll_loc, info_loc, sec = model.ctx.fit()
+    if len(model.shard.local) == 0:
+        mll_loc, info_loc, sec = np.zeros(0), np.zeros(0, dtype=np.int32), 0.0
+    else:
+        model._push_hyper()
+        mll_loc, info_loc, sec = model.ctx.fit()
     both = model.shard.gather_leaf_columns(np.stack([mll_loc, info_loc.astype(np.float64)], axis=1))   # one collective
     model.leaf_mll = np.ascontiguousarray(both[:, 0])
     model.leaf_info = both[:, 1].astype(np.int32)
@@ -466,7 +478,7 @@ def updategradients(model):
     gathered.  Also stored on the leaves (kernel.dl / kernel.ds / dnoise) like the reference does."""
     target = model.model if isinstance(model, GaussianProcess) else model
     stride = max(lf.kernel.nparams() + 1 for lf in target.leaves)
-    g_loc = target.ctx.gradients(stride)
+    g_loc = target.ctx.gradients(stride) if len(target.shard.local) else np.zeros((0, stride))
     g = target.shard.gather_leaf_columns(g_loc[:, :stride])
     for lf, row in zip(target.leaves, g):
         n = lf.kernel.nparams()
@@ -547,11 +559,14 @@ def train(model, optim=None, *, iterations=10_000, lam=0.05, randinit=True, earl
     hyp = normal(seed, 0, n) if randinit else getparams(model)
     hist = []
     c = 0
-    model.ctx.set_joint(False)     # fit is not followed by predict inside the loop: keep resident test rows out of it
+    has_leaves = len(model.shard.local) > 0
+    if has_leaves:
+        model.ctx.set_joint(False)     # fit is not followed by predict inside the loop: keep resident test rows out of it
     try:
         return _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose)
     finally:
-        model.ctx.set_joint(True)
+        if has_leaves:
+            model.ctx.set_joint(True)
 
 
 def _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose):
@@ -615,13 +630,23 @@ def finetune(model, optim=None, *, iterations=1000, lam=0.5, tau=0.05, verbose=F
     finally:
         model.ctx.set_joint(True)
     # every leaf keeps its own hyper-parameters: a kernel id per leaf, then one factorisation each (:74-77, :82-85)
+    before = [(lf.kernelid, lf.logNoise, lf.kernel.loghyp().copy()) for lf in model.leaves]
     for j, lf in enumerate(model.leaves):
         lf.kernelid = j
         lf.logNoise = float(hyp[j][-1])
         lf.kernel.set_loghyp(hyp[j][:-1])
     model._ktab = None
     model._uploaded = False
-    fit_naive(model)
+    try:
+        fit_naive(model)
+    except Exception:
+        # leave the model as it was before the per-leaf ids were assigned (one shared vector, refittable)
+        for lf, (kid, ln, lh) in zip(model.leaves, before):
+            lf.kernelid, lf.logNoise = kid, ln
+            lf.kernel.set_loghyp(lh)
+        model._ktab = None
+        model._uploaded = False
+        raise
     return model, np.array(hist)
 
 
@@ -648,12 +673,14 @@ def _routing(model, xt):
 
 def _leaf_moments(model, xt, rc):
     """(mu, var) per (leaf, routed row) for ALL leaves, computed on the owning ranks."""
+    counts = np.diff(rc["ptr"])
+    if len(model.shard.local) == 0:
+        return model.shard.gather_ragged_pair(np.zeros(0), np.zeros(0), counts)
     if not rc["uploaded"]:
         model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
         rc["uploaded"] = True
     model.last_predict_seconds = model.ctx.predict_run()
     mu_l, var_l = model.ctx.predict_fetch()
-    counts = np.diff(rc["ptr"])
     return model.shard.gather_ragged_pair(mu_l, var_l, counts)
 
 
@@ -668,7 +695,7 @@ def resident_test(model, xtest, tau=0.05):
         xt = xt.reshape(-1, 1)
     model._upload(tau)
     rc = _routing(model, xt)
-    if not rc["uploaded"]:
+    if not rc["uploaded"] and len(model.shard.local):
         model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
         rc["uploaded"] = True
 

@@ -51,6 +51,9 @@ typedef struct dsmgp_ctx dsmgp_ctx;
  * total_predict, chol_reduce (split-K reduce launches of the factorisation) */
 #define DSMGP_N_TIMINGS 14
 
+/* kernel ids are dense small integers (one hyper-vector each; finetune! gives every leaf its own) */
+#define DSMGP_MAX_KERNEL_IDS (1 << 22)
+
 /* ---- context ---------------------------------------------------------------------------------- */
 int dsmgp_create(int32_t device_id, dsmgp_ctx** out);
 int dsmgp_destroy(dsmgp_ctx* ctx);
@@ -112,7 +115,8 @@ int dsmgp_kernel_matrix(dsmgp_ctx* ctx, int32_t kernel_id, const double* x1, int
 int dsmgp_download_factor(dsmgp_ctx* ctx, int32_t leaf, double* F /* n x n */, double* alpha /* n */);
 /* hipEvent timing per launch: level 0 = totals only, 1 = the update launches of the factorisation (the dominant
  * kernel; what bench.py's roofline uses), 2 = every kernel category (adds event records between all launches;
- * also switched on by the environment variable DSMGP_PROFILE=1 at dsmgp_create) */
+ * also switched on by the environment variable DSMGP_PROFILE=1 at dsmgp_create -- the only environment variable the
+ * product library reads besides DSMGP_STEPLOG / DSMGP_HOSTLOG (stderr logging); none of them changes results) */
 int dsmgp_set_profile(dsmgp_ctx* ctx, int32_t level);
 int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the last fit/predict */);
 /* work of the dominant kernel (the f64-MFMA Cholesky update) in the last fit: algorithmic flops over
@@ -139,19 +143,6 @@ int dsmgp_probe_f64_mfma(dsmgp_ctx* ctx, double* tflops);
 /* out[0] TFLOP/s, out[1] shader cycles per MFMA per wave, out[2] shader clock (GHz) held in the loop,
  * out[3] = blocks_per_cu (256-thread workgroups per CU, i.e. waves per SIMD) */
 int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* ctx, int32_t blocks_per_cu, double* out);
-
-/* diagnostic: f64 MFMA vs f64 VALU FMA rates alone and co-issued: out[9] = {mfma TF/s, valu TF/s, ms} x {MFMA only, VALU only, both} */
-int dsmgp_probe_coissue(dsmgp_ctx* ctx, double* out);
-/* diagnostic: seconds per launch of the tile GEMM on a uniform batch of ntiles tiles of depth K
- * (mode 0: own A panel per tile, B panel shared by `group` tiles; mode 1: all operands shared, L2-resident) */
-int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,
-                     double* seconds_per_launch);
-
-/* diagnostic: chol_diag_kernel on `ntiles` independent SPD 128x128 blocks (leading dimension ld >= 128):
- * kernel_us = average launch time; phases_us[23]: [0..18] time between the kernel's 20 in-kernel stamps on block 0
- * (load, then P1/P2 of the 8 block columns, store, fused z), [19..22] wave 0's share of the fourth P2
- * (block product, LDS reads, potrf_inv16 in registers, LDS writes) */
-int dsmgp_probe_diag(dsmgp_ctx* ctx, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us);
 
 /* Host-only (no device): per leaf j the "main" leaf of the sharing schedule of src/fit.jl:78-86,
  * main[j] = argmax_i D[i,j] D[j,i] over the overlap matrix D of src/fit.jl:12-39 (first maximum, 0 if leaf j overlaps

@@ -1,0 +1,32 @@
+/*
+ * dsmgp_hip_diag.h -- entry points of the DIAGNOSTIC build only (libdsmgp_hip_diag.so, compiled with -DDSMGP_DIAG
+ * by deepstructuredmixtures_amd/csrc/build.sh diag).  They exist for kernel tuning (tools/): in-kernel cycle
+ * stamps, micro-benchmarks of single kernels, scheduling knobs read from the environment.  The product library
+ * libdsmgp_hip.so contains none of this code and none of these symbols (tests/test_host_cpu.py checks).
+ */
+#ifndef DSMGP_HIP_DIAG_H
+#define DSMGP_HIP_DIAG_H
+
+#include "dsmgp_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* diagnostic: f64 MFMA vs f64 VALU FMA rates alone and co-issued: out[9] = {mfma TF/s, valu TF/s, ms} x {MFMA only, VALU only, both} */
+int dsmgp_probe_coissue(dsmgp_ctx* ctx, double* out);
+/* diagnostic: seconds per launch of the tile GEMM on a uniform batch of ntiles tiles of depth K
+ * (mode 0: own A panel per tile, B panel shared by `group` tiles; mode 1: all operands shared, L2-resident) */
+int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,
+                     double* seconds_per_launch);
+
+/* diagnostic: chol_diag_kernel on `ntiles` independent SPD 128x128 blocks (leading dimension ld >= 128):
+ * kernel_us = average launch time; phases_us[23]: [0..18] time between the kernel's 20 in-kernel stamps on block 0
+ * (load, then P1/P2 of the 8 block columns, store, fused z), [19..22] wave 0's share of the fourth P2
+ * (block product, LDS reads, potrf_inv16 in registers, LDS writes) */
+int dsmgp_probe_diag(dsmgp_ctx* ctx, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

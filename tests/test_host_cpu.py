@@ -244,6 +244,69 @@ def test_two_rank_gloo_sharding_reproduces_the_single_process_result(tmp_path):
         assert " ok " in o
 
 
+_EMPTY_RANK_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as td
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import deepstructuredmixtures_amd as dsm
+from oracle_context import OracleContext
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+td.init_process_group("gloo", rank=rank, world_size=world)
+X = dsm.datagen.uniform(5, 0, 120).reshape((60, 2), order="F")
+y = np.sin(3 * X[:, 0])
+Xt = dsm.datagen.uniform(6, 0, 20).reshape((10, 2), order="F")
+ref = dsm.buildBCM(X, y, 4, M=100, ctx=OracleContext(), kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.2))
+mr, vr = dsm.predict(ref, Xt)
+# one leaf, two ranks: rank 1 owns nothing and must still take part in every exchange
+m = dsm.buildBCM(X, y, 4, M=100, ctx=OracleContext(), kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.2),
+                 shard_world=(rank, world))
+assert m.L == 1 and len(m.shard.local) == (1 if rank == 0 else 0)
+assert np.array_equal(m.leaf_mll, ref.leaf_mll)
+mu, var = dsm.predict(m, Xt)
+assert np.array_equal(mu, mr) and np.array_equal(var, vr)
+g = dsm.updategradients(m)
+assert g.shape == (1, 3) and np.all(np.isfinite(g))
+_, hist = dsm.train(m, dsm.ADAM(eta=0.01), iterations=2, randinit=False)
+assert len(hist) == 2
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok", len(m.shard.local))
+"""
+
+
+def test_rank_without_leaves_joins_the_collectives(tmp_path):
+    """Fewer leaf groups than ranks: the idle rank makes no device call and contributes empty parts."""
+    script = tmp_path / "worker.py"
+    script.write_text(_EMPTY_RANK_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert " ok " in o
+
+
+def test_product_library_has_no_diagnostic_code():
+    """ablation / stamp / probe variants live only in the -DDSMGP_DIAG build; the product library
+    exports none of their symbols and reads no tuning variables from the environment."""
+    if not os.path.exists(hipabi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", hipabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for pat in ("stamp", "coissue", "bench_tile", "probe_diag", "_v3", "ablat"):
+        assert pat not in out.lower(), pat
+    blob = open(hipabi.LIB_PATH, "rb").read()
+    for var in (b"DSMGP_TILE_V", b"DSMGP_XCD", b"DSMGP_TAIL_SPLIT", b"DSMGP_TAIL_ROUNDS", b"DSMGP_STAMPS"):
+        assert var not in blob, var
+    hdr = open(os.path.join(ROOT, "include", "dsmgp_hip_diag.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*|int64_t)\s+(dsmgp_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(hipabi.DIAG_SIGNATURES), declared ^ set(hipabi.DIAG_SIGNATURES)
+    lib = ctypes.CDLL(hipabi.LIB_PATH)
+    for name in declared:
+        assert not hasattr(lib, name), name
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     """Loads libdsmgp_hip.so (no compute) and checks it exports exactly what include/dsmgp_hip.h declares."""
     hdr = open(os.path.join(ROOT, "include", "dsmgp_hip.h")).read()

@@ -1,7 +1,7 @@
 import sys
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepstructuredmixtures_amd import hipabi
-ctx = hipabi.Context(0)
+ctx = hipabi.Context(0, diag=True)
 for K in (128, 256, 512):
     for nt in (2048, 8192):
         for mode in (0, 1):

@@ -3,7 +3,7 @@ launch (K sweep at one tile per CU) and whole split-K steps as UpdateSplitter sc
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepstructuredmixtures_amd import hipabi
-ctx = hipabi.Context(0)
+ctx = hipabi.Context(0, diag=True)
 print("one tile per CU, K sweep (mode 0)")
 for K in (16, 32, 64, 128, 256, 512, 720):
     tf = ctx.bench_tile(256, K, 0, 18, 10)

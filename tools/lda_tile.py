@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepstructuredmixtures_amd import hipabi
-ctx = hipabi.Context(0)
+ctx = hipabi.Context(0, diag=True)
 K = 4096
 print("contiguous panels (lda=128):", round(ctx.bench_tile(1536, K, 0, 16, 3), 2))
 for g in (2, 4, 5, 6, 8, 11, 16, 48):

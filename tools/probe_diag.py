@@ -5,7 +5,7 @@ from deepstructuredmixtures_amd import hipabi
 
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 144
 ld = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-ctx = hipabi.Context(0)
+ctx = hipabi.Context(0, diag=True)
 for n in (1, 18, nt):
     us, ph = ctx.probe_diag(n, ld)
     names = ["load"] + [f"J{j}.{p}" for j in range(8) for p in ("P1", "P2")] + ["store", "z"]

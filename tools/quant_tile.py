@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepstructuredmixtures_amd import hipabi
-ctx = hipabi.Context(0)
+ctx = hipabi.Context(0, diag=True)
 for K in (2048, 6144):
     for n in (260, 516, 772, 1028, 1540, 2048, 2646, 4096, 6000):
         r = []
