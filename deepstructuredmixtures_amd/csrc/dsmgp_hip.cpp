@@ -273,6 +273,18 @@ struct dsmgp_ctx {
     bool predicted = false;
     int64_t route_total = 0;
 
+    // aggregation of the leaf moments per test row + scores (dsmgp_aggregate*, dsmgp_scores)
+    int64_t* d_row_ptr = nullptr;   // n_t + 1: entries of every test row (built by set_test)
+    int32_t* d_row_ent = nullptr;   // entry positions, ascending per row
+    int32_t* d_ent_leaf = nullptr;  // leaf of every entry position
+    double* d_agg_part = nullptr;   // W x n_t partial sums
+    size_t agg_part_cap = 0;
+    double* d_agg_coef = nullptr;   // L
+    int32_t* d_agg_group = nullptr; // L
+    double* d_agg_out = nullptr;    // mu | var (n_t each) | y_test (n_t) | score block sums
+    int agg_family = -1, agg_G = 0, agg_W = 0;
+    bool agg_partial_ready = false, agg_done = false;
+
     // gradients (built on first use)
     bool grad_ready = false;
     double* arenaX = nullptr;       // Xt = L^-T per factor owner, npad x npad
@@ -405,6 +417,15 @@ void free_test(dsmgp_ctx* c) {
     dev_free(c->dXt);
     dev_free(c->d_route_ptr);
     dev_free(c->d_route_idx);
+    dev_free(c->d_row_ptr);
+    dev_free(c->d_row_ent);
+    dev_free(c->d_ent_leaf);
+    dev_free(c->d_agg_part);
+    dev_free(c->d_agg_coef);
+    dev_free(c->d_agg_group);
+    dev_free(c->d_agg_out);
+    c->agg_part_cap = 0;
+    c->agg_partial_ready = c->agg_done = false;
     arena_put(c, c->arenaVt);
     arena_put(c, c->arenaXt);
     arena_put(c, c->arenaPV);
@@ -1311,6 +1332,27 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     HIPCHK(c, hipMemcpy(c->d_route_ptr, route_ptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_route_idx, std::max<int64_t>(1, total) * sizeof(int64_t)));
     if (total) HIPCHK(c, hipMemcpy(c->d_route_idx, route_idx, total * sizeof(int64_t), hipMemcpyHostToDevice));
+    {
+        // per test row, the (leaf, row) entries that carry its moments, in ascending entry order (= leaf order):
+        // the index agg_partial_kernel walks
+        if (total > (int64_t)INT32_MAX) return fail(c, DSMGP_E_ARG, "set_test: more than 2^31 routed rows");
+        std::vector<int64_t> rptr((size_t)n_t + 1, 0);
+        for (int64_t i = 0; i < total; ++i) rptr[route_idx[i] + 1]++;
+        for (int64_t r = 0; r < n_t; ++r) rptr[r + 1] += rptr[r];
+        std::vector<int32_t> rent((size_t)std::max<int64_t>(1, total)), eleaf((size_t)std::max<int64_t>(1, total));
+        std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+        for (int l = 0; l < L; ++l)
+            for (int64_t i = route_ptr[l]; i < route_ptr[l + 1]; ++i) {
+                rent[fill[route_idx[i]]++] = (int32_t)i;
+                eleaf[i] = l;
+            }
+        HIPCHK(c, hipMalloc(&c->d_row_ptr, ((size_t)n_t + 1) * sizeof(int64_t)));
+        HIPCHK(c, hipMalloc(&c->d_row_ent, rent.size() * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc(&c->d_ent_leaf, eleaf.size() * sizeof(int32_t)));
+        HIPCHK(c, hipMemcpy(c->d_row_ptr, rptr.data(), rptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_row_ent, rent.data(), rent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_ent_leaf, eleaf.data(), eleaf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     if (int rc = arena_get(c, c->arenaVt, vTot)) return rc;
     if (int rc = arena_get(c, c->arenaXt, xTot)) return rc;
     if (int rc = arena_get(c, c->arenaPV, pTot)) return rc;
@@ -1506,6 +1548,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     c->timings[12] = ms * 1e-3;
     if (seconds) *seconds = ms * 1e-3;
     c->predicted = true;
+    c->agg_partial_ready = c->agg_done = false;
     return 0;
 }
 
@@ -1525,6 +1568,127 @@ int dsmgp_predict_leaves(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int6
     if (int rc = dsmgp_set_test(c, Xt, n_t, route_ptr, route_idx)) return rc;
     if (int rc = dsmgp_predict_run(c, nullptr)) return rc;
     return dsmgp_predict_fetch(c, mu_out, var_out);
+}
+
+// -------------------------------------------------------------------------------------------------
+// predict(model, x): aggregation over the leaves of every test row, and the score functions, on the device
+namespace {
+int agg_width(int family, int G) { return family == AGG_MIXTURE ? 3 : (family == AGG_RBCM ? 2 * G : 2); }
+}  // namespace
+
+int dsmgp_aggregate_partial(dsmgp_ctx* c, int32_t family, const double* leaf_coef, const int32_t* leaf_group,
+                            int32_t n_groups, double* partial_out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->predicted) return fail(c, DSMGP_E_STATE, "aggregate before predict_run");
+    if (family < AGG_MIXTURE || family > AGG_RBCM) return fail(c, DSMGP_E_ARG, "aggregate: unknown family");
+    if (family == AGG_RBCM) {
+        if (!leaf_group || n_groups <= 0 || n_groups > 4096) return fail(c, DSMGP_E_ARG, "aggregate: rBCM needs leaf groups");
+        for (int l = 0; l < c->L; ++l)
+            if (leaf_group[l] < 0 || leaf_group[l] >= n_groups) return fail(c, DSMGP_E_ARG, "aggregate: leaf group out of range");
+    } else if (!leaf_coef) {
+        return fail(c, DSMGP_E_ARG, "aggregate: leaf_coef is NULL");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int L = c->L;
+    const int G = family == AGG_RBCM ? n_groups : 0;
+    const int W = agg_width(family, G);
+    const size_t need = (size_t)W * (size_t)c->n_t;
+    if (need > c->agg_part_cap) {
+        dev_free(c->d_agg_part);
+        HIPCHK(c, hipMalloc(&c->d_agg_part, need * sizeof(double)));
+        c->agg_part_cap = need;
+    }
+    if (!c->d_agg_coef) HIPCHK(c, hipMalloc(&c->d_agg_coef, (size_t)L * sizeof(double)));
+    if (!c->d_agg_group) HIPCHK(c, hipMalloc(&c->d_agg_group, (size_t)L * sizeof(int32_t)));
+    if (leaf_coef) HIPCHK(c, hipMemcpyAsync(c->d_agg_coef, leaf_coef, (size_t)L * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (family == AGG_RBCM)
+        HIPCHK(c, hipMemcpyAsync(c->d_agg_group, leaf_group, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    AggArgs a{};
+    a.row_ptr = c->d_row_ptr;
+    a.row_ent = c->d_row_ent;
+    a.ent_leaf = c->d_ent_leaf;
+    a.mu = c->arenaPV;
+    a.var = c->arenaPV + (size_t)c->route_total;
+    a.coef = c->d_agg_coef;
+    a.group = c->d_agg_group;
+    a.part = c->d_agg_part;
+    a.n_t = c->n_t;
+    a.family = family;
+    a.G = G;
+    agg_partial_kernel<<<(unsigned)((c->n_t + 255) / 256), 256, 0, c->stream>>>(a);
+    HIPCHK(c, hipGetLastError());
+    if (partial_out) HIPCHK(c, hipMemcpyAsync(partial_out, c->d_agg_part, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // leaf_coef / leaf_group are the caller's
+    c->agg_family = family;
+    c->agg_G = G;
+    c->agg_W = W;
+    c->agg_partial_ready = true;
+    c->agg_done = false;
+    return 0;
+}
+
+int dsmgp_aggregate_finish(dsmgp_ctx* c, const double* partial_in, int32_t plain, int32_t prior_kernel_id,
+                           double* mu_out, double* var_out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->agg_partial_ready) return fail(c, DSMGP_E_STATE, "aggregate_finish before aggregate_partial");
+    if (c->agg_family == AGG_RBCM &&
+        (prior_kernel_id < 0 || prior_kernel_id >= (int)c->hyper.size() || c->hyper[prior_kernel_id].kind < 0))
+        return fail(c, DSMGP_E_ARG, "aggregate_finish: rBCM needs the kernel id of the model's first leaf");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nt = (size_t)c->n_t;
+    const size_t nblk = (nt + 255) / 256;
+    if (!c->d_agg_out) HIPCHK(c, hipMalloc(&c->d_agg_out, (3 * nt + 3 * nblk + 8) * sizeof(double)));
+    if (partial_in)   // sums over all ranks / contexts, added by the caller
+        HIPCHK(c, hipMemcpyAsync(c->d_agg_part, partial_in, (size_t)c->agg_W * nt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    agg_finish_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(c->d_agg_part, c->n_t, c->agg_family, c->agg_G, plain ? 1 : 0,
+                                                           c->d_kp, c->agg_family == AGG_RBCM ? prior_kernel_id : 0, c->dXt,
+                                                           c->D, c->d_agg_out, c->d_agg_out + nt);
+    HIPCHK(c, hipGetLastError());
+    if (mu_out) HIPCHK(c, hipMemcpyAsync(mu_out, c->d_agg_out, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (var_out) HIPCHK(c, hipMemcpyAsync(var_out, c->d_agg_out + nt, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->agg_done = true;
+    return 0;
+}
+
+int dsmgp_aggregate(dsmgp_ctx* c, int32_t family, const double* leaf_coef, const int32_t* leaf_group, int32_t n_groups,
+                    int32_t plain, int32_t prior_kernel_id, double* mu_out, double* var_out) {
+    if (int rc = dsmgp_aggregate_partial(c, family, leaf_coef, leaf_group, n_groups, nullptr)) return rc;
+    return dsmgp_aggregate_finish(c, nullptr, plain, prior_kernel_id, mu_out, var_out);
+}
+
+int dsmgp_scores(dsmgp_ctx* c, const double* y_test, double* out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->agg_done) return fail(c, DSMGP_E_STATE, "scores before aggregate");
+    if (!y_test || !out) return fail(c, DSMGP_E_ARG, "scores: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nt = (size_t)c->n_t;
+    const size_t nblk = (nt + 255) / 256;
+    double* dy = c->d_agg_out + 2 * nt;
+    double* dsum = dy + nt;
+    HIPCHK(c, hipMemcpyAsync(dy, y_test, nt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    std::vector<double> blk(3 * nblk);
+    auto pass = [&](int which, double mse, double mae, double (&tot)[3]) -> int {
+        agg_scores_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(dy, c->d_agg_out, c->d_agg_out + nt, c->n_t, which, mse, mae, dsum);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(blk.data(), dsum, blk.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        tot[0] = tot[1] = tot[2] = 0.0;
+        for (size_t b = 0; b < nblk; ++b)
+            for (int k = 0; k < 3; ++k) tot[k] += blk[3 * b + k];
+        return 0;
+    };
+    double t0[3], t1[3];
+    if (int rc = pass(0, 0.0, 0.0, t0)) return rc;
+    const double n = (double)nt;
+    const double mse = t0[0] / n, mae = t0[1] / n;
+    if (int rc = pass(1, mse, mae, t1)) return rc;
+    out[0] = mse;                                                        // mse  src/scorefunctions.jl:8
+    out[1] = nt > 1 ? std::sqrt(t1[0] / (n - 1.0)) / std::sqrt(n) : NAN; // sse  :9  (std = unbiased)
+    out[2] = mae;                                                        // mae  :13
+    out[3] = nt > 1 ? std::sqrt(t1[1] / (n - 1.0)) / std::sqrt(n) : NAN; // sae  :14
+    out[4] = t0[2] / n;                                                  // nlpd :16
+    return 0;
 }
 
 namespace {

@@ -1201,6 +1201,166 @@ __global__ __launch_bounds__(256) void dots_kernel(const LeafDev* __restrict__ l
 }
 
 // ---------------------------------------------------------------------------------------------
+// predict(model, x): sum/product aggregation of the leaf moments over the leaves every test row visits
+// (src/common.jl:134-149,198-302) and the score functions (src/scorefunctions.jl:6-16), on the moments left in HBM
+// by pred_finish_kernel.  All four model families reduce to per-row sums over (leaf, row) entries:
+//   mixture (DSMGP, :275-302): the nested log-domain recursion is linear in (mu, mu^2, sigma^2) -- unrolled it is the
+//       flat mixture with weight W_l = product of the sum-node weights on leaf l's path: S0 = sum W mu,
+//       S1 = sum W mu^2, S2 = sum W sigma^2 (sigma^2 <= 0 -> 1e-8, :137); mu = S0, var = S2 + S1 - S0^2
+//   PoE / gPoE (:145-149,198-222): t = 1/sigma^2; S0 = sum beta t mu, S1 = sum beta t (beta = 1 resp. 1/#root children)
+//   rBCM (:224-241): per root child g the PoE sums (S_g0, S_g1) = (sum t mu, sum t); combined in agg_finish_kernel
+// Partial sums are stored [k][row] (W vectors of length n_t): with leaves sharded over ranks or contexts each one
+// produces its partial sums and they are added before the finish step.  One thread per test row walks that row's
+// entries in ascending entry order (= leaf order): fixed summation order, no atomics.
+constexpr int AGG_MIXTURE = 0, AGG_POE = 1, AGG_GPOE = 2, AGG_RBCM = 3;
+
+struct AggArgs {
+    const int64_t* row_ptr;     // n_t + 1: entries of every test row
+    const int32_t* row_ent;     // entry positions (index into mu / var), ascending per row
+    const int32_t* ent_leaf;    // leaf of every entry position
+    const double* mu;           // per (leaf, routed row), route order
+    const double* var;
+    const double* coef;         // per leaf: W_l (mixture) or beta_l (PoE / gPoE); unused for rBCM
+    const int32_t* group;       // per leaf: root child (rBCM); else unused
+    double* part;               // W x n_t
+    int64_t n_t;
+    int family;
+    int G;                      // rBCM: number of groups
+};
+
+__global__ __launch_bounds__(256) void agg_partial_kernel(AggArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_t) return;
+    const int64_t e0 = a.row_ptr[r], e1 = a.row_ptr[r + 1];
+    if (a.family == AGG_MIXTURE) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int64_t e = e0; e < e1; ++e) {
+            const int pos = a.row_ent[e];
+            const double w = a.coef[a.ent_leaf[pos]];
+            const double m = a.mu[pos];
+            double v = a.var[pos];
+            if (v <= 0.0) v = 1e-8;                               // src/common.jl:137
+            s0 += w * m;
+            s1 += w * (m * m);
+            s2 += w * v;
+        }
+        a.part[r] = s0;
+        a.part[a.n_t + r] = s1;
+        a.part[2 * a.n_t + r] = s2;
+    } else if (a.family == AGG_RBCM) {
+        for (int g = 0; g < a.G; ++g) {
+            a.part[(size_t)(2 * g) * a.n_t + r] = 0.0;
+            a.part[(size_t)(2 * g + 1) * a.n_t + r] = 0.0;
+        }
+        for (int64_t e = e0; e < e1; ++e) {
+            const int pos = a.row_ent[e];
+            const int g = a.group[a.ent_leaf[pos]];
+            const double t = 1.0 / a.var[pos];                    // src/common.jl:148
+            a.part[(size_t)(2 * g) * a.n_t + r] += t * a.mu[pos];
+            a.part[(size_t)(2 * g + 1) * a.n_t + r] += t;
+        }
+    } else {
+        double s0 = 0.0, s1 = 0.0;
+        for (int64_t e = e0; e < e1; ++e) {
+            const int pos = a.row_ent[e];
+            const double bt = a.coef[a.ent_leaf[pos]] * (1.0 / a.var[pos]);
+            s0 += bt * a.mu[pos];
+            s1 += bt;
+        }
+        a.part[r] = s0;
+        a.part[a.n_t + r] = s1;
+    }
+}
+
+// Finish step on the (summed) partial sums: mu / var of predict(model, x), left in HBM for agg_scores_kernel.
+// plain: the root is a single GP (predict(node::GPNode), src/common.jl:175-179): no mixture term.
+// rBCM: s = k(x*, x*) + noise of the model's first leaf (leftGP, :227-228).
+__global__ __launch_bounds__(256) void agg_finish_kernel(const double* __restrict__ part, int64_t n_t, int family, int G,
+                                                         int plain, const KParam* __restrict__ kp, int prior_kid,
+                                                         const double* __restrict__ Xt, int D,
+                                                         double* __restrict__ mu_out, double* __restrict__ var_out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_t) return;
+    if (family == AGG_MIXTURE) {
+        const double m = part[r], m2 = part[n_t + r], sv = part[2 * n_t + r];
+        mu_out[r] = m;
+        var_out[r] = plain ? sv : sv + (m2 - m * m);              // src/common.jl:299-300
+    } else if (family == AGG_RBCM) {
+        const KParam p = kp[prior_kid];
+        double kss;
+        if (p.kind == 0) kss = p.sigma2;
+        else if (p.kind == 1) kss = p.sigma2 * (double)D;
+        else {
+            double q = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double x = Xt[r + (size_t)d * n_t];
+                q = fma(x, x, q);
+            }
+            kss = q / p.l2[0];
+        }
+        const double s = kss + p.noise;
+        double C = 1.0 / s, m = 0.0;
+        for (int g = 0; g < G; ++g) {
+            const double T = part[(size_t)(2 * g + 1) * n_t + r];
+            if (T == 0.0) continue;                               // no leaf of this child saw the row
+            const double M = part[(size_t)(2 * g) * n_t + r] / T; // mu_ of the child (:205)
+            const double beta = 0.5 * (log(s) - log(1.0 / T));    // :234-235
+            C += beta * T - beta / s;                             // :236
+            m += M * (beta * T);                                  // :237
+        }
+        mu_out[r] = m / C;
+        var_out[r] = 1.0 / C;
+    } else {
+        const double t = part[n_t + r];
+        mu_out[r] = part[r] / t;
+        var_out[r] = 1.0 / t;
+    }
+}
+
+// Score sums (src/scorefunctions.jl:6-16) in two passes for the standard errors: pass 0 sums se, ae and the nlpd
+// terms; pass 1 sums (se - mean se)^2 and (ae - mean ae)^2.  Per-block tree reduction, blocks combined in block order
+// by the host: fixed summation order.
+__global__ __launch_bounds__(256) void agg_scores_kernel(const double* __restrict__ y, const double* __restrict__ mu,
+                                                         const double* __restrict__ var, int64_t n_t, int pass,
+                                                         double mean_se, double mean_ae, double* __restrict__ out) {
+    __shared__ double red[3][256];
+    const int t = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * 256 + t;
+    double a = 0.0, b = 0.0, c = 0.0;
+    if (r < n_t) {
+        const double d = y[r] - mu[r];
+        const double se = d * d, ae = fabs(d);
+        if (pass == 0) {
+            a = se;
+            b = ae;
+            const double sd = sqrt(var[r]);                       // Normal(mu, sqrt(var)), :16
+            const double zz = d / sd;
+            c = 0.5 * (zz * zz + 1.8378770664093454835606594728112) + log(sd);
+        } else {
+            a = (se - mean_se) * (se - mean_se);
+            b = (ae - mean_ae) * (ae - mean_ae);
+        }
+    }
+    red[0][t] = a;
+    red[1][t] = b;
+    red[2][t] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            red[0][t] += red[0][t + o];
+            red[1][t] += red[1][t + o];
+            red[2][t] += red[2][t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[3 * (size_t)blockIdx.x] = red[0][0];
+        out[3 * (size_t)blockIdx.x + 1] = red[1][0];
+        out[3 * (size_t)blockIdx.x + 2] = red[2][0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // f64 MFMA issue-rate probe: register-only chains, 4 independent accumulators per wave.  Lane 0 of
 // every wave also records shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) so the
 // host can report cycles per MFMA and the clock the chip holds under this load.

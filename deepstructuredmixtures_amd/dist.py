@@ -87,6 +87,19 @@ class Shard:
         td.all_gather(out, buf)
         return [o.cpu().numpy() for o in out]
 
+    def allgather_sum(self, local):
+        """Sum over ranks of one fixed-shape float64 array per rank (the partial sums of the predict aggregation:
+        W x n_t doubles), as ONE all-gather followed by additions in rank order on every rank -- the same bits
+        everywhere, which an all-reduce does not promise."""
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        if self.world == 1:
+            return local.copy()
+        parts = self._all_gather_padded(local.reshape(-1), local.size)
+        tot = parts[0].copy()
+        for p in parts[1:]:
+            tot += p
+        return tot.reshape(local.shape)
+
     def gather_leaf_values(self, local_vals):
         """local_vals[i] belongs to leaf self.local[i]; returns the value of every leaf."""
         L = self.owner.size

@@ -11,6 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 
 N_TIMINGS = 14
+AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
+SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
+
+
+def agg_width(family, n_groups=0):
+    """Number of partial-sum vectors (of length n_t) the aggregation of a family exchanges."""
+    return 3 if family == AGG_MIXTURE else (2 * int(n_groups) if family == AGG_RBCM else 2)
 TIMING_NAMES = ("gram", "chol_update", "chol_diag", "chol_trsm", "solve", "mll", "predict_gram",
                 "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce")
 
@@ -35,6 +42,10 @@ SIGNATURES = {
     "dsmgp_predict_fetch": (C.c_int, [_ctx, _dp, _dp]),
     "dsmgp_predict_leaves": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp, _dp, _dp]),
     "dsmgp_gradients": (C.c_int, [_ctx, _dp, C.c_int32]),
+    "dsmgp_aggregate": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
+    "dsmgp_aggregate_partial": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, _dp]),
+    "dsmgp_aggregate_finish": (C.c_int, [_ctx, _dp, C.c_int32, C.c_int32, _dp, _dp]),
+    "dsmgp_scores": (C.c_int, [_ctx, _dp, _dp]),
     "dsmgp_kernel_matrix": (C.c_int, [_ctx, C.c_int32, _dp, C.c_int64, _dp, C.c_int64, _dp]),
     "dsmgp_download_factor": (C.c_int, [_ctx, C.c_int32, _dp, _dp]),
     "dsmgp_set_profile": (C.c_int, [_ctx, C.c_int32]),
@@ -134,6 +145,7 @@ class Context:
         self.L = 0
         self.D = 0
         self.route_total = 0
+        self.n_t = 0
 
     def _chk(self, rc):
         if rc != 0:
@@ -198,6 +210,7 @@ class Context:
         route_idx, p1 = _i64(route_idx)
         self._chk(self.lib.dsmgp_set_test(self.h, px, Xt.shape[0], p0, p1))
         self.route_total = int(route_ptr[-1])
+        self.n_t = int(Xt.shape[0])
 
     def predict_run(self):
         sec = C.c_double(0.0)
@@ -220,6 +233,53 @@ class Context:
         self._chk(self.lib.dsmgp_gradients(self.h, g.ctypes.data_as(_dp), int(stride)))
         return g
 
+    # ---- predict(model, x) aggregation + scores on the device (src/common.jl:134-302, src/scorefunctions.jl) ----
+    def _agg_args(self, family, leaf_coef, leaf_group):
+        coef = pc = grp = pg = None
+        if leaf_coef is not None:
+            coef, pc = _f64(leaf_coef)
+            assert coef.size == self.L
+        if leaf_group is not None:
+            grp, pg = _i32(leaf_group)
+            assert grp.size == self.L
+        return coef, pc, grp, pg
+
+    def aggregate(self, family, leaf_coef=None, leaf_group=None, n_groups=0, plain=False, prior_kernel_id=0, fetch=True):
+        """(mu, var) of length n_t from the moments of the last predict_run; fetch=False leaves them in HBM (scores)."""
+        coef, pc, grp, pg = self._agg_args(family, leaf_coef, leaf_group)
+        mu = np.empty(self.n_t) if fetch else None
+        var = np.empty(self.n_t) if fetch else None
+        self._chk(self.lib.dsmgp_aggregate(self.h, int(family), pc, pg, int(n_groups), 1 if plain else 0, int(prior_kernel_id),
+                                           mu.ctypes.data_as(_dp) if fetch else None,
+                                           var.ctypes.data_as(_dp) if fetch else None))
+        return mu, var
+
+    def aggregate_partial(self, family, leaf_coef=None, leaf_group=None, n_groups=0):
+        """This context's partial sums, shape (W, n_t): what ranks / contexts exchange and add."""
+        coef, pc, grp, pg = self._agg_args(family, leaf_coef, leaf_group)
+        part = np.empty((agg_width(family, n_groups), self.n_t))
+        self._chk(self.lib.dsmgp_aggregate_partial(self.h, int(family), pc, pg, int(n_groups), part.ctypes.data_as(_dp)))
+        return part
+
+    def aggregate_finish(self, partial=None, plain=False, prior_kernel_id=0, fetch=True):
+        pp = None
+        if partial is not None:
+            partial, pp = _f64(partial)
+        mu = np.empty(self.n_t) if fetch else None
+        var = np.empty(self.n_t) if fetch else None
+        self._chk(self.lib.dsmgp_aggregate_finish(self.h, pp, 1 if plain else 0, int(prior_kernel_id),
+                                                  mu.ctypes.data_as(_dp) if fetch else None,
+                                                  var.ctypes.data_as(_dp) if fetch else None))
+        return mu, var
+
+    def scores(self, y_test):
+        """dict(mse, sse, mae, sae, nlpd) of the aggregated prediction still on the device."""
+        y, py = _f64(y_test)
+        assert y.size == self.n_t
+        out = np.zeros(5)
+        self._chk(self.lib.dsmgp_scores(self.h, py, out.ctypes.data_as(_dp)))
+        return dict(zip(SCORE_NAMES, out.tolist()))
+
     def kernel_matrix(self, kernel_id, x1, x2):
         x1, p1 = _f64_fortran(x1)
         x2, p2 = _f64_fortran(x2)
@@ -228,10 +288,12 @@ class Context:
                                                K.ctypes.data_as(_dp)))
         return K
 
-    def download_factor(self, leaf, n):
-        F = np.empty((n, n), order="F")
+    def download_factor(self, leaf, n, factor=True):
+        """(gp.cK.factors lower triangle, gp.alpha) of one leaf; factor=False fetches alpha only (F is None)."""
+        F = np.empty((n, n), order="F") if factor else None
         alpha = np.empty(n)
-        self._chk(self.lib.dsmgp_download_factor(self.h, int(leaf), F.ctypes.data_as(_dp), alpha.ctypes.data_as(_dp)))
+        self._chk(self.lib.dsmgp_download_factor(self.h, int(leaf), F.ctypes.data_as(_dp) if factor else None,
+                                                 alpha.ctypes.data_as(_dp)))
         return F, alpha
 
     def set_joint(self, on):
@@ -454,6 +516,16 @@ class MultiContext:
         self.predict_run()
         return self.predict_fetch()
 
+    def aggregate_partial(self, family, leaf_coef=None, leaf_group=None, n_groups=0):
+        """Partial sums of all sub-contexts added in context order (the sums are linear in the leaves)."""
+        coef = None if leaf_coef is None else np.asarray(leaf_coef, dtype=np.float64)
+        grp = None if leaf_group is None else np.asarray(leaf_group, dtype=np.int32)
+        tot = None
+        for s, loc in zip(self.act, self.part):
+            p = s.aggregate_partial(family, None if coef is None else coef[loc], None if grp is None else grp[loc], n_groups)
+            tot = p if tot is None else tot + p
+        return tot
+
     def gradients(self, stride):
         self._upload()
         res = self._each(lambda s: s.gradients(stride))
@@ -519,6 +591,7 @@ class StreamingContext:
         self._hyper = {}
         self._test = None
         self.want_gradients = 0        # stride of the gradient rows to collect during the pass (0 = none)
+        self.keep_alpha = ()           # global leaf ids whose alpha is fetched before their group is released
         self.groups = None
         self._res = None               # results of the last pass
         self.passes = 0
@@ -629,6 +702,7 @@ class StreamingContext:
         mu = np.empty(self.route_total)
         var = np.empty(self.route_total)
         grads = np.zeros((self.L, self.want_gradients)) if self.want_gradients else None
+        alphas = {}
         seconds, tpred = 0.0, 0.0
         tsum = {}
         flops, launches = 0.0, 0
@@ -673,6 +747,10 @@ class StreamingContext:
                     pos += k
             if self.want_gradients:
                 grads[loc] = c.gradients(self.want_gradients)
+            for g in self.keep_alpha:
+                li = np.flatnonzero(loc == g)
+                if li.size:
+                    alphas[int(g)] = c.download_factor(int(li[0]), int(ptr[g + 1] - ptr[g]), factor=False)[1]
             for k_, v_ in c.timings().items():
                 tsum[k_] = tsum.get(k_, 0.0) + v_
             f_, n_ = c.work()
@@ -682,7 +760,7 @@ class StreamingContext:
         self.passes += 1
         self.host_seconds = host
         self._res = dict(mll=mll, info=info, mu=mu, var=var, grads=grads, seconds=seconds, tpred=tpred, timings=tsum,
-                         work=(flops, launches), has_test=self._test is not None)
+                         work=(flops, launches), has_test=self._test is not None, alpha=alphas)
 
     def fit(self):
         self._pass()
@@ -714,6 +792,10 @@ class StreamingContext:
 
     def work(self):
         return self._res["work"] if self._res else (0.0, 0)
+
+    def alpha(self, leaf):
+        """alpha of a leaf listed in `keep_alpha` before the last pass (factors themselves are discarded)."""
+        return self._res["alpha"][int(leaf)]
 
     def memory(self):
         return self.ctx.memory()

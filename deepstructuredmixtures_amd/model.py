@@ -701,7 +701,9 @@ def resident_test(model, xtest, tau=0.05):
 
 
 def predict(model, xtest):
-    """`predict(model, x)` -> (mu, var) of length n_t (`src/common.jl:294-307`)."""
+    """`predict(model, x)` -> (mu, var) of length n_t (`src/common.jl:294-307`).  The per-(leaf, row) moments stay on
+    the device and are aggregated there (`dsmgp_aggregate*`); contexts without that entry (the streaming context, whose
+    moments are on the host anyway) use the host rules below."""
     if isinstance(model, GaussianProcess):
         mu, var = prediction(model, xtest)
         var = np.where(var <= 0, EPS, var)
@@ -710,10 +712,90 @@ def predict(model, xtest):
     if xt.ndim == 1:
         xt = xt.reshape(-1, 1)
     rc = _routing(model, xt)
+    model._scores_on_device = False
+    if hasattr(_ctx_type(model), "aggregate_partial"):       # decided by the model's construction: the same on every rank
+        return _predict_device(model, xt, rc)
     mu, var = _leaf_moments(model, xt, rc)
     if model.family == "dsmgp":
         return _aggregate_dsmgp_flat(model, xt.shape[0], rc, mu, var)
     return _aggregate_poe(model, xt, rc["ptr"], mu, var)
+
+
+def _ctx_type(model):
+    """Type of the model's device context without creating it (a rank that owns no leaves never does)."""
+    if model._ctx is not None:
+        return type(model._ctx)
+    if model._stream_budget is not None:
+        return hipabi.StreamingContext
+    return hipabi.MultiContext if model._n_sub > 1 else hipabi.Context
+
+
+def _aggregation_spec(model):
+    """(family, leaf_coef, leaf_group, n_groups, plain, prior_leaf) of `dsmgp_aggregate` for this model."""
+    root = model.root
+    if model.family == "dsmgp":
+        return hipabi.AGG_MIXTURE, np.exp(model.tindex.leaf_path_logweights()), None, 0, root.kind == "gp", None
+    if root.kind == "gp" or model.family == "poe":
+        return hipabi.AGG_POE, np.ones(model.L), None, 0, False, None
+    if model.family == "gpoe":
+        return hipabi.AGG_GPOE, np.full(model.L, 1.0 / len(root.children)), None, 0, False, None      # src/common.jl:215
+    group = np.zeros(model.L, dtype=np.int32)
+    for g, c in enumerate(root.children):                                                                 # :231
+        for lf in get_leaves(c):
+            group[lf.leaf] = g
+    return hipabi.AGG_RBCM, None, group, len(root.children), False, model.leaves[0]
+
+
+def _finish_partial(model, xt, family, part, n_groups, plain, prior_leaf):
+    """Host form of `agg_finish_kernel` on summed partial sums (several ranks or contexts hold the leaves)."""
+    if family == hipabi.AGG_MIXTURE:
+        m = part[0]
+        return m, (part[2] if plain else part[2] + (part[1] - m * m))
+    if family != hipabi.AGG_RBCM:
+        return part[0] / part[1], 1.0 / part[1]
+    s = _prior_diag(prior_leaf, xt) + np.exp(2 * prior_leaf.logNoise)
+    Cc = 1.0 / s
+    m = np.zeros(xt.shape[0])
+    for g in range(n_groups):
+        T = part[2 * g + 1]
+        M = part[2 * g] / T
+        beta = 0.5 * (np.log(s) - np.log(1.0 / T))
+        Cc = Cc + (beta * T) - (beta / s)
+        m = m + M * (beta * T)
+    return m / Cc, 1.0 / Cc
+
+
+def _predict_device(model, xt, rc):
+    family, coef, group, G, plain, prior = _aggregation_spec(model)
+    loc = model.shard.local
+    have = len(loc) > 0
+    if have:
+        if not rc["uploaded"]:
+            model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
+            rc["uploaded"] = True
+        model.last_predict_seconds = model.ctx.predict_run()
+    single = model.shard.world == 1 and isinstance(model.ctx, hipabi.Context)
+    if single:      # one context holds every leaf: partial sums, finish and (later) scores never leave the device
+        mu, var = model.ctx.aggregate(family, coef, group, G, plain=plain, prior_kernel_id=prior.kernelid if prior else 0)
+        model._scores_on_device = True
+        return mu, var
+    if have:
+        part = model.ctx.aggregate_partial(family, None if coef is None else coef[loc], None if group is None else group[loc], G)
+    else:
+        part = np.zeros((hipabi.agg_width(family, G), xt.shape[0]))
+    part = model.shard.allgather_sum(part)          # the exchange step of predict: W x n_t doubles per rank
+    return _finish_partial(model, xt, family, part, G, plain, prior)
+
+
+def scores(model, y_test, mu=None, var=None):
+    """dict(mse, sse, mae, sae, nlpd) (`src/scorefunctions.jl:6-16`) of the last `predict(model, x)`: computed on the
+    device from the aggregated prediction still resident there when one context holds the model, else from (mu, var)."""
+    y_test = np.ascontiguousarray(y_test, dtype=np.float64)
+    if getattr(model, "_scores_on_device", False) and mu is None:
+        return model.ctx.scores(y_test)
+    if mu is None or var is None:
+        raise ValueError("scores: pass the (mu, var) that predict returned (they are not resident on one device)")
+    return dict(mse=mse(y_test, mu), sse=sse(y_test, mu), mae=mae(y_test, mu), sae=sae(y_test, mu), nlpd=nlpd(y_test, mu, var))
 
 
 def _aggregate_dsmgp_flat(model, n_t, rc, mu, var):
@@ -874,6 +956,18 @@ def mse(y_true, y_pred):
 
 def mae(y_true, y_pred):
     return float(np.mean(np.abs(np.asarray(y_true) - np.asarray(y_pred))))
+
+
+def sse(y_true, y_pred):
+    """standard error of the squared error (`src/scorefunctions.jl:9`; Julia's std is the unbiased one)."""
+    se = (np.asarray(y_true) - np.asarray(y_pred)) ** 2
+    return float(np.std(se, ddof=1) / np.sqrt(se.size))
+
+
+def sae(y_true, y_pred):
+    """`src/scorefunctions.jl:14`"""
+    ae = np.abs(np.asarray(y_true) - np.asarray(y_pred))
+    return float(np.std(ae, ddof=1) / np.sqrt(ae.size))
 
 
 def nlpd(y_true, mu, var):

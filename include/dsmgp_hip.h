@@ -102,6 +102,33 @@ int dsmgp_predict_fetch(dsmgp_ctx* ctx, double* mu_out, double* var_out);
 int dsmgp_predict_leaves(dsmgp_ctx* ctx, const double* Xt, int64_t n_t, const int64_t* route_ptr,
                          const int64_t* route_idx, double* mu_out, double* var_out);
 
+/* ---- predict(model, x): sum/product aggregation of the leaf moments over the leaves every test row visits, on the
+ *      moments the last dsmgp_predict_run left in HBM (replaces the host recursions of src/common.jl:134-149,198-302).
+ *      family  DSMGP_AGG_MIXTURE  DSMGP (_predict / _minpredict, :134-143,151-196,275-302): leaf_coef[l] = W_l, the product of the
+ *                                 sum-node weights exp(logweights) on leaf l's path; mu = sum W mu_l,
+ *                                 var = sum W sigma2_l + sum W mu_l^2 - mu^2 with sigma2 <= 0 -> 1e-8 (:137)
+ *              DSMGP_AGG_POE / DSMGP_AGG_GPOE   (:145-149,198-222): leaf_coef[l] = beta_l (1, resp. 1/#root children)
+ *              DSMGP_AGG_RBCM     (:224-241): leaf_group[l] = root child of leaf l (n_groups of them);
+ *                                 prior_kernel_id = kernel id of the model's first leaf (leftGP, :227)
+ *      plain != 0: the root is a single GP (predict(node::GPNode), :175-179).
+ *      dsmgp_aggregate = partial + finish on one context.  With leaves spread over ranks or contexts every holder
+ *      calls dsmgp_aggregate_partial (partial_out: W x n_t sums, W = 3 mixture / 2 PoE, gPoE / 2 n_groups rBCM), the
+ *      caller adds the partial sums (the multi-GPU exchange: one all-gather of W n_t doubles per rank) and hands the
+ *      total to dsmgp_aggregate_finish.  mu_out / var_out (n_t each) may be NULL: results stay resident for dsmgp_scores. */
+#define DSMGP_AGG_MIXTURE 0
+#define DSMGP_AGG_POE     1
+#define DSMGP_AGG_GPOE    2
+#define DSMGP_AGG_RBCM    3
+int dsmgp_aggregate(dsmgp_ctx* ctx, int32_t family, const double* leaf_coef /* L */, const int32_t* leaf_group /* L or NULL */,
+                    int32_t n_groups, int32_t plain, int32_t prior_kernel_id, double* mu_out, double* var_out);
+int dsmgp_aggregate_partial(dsmgp_ctx* ctx, int32_t family, const double* leaf_coef, const int32_t* leaf_group,
+                            int32_t n_groups, double* partial_out /* W x n_t or NULL */);
+int dsmgp_aggregate_finish(dsmgp_ctx* ctx, const double* partial_in /* NULL: the context's own sums */, int32_t plain,
+                           int32_t prior_kernel_id, double* mu_out, double* var_out);
+/* ---- score functions of src/scorefunctions.jl:6-16 on the aggregated prediction still in HBM:
+ *      out[5] = { mse, sse (std(se)/sqrt(n)), mae, sae, nlpd } */
+int dsmgp_scores(dsmgp_ctx* ctx, const double* y_test /* n_t */, double* out /* 5 */);
+
 /* ---- updategradients!(gp) + grad vector of src/gaussianprocess.jl:165-178,185-217 per leaf.
  *      grad_out[l*stride + j], j over [dl..., ds, dnoise] (reference order, src/gaussianprocess.jl:212-214),
  *      reproducing the reference's scaling and ArdSE dl == 0. */

@@ -76,3 +76,30 @@ class OracleContext:
             v = gp_.grad()
             g[i, : v.size] = v
         return g
+
+
+class OraclePartialContext(OracleContext):
+    """OracleContext that also answers `aggregate_partial` (a NumPy restatement of agg_partial_kernel's sums), so the
+    CPU suite drives the product's partial-sum exchange + host finish (`model._predict_device`) without a GPU."""
+
+    def aggregate_partial(self, family, leaf_coef=None, leaf_group=None, n_groups=0):
+        n_t = self.Xt.shape[0]
+        leaf = np.repeat(np.arange(self.L), np.diff(self.rptr))
+        mu, var, rows = self._mu, self._var, self.ridx
+        if family == 0:
+            w = np.asarray(leaf_coef)[leaf]
+            v = np.where(var <= 0, 1e-8, var)
+            return np.stack([np.bincount(rows, weights=w * mu, minlength=n_t),
+                             np.bincount(rows, weights=w * mu * mu, minlength=n_t),
+                             np.bincount(rows, weights=w * v, minlength=n_t)])
+        t = 1.0 / var
+        if family == 3:
+            g = np.asarray(leaf_group)[leaf]
+            out = np.zeros((2 * n_groups, n_t))
+            for k in range(n_groups):
+                sel = g == k
+                out[2 * k] = np.bincount(rows[sel], weights=(t * mu)[sel], minlength=n_t)
+                out[2 * k + 1] = np.bincount(rows[sel], weights=t[sel], minlength=n_t)
+            return out
+        b = np.asarray(leaf_coef)[leaf]
+        return np.stack([np.bincount(rows, weights=b * t * mu, minlength=n_t), np.bincount(rows, weights=b * t, minlength=n_t)])

@@ -10,7 +10,7 @@ import pytest
 import deepstructuredmixtures_amd as dsm
 from deepstructuredmixtures_amd import hipabi, tree as ptree
 from deepstructuredmixtures_amd.datagen import uniform, normal, regression_data
-from oracle import gp as ogp, spn as ospn
+from oracle import gp as ogp, spn as ospn, scores as oscores
 
 pytestmark = pytest.mark.gpu
 
@@ -448,7 +448,9 @@ assert 0 < len(m.shard.local) < m.L
 z = dsm.update(m)
 mu, var = dsm.predict(m, Xt)
 assert np.array_equal(m.leaf_mll, ref["leaf_mll"]) and z == float(ref["z"])
-assert np.array_equal(mu, ref["mu"]) and np.array_equal(var, ref["var"])
+# predict: every rank aggregates its own leaves on its device, the partial sums are added in rank order -- another
+# association than the single-context sum over all leaves, the same terms
+assert np.allclose(mu, ref["mu"], rtol=1e-12, atol=1e-13) and np.allclose(var, ref["var"], rtol=1e-10, atol=1e-13)
 dsm.updategradients(m)
 assert np.array_equal(dsm.grad_mll(m), ref["grad"])
 td.barrier(); td.destroy_process_group()
@@ -458,7 +460,8 @@ print("rank", rank, "ok", len(m.shard.local))
 
 def test_two_ranks_sharing_leaves_reproduce_the_single_process_result_bitwise(tmp_path):
     """Leaf sharding through the real HIP contexts (two processes on the one GPU of this box, gloo for the
-    all-gather): identical bits to the unsharded run, because every per-leaf result is reproducible."""
+    all-gathers): per-leaf results (log-marginals, gradients) are bit-identical to the unsharded run; the aggregated
+    prediction adds per-rank partial sums and agrees to rounding."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -471,7 +474,7 @@ def test_two_ranks_sharing_leaves_reproduce_the_single_process_result_bitwise(tm
     np.savez(ref, leaf_mll=m.leaf_mll, z=z, mu=mu, var=var, grad=dsm.grad_mll(m))
     script = tmp_path / "worker.py"
     script.write_text(_SHARD_WORKER.format(root=root, ref=ref))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29000 + os.getpid() % 2000), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
@@ -528,6 +531,41 @@ def test_config4_headline_size_sampled_against_oracle_and_properties():
         mo, vo = g.prediction(Xt[rows])
         assert np.allclose(mu_l[ptr[j]:ptr[j + 1]], mo, rtol=RTOL, atol=1e-9)
         assert np.allclose(var_l[ptr[j]:ptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
+    # The leaves that matter: the largest one (n ~ 13k: most block steps, deepest split-K, worst
+    # conditioning, on the multi-GPU critical path) and one of ~9k rows, against the oracle entry by entry, plus the
+    # backward error of the downloaded factor  ||K_y - L L^T||_F <= 1e-14 ||K_y||_F  and the residual of K_y alpha = y.
+    import scipy.linalg as sla
+    big = [int(order[-1]), int(order[np.searchsorted(nobs[order], 9000)])]
+    assert nobs[big[0]] > 13000 and 8500 < nobs[big[1]] < 10500
+    for j in big:
+        lf = model.leaves[j]
+        g = ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.IsoSE(lf.kernel.logl, lf.kernel.logs), lf.logNoise,
+                                exact_dist=True)
+        Ky = g.noisy_kernel()
+        g.P = None                                       # 1.4 GB at n = 13k: not needed again
+        C, info = sla.lapack.dpotrf(Ky, lower=1, clean=1)
+        g.factors, g.info = C, int(info)
+        g.solve_alpha()
+        assert info == 0 and abs(model.leaf_mll[j] - g.mll()) <= RTOL * abs(g.mll())
+        F, alpha = model.ctx.download_factor(j, lf.nobs)
+        assert np.max(np.abs(alpha - g.alpha)) <= 1e-7 * np.max(np.abs(g.alpha))
+        assert np.max(np.abs(F - C)) <= 1e-9 * np.max(np.abs(C))
+        yc = y[lf.obs] - lf.mean.m
+        assert np.max(np.abs(Ky @ alpha - yc)) <= 1e-8 * np.max(np.abs(yc))
+        R = sla.blas.dsyrk(1.0, F, lower=1)              # lower triangle of L L^T
+        R -= np.tril(Ky)
+        off = np.tril(R, -1)
+        res = np.sqrt(2.0 * np.sum(off * off) + np.sum(np.diag(R) ** 2))
+        assert res <= 1e-14 * np.linalg.norm(Ky), (lf.nobs, res / np.linalg.norm(Ky))
+        del R, off, F, Ky
+        rows = idx[ptr[j]:ptr[j + 1]]
+        Knt = ogp.kernelmatrix(g.kernel, g.x, Xt[rows], True)
+        mo = g.mean + Knt.T @ g.alpha
+        V = sla.solve_triangular(C, Knt, lower=True)
+        vo = ogp.prior_diag(g.kernel, Xt[rows]) - np.sum(V * V, axis=0) + g.getnoise()
+        assert np.allclose(mu_l[ptr[j]:ptr[j + 1]], mo, rtol=RTOL, atol=1e-9)
+        assert np.allclose(var_l[ptr[j]:ptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
+        del C, V, Knt, g
     # properties of the whole model
     m0 = model.leaf_mll.copy()
     assert np.all(np.isfinite(model.leaf_mll)) and np.all(model.leaf_info == 0)
@@ -650,3 +688,248 @@ def test_streaming_factor_and_discard_equals_resident():
     mc = dsm.buildDSMGP(z["x"].reshape(-1, 1), z["y"], 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5),
                         seed=11, stream_budget=6 << 20)
     assert len(mc.ctx.groups) >= 2 and np.allclose(mc.leaf_mll, z["leaf_mll"], rtol=RTOL, atol=1e-9)
+
+
+def test_reference_self_check_construction_through_the_hip_path(ctx, golden_dir):
+    """The only executable checks the reference holds for this path -- src/AdvancedCholeskey.jl test_chol_continue
+    (:121-135: potrf of the leading P x P block, chol_continue! from column P+1, compare with cholesky) and lrtest
+    (:61-110: genCov matrix with ten rows removed, compare with cholesky of the reduced matrix) -- rebuilt with the
+    portable generator (tests/golden/make_advchol.py) and pushed through the C ABI: the genCov matrix Sigma becomes
+    the Gram matrix of an IsoLinear leaf (K_y = X X^T + 1 with X = chol(Sigma - I), l = 1, noise + eps = 1), the
+    leading block is a source leaf and the whole matrix a PREFIX leaf (= chol_continue!), the reduced matrix a leaf
+    over the kept rows.  Expected factors: LAPACK dpotrf, mpmath-checked (fixture advchol.npz)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_advchol", os.path.join(golden_dir, "make_advchol.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    z = np.load(os.path.join(golden_dir, "advchol.npz"))
+    logn = 0.5 * np.log(1.0 - 1e-8)                     # exp(2 logNoise) + 1e-8 == 1
+    for name in ("cont_d100_p10", "cont_d192_p150"):
+        D, P, seed = int(z[f"{name}/D"]), int(z[f"{name}/P"]), int(z[f"{name}/seed"])
+        S = mod.gen_cov(D, seed)
+        X = np.linalg.cholesky(S - np.eye(D))
+        ctx.set_train(X, np.zeros(D))
+        ctx.set_leaves([0, P, P + D], np.concatenate([np.arange(P), np.arange(D)]), [0, 0], [0.0, 0.0])
+        ctx.set_hyper(0, 2, [0.0, 0.0, logn])
+        ctx.set_sharing([0, 2], [-1, 0], [0, P])        # leaf 1 continues leaf 0's factor from column P+1
+        mll, info, _ = ctx.fit()
+        assert info[0] == 0 and info[1] == 0
+        F, _ = ctx.download_factor(1, D)
+        Lref = z[f"{name}/L"]
+        assert np.max(np.abs(F - Lref)) <= 1e-12 * np.max(np.abs(Lref)), name
+        assert np.sum(np.abs(F - Lref)) < 1e-9           # the quantity test_chol_continue returns (:134)
+        F0, _ = ctx.download_factor(0, P)
+        assert np.max(np.abs(F0 - Lref[:P, :P])) <= 1e-12 * np.max(np.abs(Lref))
+        # y = 0: alpha = 0 and mll = -(logdet + n log 2pi)/2
+        assert abs(mll[1] + (2 * np.sum(np.log(np.diag(Lref))) + D * np.log(2 * np.pi)) / 2) <= 1e-10 * abs(mll[1])
+    D, seed = int(z["lr/D"]), int(z["lr/seed"])
+    A = mod.gen_cov(D, seed)
+    idx = np.setdiff1d(np.arange(D), z["lr/missing"])
+    X = np.linalg.cholesky(A - np.eye(D))
+    ctx.set_train(X, np.zeros(D))
+    ctx.set_leaves([0, D, D + idx.size], np.concatenate([np.arange(D), idx]), [0, 0], [0.0, 0.0])
+    ctx.set_hyper(0, 2, [0.0, 0.0, logn])
+    ctx.set_sharing(None, None, None)                   # row deletion -> full factorisation (SURVEY F4)
+    mll, info, _ = ctx.fit()
+    assert np.all(info == 0)
+    for leaf, tag, n in ((0, "lr_A", D), (1, "lr_B", idx.size)):
+        F, _ = ctx.download_factor(leaf, n)
+        assert np.allclose(np.diag(F), z[f"{tag}/diag"], rtol=1e-12)
+        assert abs(np.linalg.norm(F) - float(z[f"{tag}/fro"])) <= 1e-12 * float(z[f"{tag}/fro"])
+        cols = z[f"{tag}/cols"]
+        assert np.max(np.abs(F[:, cols] - z[f"{tag}/colvals"])) <= 1e-12 * np.max(np.abs(z[f"{tag}/colvals"]))
+        assert abs(mll[leaf] + (float(z[f"{tag}/logdet"]) + n * np.log(2 * np.pi)) / 2) <= 1e-10 * abs(mll[leaf])
+
+
+def test_environment_cannot_change_results(ctx):
+    """The product library reads no tuning variables: DSMGP_TILE_V=101 used to route every
+    factorisation through an ablation kernel with wrong results; now a context created under it is bit-identical."""
+    X, y, _ = regression_data(1500, 3, n_test=8, seed=91)
+    h = [np.log(0.3), 0.0, np.log(0.1)]
+    ref, info, _ = _single(ctx, X, y, 0.0, 0, np.array(h[:2]), h[2])
+    old = {k: os.environ.get(k) for k in ("DSMGP_TILE_V", "DSMGP_XCD", "DSMGP_TAIL_SPLIT")}
+    os.environ.update(DSMGP_TILE_V="101", DSMGP_XCD="0", DSMGP_TAIL_SPLIT="7")
+    try:
+        c2 = hipabi.Context(0)
+        got, info2, _ = _single(c2, X, y, 0.0, 0, np.array(h[:2]), h[2])
+        c2.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert info[0] == 0 and info2[0] == 0 and got[0] == ref[0]
+
+
+def test_config5_streaming_at_a_size_that_really_streams():
+    """BASELINE config 5 at N = 250k, D = 16, M = 300, [IsoSE, IsoLinear]: 288 leaves, n = 3.8k..41.7k, 0.69 TB of
+    factors -> the streaming context needs >= 2 leaf groups on a 288 GB GPU (the regime that defines config 5: pool reuse,
+    npad^2 past int32, test rows riding through every group).  Checked against the oracle on the smallest leaves of both
+    kernels, through K_y alpha = y on the LARGEST leaf of both kernels, and against a plain resident context on
+    mid-size leaves."""
+    import scipy.linalg as sla
+    N, D = 250_000, 16
+    X, y, Xt = regression_data(N, D, seed=20205)
+    kern = [dsm.IsoSE(np.log(0.3), 0.0), dsm.IsoLinear(np.log(1.5))]
+    m = dsm.buildDSMGP(X, y, 3, 4, M=300, D=2, kernel=kern, logNoise=np.log(0.1), seed=20205, fit_now=False,
+                       stream_budget="auto")
+    nobs = np.array([lf.nobs for lf in m.leaves])
+    kind = np.array([lf.kernel.kind for lf in m.leaves])
+    assert m.L == 288 and nobs.max() > 40_000
+    big = [int(np.flatnonzero(kind == k)[np.argmax(nobs[kind == k])]) for k in (0, 2)]
+    small = [int(np.flatnonzero(kind == k)[np.argmin(nobs[kind == k])]) for k in (0, 2)]
+    m.ctx.keep_alpha = tuple(big)
+    dsm.resident_test(m, Xt)
+    dsm.fit(m)
+    assert isinstance(m.ctx, hipabi.StreamingContext) and len(m.ctx.groups) >= 2
+    assert np.all(m.leaf_info == 0) and np.all(np.isfinite(m.leaf_mll))
+    z = dsm.infer(m)
+    passes = m.ctx.passes
+    mu, var = dsm.predict(m, Xt)
+    assert m.ctx.passes == passes                          # the test rows rode through the fit pass
+    assert np.isfinite(z) and np.all(np.isfinite(mu)) and np.all(var > 0)
+    ptr, idx = m._route_cache["ptr"], m._route_cache["idx"]
+    mu_l, var_l = m.ctx.predict_fetch()
+    # smallest leaf of each kernel against the oracle
+    for j in small:
+        lf = m.leaves[j]
+        g = ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(lf.kernel.kind, lf.kernel.loghyp()),
+                                lf.logNoise, exact_dist=True).update_cholesky()
+        assert abs(m.leaf_mll[j] - g.mll()) <= RTOL * abs(g.mll())
+        mo, vo = g.prediction(Xt[idx[ptr[j]:ptr[j + 1]]])
+        assert np.allclose(mu_l[ptr[j]:ptr[j + 1]], mo, rtol=RTOL, atol=1e-9)
+        assert np.allclose(var_l[ptr[j]:ptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
+    # largest leaf of each kernel: residual of K_y alpha = y - m, K_y assembled on the host in row blocks
+    for j in big:
+        lf = m.leaves[j]
+        alpha = m.ctx.alpha(j)
+        xs, yc = X[lf.obs], y[lf.obs] - lf.mean.m
+        c = np.exp(2 * lf.logNoise) + 1e-8
+        if lf.kernel.kind == 2:
+            r = xs @ (xs.T @ alpha) / np.exp(2 * lf.kernel.logl) + c * alpha - yc
+        else:
+            l2, s2 = np.exp(2 * lf.kernel.logl), np.exp(2 * lf.kernel.logs)
+            sq = np.sum(xs * xs, axis=1)
+            r = np.empty(lf.nobs)
+            for a in range(0, lf.nobs, 2048):
+                P = np.maximum(sq[a:a + 2048, None] + sq[None, :] - 2.0 * (xs[a:a + 2048] @ xs.T), 0.0)
+                r[a:a + 2048] = (s2 * np.exp(-0.5 * P / l2)) @ alpha
+            r += c * alpha - yc
+        assert np.max(np.abs(r)) <= 1e-7 * np.max(np.abs(yc)), (lf.nobs, lf.kernel.kind, np.max(np.abs(r)))
+    # streamed == resident: six mid-size leaves refitted in a plain context (no pool, no groups)
+    order = np.argsort(nobs)
+    mid = [int(j) for j in order[140:146]]
+    c2 = hipabi.Context(0)
+    c2.set_train(X, y)
+    lv = [m.leaves[j] for j in mid]
+    c2.set_leaves(np.concatenate([[0], np.cumsum([lf.nobs for lf in lv])]), np.concatenate([lf.obs for lf in lv]),
+                  [lf.kernelid for lf in lv], [lf.mean.m for lf in lv])
+    for lf in m.kernel_table():
+        c2.set_hyper(lf.kernelid, lf.kernel.kind, np.concatenate([lf.kernel.loghyp(), [lf.logNoise]]))
+    mll2, info2, _ = c2.fit()
+    c2.close()
+    # a leaf's split-K schedule depends on which leaves share its launches: last-bit differences in the factor, amplified by
+    # the conditioning of the rank-16 IsoLinear Gram (measured 5e-12 relative on its log-marginal)
+    assert np.all(info2 == 0) and np.allclose(mll2, m.leaf_mll[mid], rtol=1e-10)
+
+
+@pytest.mark.parametrize("family", ["dsmgp", "kernel_vector", "poe", "gpoe", "rbcm", "single_leaf"])
+def test_device_aggregation_and_scores(family):
+    """the sum/product aggregation of predict (src/common.jl:134-149,198-302) and the score functions
+    (src/scorefunctions.jl:6-16) run on the moments resident in HBM (dsmgp_aggregate*, dsmgp_scores).  Against the
+    oracle's literal recursions at 1e-8, against the host rules on the SAME moments at 1e-12 (they differ only in
+    summation association), through the partial-sum path several contexts / ranks use, and the scores against the
+    oracle's restatement."""
+    from deepstructuredmixtures_amd import model as pmodel
+    N, D = 2500, 3
+    X, y, Xt = regression_data(N, D, n_test=333, seed=901)
+    yt = np.mean([np.sin(2 * np.pi * (d + 1) * Xt[:, d]) for d in range(D)], axis=0)
+    kern = dsm.IsoSE(np.log(0.3), 0.0)
+    kw = dict(logNoise=np.log(0.1), seed=4)
+    if family == "dsmgp":
+        m = dsm.buildDSMGP(X, y, 3, 4, M=60, kernel=kern, **kw)
+    elif family == "kernel_vector":
+        m = dsm.buildDSMGP(X, y, 2, 4, M=60, kernel=[kern, dsm.IsoLinear(np.log(1.5))], **kw)
+    elif family == "poe":
+        m = dsm.buildPoE(X, y, 8, M=100, kernel=kern, meanFun=dsm.ConstMean(float(np.mean(y))), **kw)
+    elif family == "gpoe":
+        m = dsm.buildPoE(X, y, 8, M=100, kernel=kern, meanFun=dsm.ConstMean(float(np.mean(y))), generalized=True, **kw)
+    elif family == "rbcm":
+        m = dsm.buildBCM(X, y, 8, M=100, kernel=dsm.IsoLinear(np.log(0.7)), **kw)       # k(x*,x*) depends on the row
+    else:
+        m = dsm.buildBCM(X[:300], y[:300], 4, M=400, kernel=kern, **kw)
+        assert m.L == 1
+    Xn, yn = (X[:300], y[:300]) if family == "single_leaf" else (X, y)
+    gps, _ = _oracle_model(m, Xn, yn)
+    if m.family == "dsmgp":
+        dsm.update(m)
+        ospn.update(m.root, gps)
+        mo, vo = ospn.predict(m.root, gps, Xt)
+    elif m.root.kind == "gp" or m.family == "poe":
+        mo, vo = ospn.predict_poe(m.root, gps, Xt)
+    elif m.family == "gpoe":
+        mo, vo = ospn.predict_gpoe(m.root, gps, Xt)
+    else:
+        mo, vo = ospn.predict_rbcm(m.root, gps, Xt)
+    mu, var = dsm.predict(m, Xt)                              # device aggregation
+    assert m._scores_on_device
+    assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9), float(np.max(np.abs(mu - mo)))
+    assert np.allclose(var, vo, rtol=RTOL, atol=1e-10), float(np.max(np.abs(var - vo) / vo))
+    # host rules on the same moments
+    rc = m._route_cache
+    mu_l, var_l = m.ctx.predict_fetch()
+    if m.family == "dsmgp":
+        mh, vh = pmodel._aggregate_dsmgp_flat(m, Xt.shape[0], rc, mu_l, var_l)
+        mr, vr = pmodel._aggregate_dsmgp(m, np.asfortranarray(Xt), rc["ptr"], mu_l, var_l)
+        assert np.allclose(mu, mr, rtol=1e-12, atol=1e-13) and np.allclose(var, vr, rtol=1e-9, atol=1e-13)
+    else:
+        mh, vh = pmodel._aggregate_poe(m, np.asfortranarray(Xt), rc["ptr"], mu_l, var_l)
+    assert np.allclose(mu, mh, rtol=1e-12, atol=1e-13) and np.allclose(var, vh, rtol=1e-11, atol=1e-14)
+    # partial sums + finish (what several ranks / contexts do), device finish and host finish
+    fam, coef, group, G, plain, prior = pmodel._aggregation_spec(m)
+    part = m.ctx.aggregate_partial(fam, coef, group, G)
+    assert part.shape == (hipabi.agg_width(fam, G), Xt.shape[0])
+    m1, v1 = m.ctx.aggregate_finish(None, plain=plain, prior_kernel_id=prior.kernelid if prior else 0)
+    assert np.array_equal(m1, mu) and np.array_equal(v1, var)
+    half = 0.5 * part
+    m2, v2 = m.ctx.aggregate_finish(half + half, plain=plain, prior_kernel_id=prior.kernelid if prior else 0)
+    assert np.array_equal(m2, mu) and np.array_equal(v2, var)
+    m3, v3 = pmodel._finish_partial(m, np.asfortranarray(Xt), fam, part, G, plain, prior)
+    assert np.allclose(m3, mu, rtol=1e-13, atol=1e-15) and np.allclose(v3, var, rtol=1e-12, atol=1e-15)
+    # scores of the resident prediction against the oracle's restatement of scorefunctions.jl
+    sc = dsm.scores(m, yt)
+    ref = dict(mse=oscores.mse(yt, mo), sse=oscores.sse(yt, mo), mae=oscores.mae(yt, mo), sae=oscores.sae(yt, mo),
+               nlpd=oscores.nlpd(yt, mo, vo))
+    for k, v in ref.items():
+        assert abs(sc[k] - v) <= RTOL * max(1.0, abs(v)), (k, sc[k], v)
+    host = dsm.scores(m, yt, mu, var)
+    assert all(abs(host[k] - sc[k]) <= 1e-12 * max(1.0, abs(sc[k])) for k in sc)
+    if family == "dsmgp":      # the same model over two concurrent contexts: partial sums of the sub-contexts, host finish
+        m2c = dsm.buildDSMGP(X, y, 3, 4, M=60, kernel=kern, n_sub=2, **kw)
+        dsm.update(m2c)
+        mu2, var2 = dsm.predict(m2c, Xt)
+        assert not m2c._scores_on_device
+        assert np.allclose(mu2, mu, rtol=1e-11, atol=1e-12) and np.allclose(var2, var, rtol=1e-9, atol=1e-13)
+
+
+def test_aggregate_error_paths(ctx):
+    X, y, Xt = regression_data(600, 2, n_test=20, seed=17)
+    ctx.set_train(X, y)
+    ctx.set_leaves([0, 300, 600], np.arange(600), [0, 0], [0.0, 0.0])
+    ctx.set_sharing(None, None, None)
+    ctx.set_hyper(0, 0, [np.log(0.3), 0.0, np.log(0.1)])
+    ctx.fit()
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.aggregate(hipabi.AGG_POE, np.ones(2))                     # no prediction yet
+    ctx.predict_leaves(Xt, [0, 20, 40], np.tile(np.arange(20), 2))
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.scores(np.zeros(20))                                      # no aggregation yet
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.aggregate(7, np.ones(2))
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.aggregate(hipabi.AGG_RBCM, None, np.array([0, 5], dtype=np.int32), 2)   # group out of range
+    mu, var = ctx.aggregate(hipabi.AGG_POE, np.ones(2))
+    ml, vl = ctx.predict_fetch()
+    t = 1 / vl.reshape(2, 20)
+    assert np.allclose(var, 1 / t.sum(0), rtol=1e-14) and np.allclose(mu, (t * ml.reshape(2, 20)).sum(0) / t.sum(0), rtol=1e-13)

@@ -168,3 +168,39 @@ def test_mixture_identity_and_poe_rules():
     ml = np.array([g.mll() for g in gps])
     assert abs(z - (np.log(np.mean(np.exp(ml - ml.max()))) + ml.max())) < 1e-12
     assert abs(np.exp(s.logweights).sum() - 1) < 1e-12
+
+
+def _advchol(golden_dir):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_advchol", os.path.join(golden_dir, "make_advchol.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    z = np.load(os.path.join(golden_dir, "advchol.npz"))
+    return mod, z
+
+
+def test_chol_continue_on_the_reference_self_check_construction(golden_dir):
+    """The reference's own executable checks for this path (src/AdvancedCholeskey.jl:121-135 test_chol_continue,
+    :61-110 lrtest) rebuilt with the portable generator: potrf of the leading P x P block + chol_continue!(A, P+1)
+    must equal the Cholesky factor of the whole genCov matrix (fixture: LAPACK dpotrf, mpmath-checked at D = 100)."""
+    mod, z = _advchol(golden_dir)
+    for name in ("cont_d100_p10", "cont_d192_p150"):
+        D, P, seed = int(z[f"{name}/D"]), int(z[f"{name}/P"]), int(z[f"{name}/seed"])
+        S = mod.gen_cov(D, seed)
+        A = S.copy()
+        C, info = sla.lapack.dpotrf(A[:P, :P], lower=1, clean=1)     # LAPACK.potrf!('L', view(A.data, 1:P, 1:P))  :129
+        assert info == 0
+        A[:P, :P] = C
+        L, info = ogp.chol_continue(A, P + 1)                        # :130
+        assert info == 0
+        assert np.max(np.abs(L - z[f"{name}/L"])) <= 1e-13 * np.max(np.abs(z[f"{name}/L"]))
+        assert np.sum(np.abs(L - np.linalg.cholesky(S))) < 1e-10     # the quantity test_chol_continue returns (:134)
+    # lrtest: the factor the row-deletion update must reproduce is cholesky(B), B = A[idx, idx]
+    D, seed = int(z["lr/D"]), int(z["lr/seed"])
+    A = mod.gen_cov(D, seed)
+    miss = mod.missing_rows(D, seed + 1)
+    assert np.array_equal(miss, z["lr/missing"]) and miss.size == 10 and miss.max() < D - 1
+    idx = np.setdiff1d(np.arange(D), miss)
+    C, info = sla.lapack.dpotrf(A[np.ix_(idx, idx)], lower=1, clean=1)
+    assert info == 0 and np.allclose(np.diag(C), z["lr_B/diag"], rtol=1e-13)
+    assert abs(2 * np.sum(np.log(np.diag(C))) - float(z["lr_B/logdet"])) < 1e-10
