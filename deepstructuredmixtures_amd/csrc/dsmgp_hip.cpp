@@ -251,6 +251,7 @@ struct dsmgp_ctx {
     DevBuf<SolveTask> fwd, bwd;
     int solve_steps = 0;
     bool fitted = false;
+    bool alpha_valid = false;       // alpha = L^-T z has been computed for the current factors (ensure_alpha)
 
     // prediction
     double* dXt = nullptr;
@@ -887,7 +888,7 @@ int build_plan(dsmgp_ctx* c) {
 }
 
 void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */) {
-    if (role == 1) tile_gemm_kernel_v2<false, 1><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    if (role == 1) tile_trsm_kernel<<<n, 256, 0, c->stream>>>(tasks);   // B = inverse of a diagonal block, K = 128
     else tile_gemm_kernel_v2<false, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr);
 }
 
@@ -990,6 +991,29 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         }
     }
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// alpha = L^-T z by the backward block sweep on w = copy of z (z stays: the predictive mean is m + V^T z).
+int ensure_alpha(dsmgp_ctx* c) {
+    if (c->alpha_valid) return 0;
+    EventPair ev;
+    HIPCHK(c, ev.init());
+    HIPCHK(c, hipEventRecord(ev.a, c->stream));
+    int maxpad = 0;
+    for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
+    copy_z_kernel<<<dim3((maxpad + 255) / 256, c->L), 256, 0, c->stream>>>(c->d_leaves);
+    for (int s = 0; s < c->solve_steps; ++s) {
+        const int n = c->bwd_off[s + 1] - c->bwd_off[s];
+        if (n > 0) solve_bwd_kernel<<<n, 256, 0, c->stream>>>(c->bwd.p + c->bwd_off[s]);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(ev.b, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+    c->timings[14] = ms * 1e-3;
+    c->alpha_valid = true;
     return 0;
 }
 
@@ -1197,6 +1221,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     for (int i = 0; i < 6; ++i) c->timings[i] = 0.0;
     c->timings[11] = 0.0;
     c->timings[13] = 0.0;
+    c->timings[14] = 0.0;
     c->n_update_launches = 0;
     PhaseTimer pt(c);
     EventPair ev;
@@ -1240,23 +1265,18 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     }
     if (any_prefix)
         if (int rc = run_phase(c, phases[1], pt, true)) return rc;
-    // 4. alpha = L^-T (L^-1 y)                                (src/gaussianprocess.jl:105)
+    // 4. z = L^-1 (y - m) for the leaves whose factor came from another leaf (COPY, PREFIX); leaves factorised in
+    //    full produced z during the factorisation.  alpha = L^-T z (src/gaussianprocess.jl:105) is NOT computed here:
+    //    neither the log-marginal (z.z) nor the prediction (V^T z) needs it -- ensure_alpha() runs the backward sweep
+    //    on first use (gradients, dsmgp_download_factor).
     {
         pt.begin(4);
         for (int k = 0; k < c->solve_steps; ++k) {
             const int n = c->fwd_off[k + 1] - c->fwd_off[k];
             if (n > 0) solve_fwd_kernel<<<n, 256, 0, c->stream>>>(c->fwd.p + c->fwd_off[k]);
         }
-        {
-            int maxpad = 0;
-            for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
-            copy_z_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);   // w = z
-        }
-        for (int s = 0; s < c->solve_steps; ++s) {
-            const int n = c->bwd_off[s + 1] - c->bwd_off[s];
-            if (n > 0) solve_bwd_kernel<<<n, 256, 0, c->stream>>>(c->bwd.p + c->bwd_off[s]);
-        }
         pt.end();
+        c->alpha_valid = false;
     }
     // 5. log marginal likelihood                              (src/gaussianprocess.jl:163)
     pt.begin(5);
@@ -1855,6 +1875,7 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     }
     if (!c->grad_ready)
         if (int rc = build_grad_plan(c)) return rc;
+    if (int rc = ensure_alpha(c)) return rc;
     c->timings[10] = 0.0;
     EventPair ev;
     HIPCHK(c, ev.init());
@@ -1984,7 +2005,10 @@ int dsmgp_download_factor(dsmgp_ctx* c, int32_t leaf, double* F, double* alpha) 
         for (int col = 1; col < lf.n; ++col)
             for (int r = 0; r < col; ++r) F[r + (size_t)col * lf.n] = 0.0;
     }
-    if (alpha) HIPCHK(c, hipMemcpy(alpha, d.alpha, lf.n * sizeof(double), hipMemcpyDeviceToHost));
+    if (alpha) {
+        if (int rc = ensure_alpha(c)) return rc;
+        HIPCHK(c, hipMemcpy(alpha, d.alpha, lf.n * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

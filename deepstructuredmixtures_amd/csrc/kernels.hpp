@@ -419,6 +419,130 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Panel solve X = T Dinv^T  (T = tk.A: one 128x128 tile; Dinv = tk.B: inverse of the step's diagonal block, LOWER
+// triangular, ld 128; K = 128).  X(r,c) = sum_{j <= c} T(r,j) Dinv(c,j): the 16-column block cb of X needs only
+// j < 16 (cb + 1), so 36 of the 64 (column block, 16-wide j range) products are structurally zero-free and the rest
+// is skipped.  To give every wave the same work the waves split the ROWS (wave w: rows 32w..32w+31, all 128 columns,
+// acc[cb][rn] = 8 x 2 MFMA tiles) instead of the 2x2 quadrants of the update kernel; with the 16 chunks of 8 columns
+// fully unrolled, which products exist is known at compile time: 288 MFMAs per wave instead of 512.
+// A wave holds whole rows of X, so the riders of the epilogue (forward substitution w_i -= X z_k for train rows,
+// predictive moments mu += X z_k, sum of squares for test rows) reduce inside the wave.
+__global__ __launch_bounds__(256, 2) void tile_trsm_kernel(const TileTask* __restrict__ tasks) {
+    __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
+    __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
+    const TileTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4 acc[8][2];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int rn = 0; rn < 2; ++rn) acc[cb][rn] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // staging as in gemm_mainloop_v2: thread t moves column (t>>5) of a chunk, rows 2*(t&31) + 64j
+    const int scol = t >> 5, srow = 2 * (t & 31);
+    const double* gA = tk.A + srow + (size_t)scol * tk.lda;
+    const double* gB = tk.B + srow + (size_t)scol * tk.ldb;
+    const int sOff = scol * LDP + srow;
+    d2 ra[2][2], rb[2][2];
+#define TGLOAD(S, CH)                                                                            \
+    do {                                                                                         \
+        const size_t oa_ = (size_t)(CH) * KC2 * tk.lda, ob_ = (size_t)(CH) * KC2 * tk.ldb;       \
+        ra[S][0] = *AS_GLOBAL_D2(gA + oa_);                                                      \
+        ra[S][1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                                 \
+        rb[S][0] = *AS_GLOBAL_D2(gB + ob_);                                                      \
+        rb[S][1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                                 \
+    } while (0)
+#define TSWRITE(S, BUF)                                                                          \
+    do {                                                                                         \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff]) = ra[S][0];                                       \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = ra[S][1];                                  \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff]) = rb[S][0];                                       \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = rb[S][1];                                  \
+    } while (0)
+    TGLOAD(0, 0);
+    TGLOAD(1, 1);
+    TSWRITE(0, 0);
+    TGLOAD(0, 2);
+    TSWRITE(1, 1);
+    TGLOAD(1, 3);
+    TSWRITE(0, 2);
+    __syncthreads();
+    constexpr int NCH = TB / KC2;   // 16
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int buf = c & (NRING - 1);
+        if (c + 4 < NCH) TGLOAD(c & 1, c + 4);
+        const int cb0 = c / 2;      // column blocks below cb0 only see zeros of Dinv in this j range
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            double fb[2], fa[8];
+            const double* pb = &sA[buf][(g * 4 + l4) * LDP + w * 32 + l15];
+            const double* pa = &sB[buf][(g * 4 + l4) * LDP + l15];
+            fb[0] = pb[0];
+            fb[1] = pb[16];
+#pragma unroll
+            for (int cb = cb0; cb < 8; ++cb) fa[cb] = pa[16 * cb];
+#pragma unroll
+            for (int cb = cb0; cb < 8; ++cb) {
+                acc[cb][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cb], fb[0], acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cb], fb[1], acc[cb][1], 0, 0, 0);
+            }
+        }
+        if (c + 3 < NCH) TSWRITE((c + 1) & 1, (c + 3) & (NRING - 1));
+        if (c + 1 < NCH) __syncthreads();
+    }
+#undef TSWRITE
+#undef TGLOAD
+
+    // store: register r of acc[cb][rn] is X(row = 32 w + 16 rn + l15, col = 16 cb + l4 + 4 r)
+    const unsigned lofs = (unsigned)(w * 32 + l15) + (unsigned)l4 * (unsigned)tk.ldc;
+    const size_t ldc = (size_t)tk.ldc;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * r) * ldc);
+            col[lofs] = acc[cb][0][r];
+            col[lofs + 16] = acc[cb][1][r];
+        }
+    if (tk.wi != nullptr) {
+        double p[2] = {0.0, 0.0}, q2[2] = {0.0, 0.0};
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double z = tk.zk[16 * cb + l4 + 4 * r];
+#pragma unroll
+                for (int rn = 0; rn < 2; ++rn) {
+                    p[rn] = fma(acc[cb][rn][r], z, p[rn]);
+                    q2[rn] = fma(acc[cb][rn][r], acc[cb][rn][r], q2[rn]);
+                }
+            }
+#pragma unroll
+        for (int rn = 0; rn < 2; ++rn) {
+            p[rn] += __shfl_xor(p[rn], 16);
+            p[rn] += __shfl_xor(p[rn], 32);
+            q2[rn] += __shfl_xor(q2[rn], 16);
+            q2[rn] += __shfl_xor(q2[rn], 32);
+        }
+        if (l4 == 0) {
+#pragma unroll
+            for (int rn = 0; rn < 2; ++rn) {
+                const int row = w * 32 + 16 * rn + l15;
+                if (tk.sq == nullptr) tk.wi[row] -= p[rn];
+                else {
+                    tk.wi[row] += p[rn];
+                    tk.sq[row] += q2[rn];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Gradient contraction (updategradients!, src/gaussianprocess.jl:165-178 + src/kernels.jl:85-99):
 // one tile G = (K_y^-1)[i-tile, j-tile] = sum_k Xt[i,k] Xt[j,k]^T with Xt = L^-T (rows = columns of L^-1),
 // never stored: the epilogue contracts  sum_rc (alpha_r alpha_c - G_rc) * K_rc * P_rc  (IsoSE: K = kernel
@@ -1057,7 +1181,9 @@ __global__ void gather_test_kernel(const LeafDev* __restrict__ leaves, const int
     for (int d = 0; d < D; ++d) xg[r + (size_t)d * lf.ntpad] = valid ? Xt[g + (size_t)d * n_t] : 0.0;
 }
 
-// mll = -(y.alpha + 2 sum log L_ii + n log 2pi)/2   (src/gaussianprocess.jl:163)
+// mll = -(y.alpha + 2 sum log L_ii + n log 2pi)/2   (src/gaussianprocess.jl:163), with y.alpha evaluated as z.z
+// (z = L^-1 y, alpha = L^-T z  =>  y.alpha = (L z).(L^-T z) = z.z): the log-marginal needs the forward substitution
+// only, so fit! does not run the backward sweep; alpha is materialised on first use (ensure_alpha).
 __global__ __launch_bounds__(256) void mll_kernel(const LeafDev* __restrict__ leaves, double* __restrict__ mll_out) {
     __shared__ double red[256];
     __shared__ double red2[256];
@@ -1065,7 +1191,7 @@ __global__ __launch_bounds__(256) void mll_kernel(const LeafDev* __restrict__ le
     const int t = threadIdx.x;
     double s = 0.0, ld = 0.0;
     for (int i = t; i < lf.n; i += 256) {
-        s = fma(lf.yc[i], lf.alpha[i], s);
+        s = fma(lf.z[i], lf.z[i], s);
         ld += log(lf.F[i + (size_t)i * lf.npad]);
     }
     red[t] = s;

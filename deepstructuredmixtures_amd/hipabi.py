@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 
-N_TIMINGS = 14
+N_TIMINGS = 15
 AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
@@ -19,7 +19,7 @@ def agg_width(family, n_groups=0):
     """Number of partial-sum vectors (of length n_t) the aggregation of a family exchanges."""
     return 3 if family == AGG_MIXTURE else (2 * int(n_groups) if family == AGG_RBCM else 2)
 TIMING_NAMES = ("gram", "chol_update", "chol_diag", "chol_trsm", "solve", "mll", "predict_gram",
-                "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce")
+                "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce", "alpha")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -47,9 +47,10 @@ typedef struct dsmgp_ctx dsmgp_ctx;
 #define DSMGP_E_NODEVICE   -5
 
 /* number of doubles dsmgp_timings() fills: gram, chol_update (the update launches of the tile kernel alone),
- * chol_diag, chol_trsm, solve, mll, predict_gram, predict_update, predict_trsm, predict_var, gradients, total_fit,
- * total_predict, chol_reduce (split-K reduce launches of the factorisation) */
-#define DSMGP_N_TIMINGS 14
+ * chol_diag, chol_trsm, solve (forward substitution of COPY / PREFIX leaves), mll, predict_gram, predict_update,
+ * predict_trsm, predict_var, gradients, total_fit, total_predict, chol_reduce (split-K reduce launches of the
+ * factorisation), alpha (the backward sweep alpha = L^-T z, run on first use after a fit: gradients, download_factor) */
+#define DSMGP_N_TIMINGS 15
 
 /* kernel ids are dense small integers (one hyper-vector each; finetune! gives every leaf its own) */
 #define DSMGP_MAX_KERNEL_IDS (1 << 22)
@@ -82,7 +83,8 @@ int dsmgp_set_hyper(dsmgp_ctx* ctx, int32_t kernel_id, int32_t kind, const doubl
 /* ---- fit!: Gram assembly + Cholesky + alpha for every leaf
  *      replaces fit!/fit_naive!/update_cholesky! (src/fit.jl:71-122,294-304; src/gaussianprocess.jl:82-108)
  *      and mll(gp) (src/gaussianprocess.jl:163).
- *      mll_out[l]  = -(y.alpha + logdet + n log 2pi)/2
+ *      mll_out[l]  = -(y.alpha + logdet + n log 2pi)/2, with y.alpha evaluated as |L^-1 y|^2; gp.alpha itself is
+ *                    materialised on first use (dsmgp_gradients, dsmgp_download_factor), not by fit
  *      info_out[l] = 0, or k>0 if the leading minor of order k is not positive definite (LAPACK potrf)
  *      seconds     = device time of the call (hipEvents), like the @elapsed value fit! returns */
 int dsmgp_fit(dsmgp_ctx* ctx, double* mll_out /* L */, int32_t* info_out /* L */, double* seconds);
