@@ -572,6 +572,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             S.trsm_off[k] = (int)trsm.size();
             S.diag_off[k] = (int)diag.size();
             std::vector<TileTask> tiles;
+            size_t nsym = 0;
             for (int l = 0; l < L; ++l) {
                 const LeafHost& lf = c->leaves[l];
                 if (lf.nb <= k || !in_phase(lf)) continue;
@@ -591,6 +592,8 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             u.k0 = 0;
                             u.k1 = k * TB;
                             u.update = 1;
+                            u.sym = (i == k) ? 1 : 0;   // diagonal tile: A == B, lower blocks only
+                            nsym += (size_t)u.sym;
                             tiles.push_back(u);
                         }
                         if (i > k) {
@@ -661,6 +664,14 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                     }
                 }
             }
+            // The lower-blocks-only form of a diagonal tile takes ~0.6 of a full tile (tools/bench_tile_sym.py).  It pays
+            // where diagonal tiles are a large share of a launch (many small leaves: -6 % on the update launches of the
+            // depth-4 model).  In launches dominated by full tiles it does not: tasks of one launch run in rounds of
+            // equal duration and tiles that share a B panel stream it through L2 together; a few shorter tasks mixed in
+            // break that lockstep (measured +1.2 % on the headline model, +0.4 % when issued last), so there the
+            // diagonal tiles stay full tiles.
+            if (nsym * 5 < tiles.size())
+                for (auto& u : tiles) u.sym = 0;
             U.add_step(tiles, k * TB);
             S.step_tiles[k] = (int)tiles.size();
         }
@@ -978,7 +989,9 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int nd = S.diag_off[k + 1] - S.diag_off[k];
         if (nd > 0) {
             pt.begin(2);
-            chol_diag_kernel<<<nd, 256, DIAG_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
+            // more blocks than CUs: the throughput form (two workgroups per CU); else the latency form
+            if (nd > c->ncu) chol_diag_packed_kernel<<<nd, 256, DIAGP_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
+            else chol_diag_kernel<<<nd, 256, DIAG_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
             pt.note(k, nd, 0);
             pt.end();
         }
@@ -1037,6 +1050,8 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
@@ -2259,7 +2274,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     if (!c || ntiles <= 0 || K <= 0 || K % KC || !seconds_per_launch || group <= 0) return DSMGP_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t panel = (size_t)TB * K;
-    const int nA = mode == 1 ? 1 : (mode == 3 ? (ntiles + group - 1) / group * group : ntiles);
+    const int nA = mode == 1 ? 1 : ((mode == 3 || mode == 5) ? (ntiles + group - 1) / group * group : ntiles);
     const int nB = mode == 1 ? 1 : (ntiles + group - 1) / group;
     if (mode == 2 && std::getenv("DSMGP_STAMPS")) return fail(c, DSMGP_E_ARG, "no stamps in mode 2");
     double *A = nullptr, *B = nullptr, *C = nullptr;
@@ -2282,7 +2297,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
         t.B = B + (mode == 1 ? 0 : (size_t)(i / group) * panel);
         t.C = C + (size_t)i * TB * TB;
         t.lda = t.ldb = TB;
-        if (mode == 3) {   // A tiles are row tiles of a (group*128) x K column-major matrix, like the rows of Vt
+        if (mode == 3 || mode == 5) {   // A tiles are row tiles of a (group*128) x K column-major matrix, like the rows of Vt
             t.A = A + (size_t)(i / group) * group * panel + (size_t)(i % group) * TB;
             t.lda = group * TB;
         }
@@ -2290,6 +2305,11 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
         t.k0 = 0;
         t.k1 = K;
         t.update = 1;
+        if (mode == 4 || mode == 5) {   // diagonal tiles of the factorisation: C -= A A^T, lower blocks only
+            t.B = t.A;
+            t.ldb = t.lda;
+            t.sym = 1;
+        }
         tasks[i] = t;
     }
     // mode 0/1: the raw batch; mode 2: the batch as UpdateSplitter would schedule it (split-K + reduce)

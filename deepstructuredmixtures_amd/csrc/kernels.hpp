@@ -172,6 +172,8 @@ struct TileTask {
     int lda, ldb, ldc;
     int k0, k1;         // K range, multiples of 8
     int update;         // 0 = store the product, 1 = C - product
+    int sym;            // 1: diagonal tile of the factorisation, B == A (C -= A A^T): only the lower 16x16 blocks are
+                        //    computed and written (tile_syrk_body); the strictly upper blocks of C are left alone
 };
 
 // diagnostic builds (-DDSMGP_DIAG, tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
@@ -404,6 +406,168 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Diagonal tiles of the factorisation: F[k,k] -= F[k,0:K] F[k,0:K]^T is symmetric, and chol_diag_*_kernel reads only
+// the lower 16x16 blocks of the tile (whole blocks on the diagonal).  Of the 8 x 8 grid of 16x16 MFMA tiles the 36
+// lower ones are computed, 9 per wave:
+//   wave 0: block rows 5..7 x block columns 0..2      wave 1: rows 5..7 x columns 3..5
+//   wave 2: block rows 2..4 x block columns 0..2      wave 3: the three 2x2 lower triangles at blocks 0, 3 and 6
+// Every wave reads 6 operand fragments per 4-column group (one LDS image: B == A) for its 9 MFMAs: 9/16 of the matrix
+// work, half the global and LDS staging traffic of a full tile.  Same ring / prefetch protocol as gemm_mainloop_v2.
+template <int SHAPE>   // 0: 3x3 square (F[0..2] rows, F[3..5] columns), 1: three 2x2 lower triangles (F[2q], F[2q+1])
+__device__ __forceinline__ void syrk_mainloop(const TileTask& tk, d4 (&acc)[9], double (*sA)[KC2 * LDP], const int (&blk)[6]) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int scol = t >> 5, srow = 2 * (t & 31);
+    const double* gA = tk.A + srow + (size_t)(tk.k0 + scol) * tk.lda;
+    const int sOff = scol * LDP + srow;
+    d2 ra0[2], ra1[2];
+#define SGLOAD(RA, CH)                                                                           \
+    do {                                                                                         \
+        const size_t oa_ = (size_t)(CH) * KC2 * tk.lda;                                          \
+        RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
+        RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                                    \
+    } while (0)
+#define SSWRITE(RA, BUF)                                                                         \
+    do {                                                                                         \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA[0];                                          \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                                     \
+    } while (0)
+#define SFRAGS(F, BUF, G)                                                                        \
+    do {                                                                                         \
+        const double* p_ = &sA[BUF][((G) * 4 + l4) * LDP + l15];                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) F[i_] = p_[16 * blk[i_]];               \
+    } while (0)
+#define SMFMA9(F)                                                                                \
+    do {                                                                                         \
+        if (SHAPE == 0) {                                                                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                     \
+                _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                 \
+                    acc[3 * i_ + j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[3 + j_], F[i_], acc[3 * i_ + j_], 0, 0, 0); \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                   \
+                acc[3 * q_] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2 * q_], F[2 * q_], acc[3 * q_], 0, 0, 0); \
+                acc[3 * q_ + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2 * q_], F[2 * q_ + 1], acc[3 * q_ + 1], 0, 0, 0); \
+                acc[3 * q_ + 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2 * q_ + 1], F[2 * q_ + 1], acc[3 * q_ + 2], 0, 0, 0); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+    const int nch = (tk.k1 - tk.k0) / KC2;
+    if (nch > 0) {
+        SGLOAD(ra0, 0);
+        SGLOAD(ra1, min(1, nch - 1));
+        SSWRITE(ra0, 0);
+        SGLOAD(ra0, min(2, nch - 1));
+        SSWRITE(ra1, 1);
+        SGLOAD(ra1, min(3, nch - 1));
+        SSWRITE(ra0, 2);
+    }
+    __syncthreads();
+    double f0[6], f1[6];
+    if (nch > 0) SFRAGS(f0, 0, 0);
+#define SCHUNK(C, LRA, WRA)                                                                      \
+    do {                                                                                         \
+        const int c_ = (C);                                                                      \
+        const int buf_ = c_ & (NRING - 1);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        SGLOAD(LRA, min(c_ + 4, nch - 1));                                                       \
+        SFRAGS(f1, buf_, 1);                                                                     \
+        SMFMA9(f0);                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                   \
+        }                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+        }                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        SSWRITE(WRA, (c_ + 3) & (NRING - 1));                                                    \
+        SFRAGS(f0, (c_ + 1) & (NRING - 1), 0);                                                   \
+        SMFMA9(f1);                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                   \
+        }                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+        }                                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __syncthreads();                                                                         \
+    } while (0)
+    int c = 0;
+    for (; c + 1 < nch; c += 2) {
+        SCHUNK(c, ra0, ra1);
+        SCHUNK(c + 1, ra1, ra0);
+    }
+    if (c < nch) SCHUNK(c, ra0, ra1);
+#undef SCHUNK
+#undef SMFMA9
+#undef SFRAGS
+#undef SSWRITE
+#undef SGLOAD
+}
+
+// store / subtract the 9 tiles of a wave: register r of the tile at (block row rb, block column cb) is
+// C(16 rb + l15, 16 cb + l4 + 4 r)
+template <int SHAPE>
+__device__ __forceinline__ void syrk_epilogue(const TileTask& tk, d4 (&acc)[9], const int (&blk)[6]) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const size_t ldc = (size_t)tk.ldc;
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {       // three tiles at a time: loads of a group in flight before its stores
+        int rb[3], cb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (SHAPE == 0) {
+                rb[j] = blk[g3];
+                cb[j] = blk[3 + j];
+            } else {
+                rb[j] = blk[2 * g3 + (j > 0 ? 1 : 0)];
+                cb[j] = blk[2 * g3 + (j > 1 ? 1 : 0)];
+            }
+        }
+        double cv[3][4];
+        if (tk.update == 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cv[j][r] = AS_GLOBAL_F64(tk.C)[(size_t)(16 * rb[j] + l15) + (size_t)(16 * cb[j] + l4 + 4 * r) * ldc];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = acc[3 * g3 + j][r];
+                AS_GLOBAL_F64(tk.C)[(size_t)(16 * rb[j] + l15) + (size_t)(16 * cb[j] + l4 + 4 * r) * ldc] =
+                    (tk.update == 1) ? cv[j][r] - v : v;
+            }
+    }
+}
+
+__device__ __forceinline__ void tile_syrk_body(const TileTask& tk, double (*sA)[KC2 * LDP]) {
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    d4 acc[9];
+    if (w == 3) {
+        const int blk[6] = {0, 1, 3, 4, 6, 7};
+        syrk_mainloop<1>(tk, acc, sA, blk);
+        syrk_epilogue<1>(tk, acc, blk);
+    } else {
+        const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
+        const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
+        syrk_mainloop<0>(tk, acc, sA, blk);
+        syrk_epilogue<0>(tk, acc, blk);
+    }
+}
+
 // ROLE only names the instantiation (same code): 0 = update launches (whole tiles and split-K pieces), 1 = panel
 // solves (K = 128), so that profilers report the two populations as two kernels
 // (tile_gemm_kernel_v2<false, 0> is the dominant kernel of bench.py's roofline).
@@ -413,6 +577,10 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
     __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
     __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
     const TileTask tk = tasks[blockIdx.x];
+    if (tk.sym) {       // diagonal tile of the factorisation: lower blocks only (workgroup-uniform branch)
+        tile_syrk_body(tk, sA);
+        return;
+    }
     d4 acc[4][4];
     gemm_mainloop_v2<STAMP>(tk, acc, sA, sB, stamps);
     tile_epilogue(tk, acc, &sA[0][0]);
@@ -1019,6 +1187,300 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restri
     extern __shared__ __attribute__((aligned(16))) double S[];   // [128 cols][DLD rows] + Winv[256] + rhs[128]
     const DiagTask tk = tasks[blockIdx.x];
     chol_diag_body<false>(tk, S, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Throughput form of the diagonal-block kernel: the same factorisation with a 75 KB LDS image, so TWO workgroups fit a
+// CU (the latency form above holds L and L^-1 side by side in 147 KB: one per CU).  Used when a launch has more
+// blocks than the chip has CUs (thousands of small leaves: depth >= 3 trees); launches of the headline regime, where
+// the kernel sits on the chain of dependent launches with fewer blocks than CUs, keep the latency form.
+//   image : the 36 lower 16x16 blocks in a 9 x 4 block rectangle (PLD = 144 rows, 64 columns): block (I,K) with
+//           K < 4 at block position (I, K); the ten blocks with K >= 4 fill the six free positions above the
+//           diagonal of the first four block columns and the ninth block row (PackedMap)
+//   phase 1: blocked right-looking Cholesky exactly as above (potrf_inv16 on wave 0 with lookahead, panel products,
+//           trailing products) without the inverse products.  L_JJ goes from registers straight to the tile in global
+//           memory; its slot in the image keeps L_JJ^-1 (operand of the panel products and of phase 2)
+//   phase 2: after the off-diagonal blocks of L are written out, L^-1 overwrites L in place, block column by block
+//           column from the right:  Y(J) = L(J,K) X(K,K) (J > K), then X(I,K) = - sum_{J=K+1..I} X(I,J) Y(J), computed
+//           into registers by all waves, written after a barrier (other waves still read the Y blocks)
+constexpr int PLD = 144;
+constexpr int PIMG = 64 * PLD;
+constexpr int DIAGP_LDS_BYTES = (PIMG + TB + 64) * (int)sizeof(double);   // image + rhs block + block-offset table
+
+struct PackedMap {
+    unsigned short off[64];     // [I * 8 + K], doubles; 0xFFFF above the diagonal
+    unsigned char lower[36];    // the 36 lower blocks, I << 4 | K, column by column
+    constexpr PackedMap() : off{}, lower{} {
+        const int freeR[10] = {0, 0, 1, 0, 1, 2, 8, 8, 8, 8}, freeC[10] = {1, 2, 2, 3, 3, 3, 0, 1, 2, 3};
+        int f = 0, n = 0;
+        for (int K = 0; K < 8; ++K)
+            for (int I = 0; I < 8; ++I) {
+                if (I < K) {
+                    off[I * 8 + K] = 0xFFFF;
+                    continue;
+                }
+                int R = I, C = K;
+                if (K >= 4) {
+                    R = freeR[f];
+                    C = freeC[f];
+                    ++f;
+                }
+                off[I * 8 + K] = (unsigned short)((C * 16) * PLD + R * 16);
+                lower[n++] = (unsigned char)(I << 4 | K);
+            }
+    }
+};
+__constant__ const PackedMap PACKED{};
+
+__global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* __restrict__ tasks) {
+    extern __shared__ __attribute__((aligned(16))) double S[];   // image [64 cols][PLD rows] + rhs[128] + int off[64]
+    const DiagTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double* wl = S + PIMG;
+    int* soff = reinterpret_cast<int*>(S + PIMG + TB);
+    // block offsets: lane l keeps the offset of block (l >> 3, l & 7) and the l-th lower block; wave-uniform lookups
+    // are v_readlane, per-thread lookups (the fused z at the end) go through the copy in LDS
+    const int mytab = PACKED.off[lane];
+    const int myblk = PACKED.lower[lane < 36 ? lane : 0];
+    if (t < 64) soff[t] = mytab;
+    auto off = [&](int I, int K) { return __builtin_amdgcn_readlane(mytab, I * 8 + K); };
+
+    {   // lower blocks of the tile -> image: 9 blocks per wave, a lane moves four rows of one column of a block
+        const int bc = lane >> 2, br = 4 * (lane & 3);
+        d2 v[9][2];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
+            const int I = e >> 4, K = e & 15;
+            const gd2_cptr src = AS_GLOBAL_D2(tk.T + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * tk.ld);
+            v[q][0] = src[0];
+            v[q][1] = src[1];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
+            double* dst = S + off(e >> 4, e & 15) + bc * PLD + br;
+            *reinterpret_cast<d2*>(dst) = v[q][0];
+            *reinterpret_cast<d2*>(dst + 2) = v[q][1];
+        }
+    }
+    if (tk.wk != nullptr && t < TB) wl[t] = tk.wk[t];
+    __syncthreads();
+
+    int bad = 0;
+    // diagonal block J on wave 0: L_JJ -> global tile (from registers), L_JJ^-1 -> its slot in the image and -> Dinv
+    auto diag_block = [&](int J) {
+        const int c = l15;
+        const bool isb = (lane & 16) != 0;
+        double x[16], xs, xd;
+        double* slot = S + off(J, J) + c * PLD;
+        const d2* src = reinterpret_cast<const d2*>(slot);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const d2 v = src[r >> 1];
+            x[r] = isb ? ((r == c) ? 1.0 : 0.0) : v[0];
+            x[r + 1] = isb ? ((r + 1 == c) ? 1.0 : 0.0) : v[1];
+        }
+        const int bj = potrf_inv16(x, xs, xd, lane);
+        if (bj != 0 && bad == 0) bad = J * 16 + bj;
+        if (lane < 32) {
+            const int thr = isb ? c : c + 1;
+            const double mul = isb ? 1.0 : xs;
+            double* gdst = isb ? tk.Dinv + (size_t)(16 * J) + (size_t)(16 * J + c) * TB
+                               : tk.T + (size_t)(16 * J) + (size_t)(16 * J + c) * tk.ld;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                d2 v;
+                v[0] = (r >= thr) ? x[r] * mul : ((r == c) ? xd : 0.0);
+                v[1] = (r + 1 >= thr) ? x[r + 1] * mul : ((r + 1 == c) ? xd : 0.0);
+                *reinterpret_cast<d2*>(gdst + r) = v;
+                if (isb) *reinterpret_cast<d2*>(slot + r) = v;
+            }
+        }
+    };
+    struct BlkOp {
+        const double* pa; int saa, sak;
+        const double* pb; int sbk;
+        double* dst;
+    };
+    // two independent block products at once (see chol_diag_body): dst (-)= Bop Aop^T
+    auto run_pair = [&](const BlkOp& o0, const BlkOp& o1, bool two, bool subtract) {
+        double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = 4 * q + l4;
+            a0[q] = o0.pa[l15 * o0.saa + kk * o0.sak];
+            b0[q] = o0.pb[l15 + kk * o0.sbk];
+            a1[q] = o1.pa[l15 * o1.saa + kk * o1.sak];
+            b1[q] = o1.pb[l15 + kk * o1.sbk];
+        }
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        double c0[4], c1[4];
+        if (subtract) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                c0[r] = o0.dst[(l4 + 4 * r) * PLD + l15];
+                c1[r] = o1.dst[(l4 + 4 * r) * PLD + l15];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o0.dst[(l4 + 4 * r) * PLD + l15] = subtract ? c0[r] - acc0[r] : acc0[r];
+        if (two) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o1.dst[(l4 + 4 * r) * PLD + l15] = subtract ? c1[r] - acc1[r] : acc1[r];
+        }
+    };
+    auto op_trailing = [&](int J, int I, int K) {   // S(I,K) -= S(I,J) S(K,J)^T
+        return BlkOp{S + off(K, J), 1, PLD, S + off(I, J), PLD, S + off(I, K)};
+    };
+
+    // ---- phase 1: factorisation
+    if (w == 0) diag_block(0);
+    __syncthreads();
+    for (int J = 0; J < 8; ++J) {
+        const int mytask = DIAG_TASKS.e[J][lane < 36 ? lane : 0];
+        {   // P1: S(I,J) <- S(I,J) L_JJ^-T, I > J; wave w takes I = J+1+w and J+1+w+4
+            const int m = 7 - J;
+            if (w < m) {
+                double* d0 = S + off(J + 1 + w, J);
+                const bool two = w + 4 < m;
+                double* d1 = two ? S + off(J + 1 + w + 4, J) : d0;
+                const double* linv = S + off(J, J);
+                run_pair(BlkOp{linv, 1, PLD, d0, PLD, d0}, BlkOp{linv, 1, PLD, d1, PLD, d1}, two, false);
+            }
+        }
+        __syncthreads();
+        const int m = 7 - J;
+        if (w == 0) {
+            if (m > 0) {
+                const BlkOp o = op_trailing(J, J + 1, J + 1);
+                run_pair(o, o, false, true);
+                diag_block(J + 1);
+            }
+        } else {
+            const int total = DIAG_TASKS.ntrail[J];
+            auto op_p2 = [&](int task) {
+                const int e = __builtin_amdgcn_readlane(mytask, task);
+                return op_trailing(J, (e >> 4) & 15, e & 15);
+            };
+            for (int task = 1 + (w - 1); task < total; task += 6) {
+                const bool two = task + 3 < total;
+                const BlkOp o0 = op_p2(task);
+                run_pair(o0, two ? op_p2(task + 3) : o0, two, true);
+            }
+        }
+        __syncthreads();
+    }
+    bad = __shfl(bad, 0);
+    // ---- off-diagonal blocks of L -> tile, zeros above the diagonal (diagonal blocks were written by diag_block);
+    //      the same sweep zeroes the upper blocks of Dinv.  16 of the 64 blocks per wave.
+    {
+        const int bc = lane >> 2, br = 4 * (lane & 3);
+        const d2 zero = {0.0, 0.0};
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int b = w + 4 * q, I = b >> 3, K = b & 7;
+            if (I == K) continue;
+            double* gT = tk.T + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * tk.ld;
+            if (I > K) {
+                const double* src = S + off(I, K) + bc * PLD + br;
+                *reinterpret_cast<d2*>(gT) = *reinterpret_cast<const d2*>(src);
+                *reinterpret_cast<d2*>(gT + 2) = *reinterpret_cast<const d2*>(src + 2);
+            } else {
+                double* gD = tk.Dinv + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * TB;
+                *reinterpret_cast<d2*>(gT) = zero;
+                *reinterpret_cast<d2*>(gT + 2) = zero;
+                *reinterpret_cast<d2*>(gD) = zero;
+                *reinterpret_cast<d2*>(gD + 2) = zero;
+            }
+        }
+    }
+    __syncthreads();   // every wave has read its L blocks: the image may be overwritten
+    // ---- phase 2: L^-1 in place, block columns from the right
+    for (int K = 6; K >= 0; --K) {
+        const int m = 7 - K;
+        if (w < m) {   // (a) Y(J) = L(J,K) X(K,K), J = K+1+w and K+1+w+4
+            double* d0 = S + off(K + 1 + w, K);
+            const bool two = w + 4 < m;
+            double* d1 = two ? S + off(K + 1 + w + 4, K) : d0;
+            const double* xkk = S + off(K, K);
+            run_pair(BlkOp{xkk, PLD, 1, d0, PLD, d0}, BlkOp{xkk, PLD, 1, d1, PLD, d1}, two, false);
+        }
+        __syncthreads();
+        // (b) X(I,K) = - sum_{J=K+1..I} X(I,J) Y(J): outputs i = 0..m-1 (I = K+1+i, i+1 products); wave w takes the
+        //     short chain i = w and the long chain i = m-1-w, interleaved
+        const bool have = w < (m + 1) / 2;
+        const int i1 = w, i2 = m - 1 - w;
+        const bool two = have && i2 > i1;
+        d4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        if (have) {
+            const int I1 = K + 1 + i1, I2 = K + 1 + i2;
+            for (int s = 0; s <= i2; ++s) {
+                const int J = K + 1 + s;
+                const double* y = S + off(J, K);                 // Y(J): Aop(a,k) = Y(k,a)
+                double ya[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ya[q] = y[l15 * PLD + (4 * q + l4)];
+                if (s <= i1) {
+                    const double* x1 = S + off(I1, J);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q], x1[l15 + (4 * q + l4) * PLD], acc1, 0, 0, 0);
+                }
+                if (two) {
+                    const double* x2 = S + off(I2, J);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q], x2[l15 + (4 * q + l4) * PLD], acc2, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (have) {
+            double* d1 = S + off(K + 1 + i1, K);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[(l4 + 4 * r) * PLD + l15] = -acc1[r];
+            if (two) {
+                double* d2p = S + off(K + 1 + i2, K);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d2p[(l4 + 4 * r) * PLD + l15] = -acc2[r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- off-diagonal blocks of L^-1 -> Dinv (7 of the 28 per wave)
+    {
+        const int bc = lane >> 2, br = 4 * (lane & 3);
+#pragma unroll 3
+        for (int q = 0; q < 9; ++q) {
+            const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
+            const int I = e >> 4, K = e & 15;
+            if (I == K) continue;
+            const double* src = S + off(I, K) + bc * PLD + br;
+            double* gD = tk.Dinv + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * TB;
+            *reinterpret_cast<d2*>(gD) = *reinterpret_cast<const d2*>(src);
+            *reinterpret_cast<d2*>(gD + 2) = *reinterpret_cast<const d2*>(src + 2);
+        }
+    }
+    if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
+    if (tk.wk != nullptr) {
+        // z_k = L_kk^-1 w_k from the inverse still in the image: thread (r = t >> 1, h = t & 1) sums the columns
+        // [64h, 64h+64) of row r
+        const int r = t >> 1, h = t & 1;
+        const int R = r >> 4, ri = r & 15;
+        double sum = 0.0;
+        const int cend = min(r, 64 * h + 63);
+        for (int c = 64 * h; c <= cend; ++c) sum = fma(S[soff[R * 8 + (c >> 4)] + (c & 15) * PLD + ri], wl[c], sum);
+        sum += __shfl_xor(sum, 1);
+        if (h == 0) tk.zk[r] = sum;
+    }
 }
 
 #ifdef DSMGP_DIAG

@@ -933,3 +933,45 @@ def test_aggregate_error_paths(ctx):
     ml, vl = ctx.predict_fetch()
     t = 1 / vl.reshape(2, 20)
     assert np.allclose(var, 1 / t.sum(0), rtol=1e-14) and np.allclose(mu, (t * ml.reshape(2, 20)).sum(0) / t.sum(0), rtol=1e-13)
+
+
+def test_throughput_and_latency_forms_of_the_diagonal_block_kernel_agree(ctx):
+    """A launch with more diagonal blocks than CUs takes the 75 KB packed kernel (two workgroups per CU, L^-1 formed in
+    place after L), smaller launches the 147 KB latency kernel: same factors, inverses (through alpha and the
+    prediction) and fused forward solves, to rounding.  600 leaves of 140..330 rows in one table against the same
+    leaves fitted 100 at a time, and a sample against the oracle."""
+    N, D, L = 40_000, 3, 600
+    X, y, Xt = regression_data(N, D, n_test=40, seed=4711)
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(140, 331, size=L)
+    obs = [np.sort(rng.choice(N, size=int(n), replace=False)) for n in sizes]
+    hyp = [np.log(0.3), 0.0, np.log(0.1)]
+
+    def run(sel):
+        ctx.set_train(X, y)
+        ctx.set_leaves(np.concatenate([[0], np.cumsum([obs[j].size for j in sel])]), np.concatenate([obs[j] for j in sel]),
+                       np.zeros(len(sel), dtype=np.int32), [float(np.mean(y[obs[j]])) for j in sel])
+        ctx.set_sharing(None, None, None)
+        ctx.set_hyper(0, 0, hyp)
+        mll, info, _ = ctx.fit()
+        assert np.all(info == 0)
+        nt = Xt.shape[0]
+        mu, var = ctx.predict_leaves(Xt, np.arange(len(sel) + 1) * nt, np.tile(np.arange(nt), len(sel)))
+        alphas = [ctx.download_factor(i, obs[j].size)[1] for i, j in enumerate(sel[:5])]
+        return mll, mu.reshape(len(sel), nt), var.reshape(len(sel), nt), alphas
+
+    big = run(list(range(L)))                                   # 600 blocks per launch > 256 CUs: packed kernel
+    for a in range(0, L, 100):                                  # 100 blocks per launch: latency kernel
+        sel = list(range(a, a + 100))
+        small = run(sel)
+        assert np.allclose(big[0][a:a + 100], small[0], rtol=1e-12)
+        assert np.allclose(big[1][a:a + 100], small[1], rtol=1e-11, atol=1e-12)
+        assert np.allclose(big[2][a:a + 100], small[2], rtol=1e-10, atol=1e-13)
+        if a == 0:
+            for u, v in zip(big[3], small[3]):
+                assert np.allclose(u, v, rtol=1e-10, atol=1e-12)
+    for j in (0, 299, 599):
+        g = ogp.GaussianProcess(X[obs[j]], y[obs[j]], float(np.mean(y[obs[j]])), ogp.IsoSE(hyp[0], hyp[1]), hyp[2], True).update_cholesky()
+        assert abs(big[0][j] - g.mll()) <= RTOL * abs(g.mll())
+        mo, vo = g.prediction(Xt)
+        assert np.allclose(big[1][j], mo, rtol=RTOL, atol=1e-9) and np.allclose(big[2][j], vo, rtol=RTOL, atol=1e-10)
