@@ -9,8 +9,11 @@ N=100k, D=8, IsoSE, tree depth 2 (reference default) -> 144 leaf GPs, n ~ 1.5k-1
 One step = fit! (Gram assembly + batched Cholesky + alpha + per-leaf mll) + update! + predict
 (K_tn assembly, triangular solves, predictive moments, sum/product aggregation), inputs resident in HBM.
 With N > 1 the SAME model is sharded leaf-wise over the ranks (strong scaling); the only exchange is
-an all-gather of per-leaf log-marginals and per-(leaf, test row) moments (RCCL over xGMI).
-Rank 0 prints one JSON line.
+an all-gather of per-leaf log-marginals after fit! and of the aggregation's partial sums (3 n_t doubles per rank) after
+predict (RCCL over xGMI).  Rank 0 prints one JSON line.
+
+    python bench.py --mode train [--steps 5]     one train! iteration (src/optimisers.jl:40-80) per step: setparams!,
+                                                 fit!, mll, updategradients!, grad of the tree mll, stateless-ADAM step
 """
 import argparse
 import json
@@ -23,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_FILE = "r02_update_kernel_traffic.json"
 F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X public spec, fp64 matrix = fp64 vector; the in-container guide lists no fp64 figure
 
 CONFIGS = {
@@ -128,12 +132,103 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
                                f"{written3 / lean3:.2f}x the lean form on 3 sampled leaves ({lean3:.1f} s vs {written3:.1f} s)"}
 
 
+def bench_train(args, model, X, y, rank, world, td, torch):
+    """One train! iteration per step (src/optimisers.jl:40-80) on the bench config: setparams!, fit!, tree mll,
+    updategradients! (L^-T by blocked triangular inversion + contraction tiles), gradient of the tree mll
+    (src/optimize.jl:42-89), stateless-ADAM step.  Not the BASELINE metric: printed with its own name."""
+    import deepstructuredmixtures_amd as dsm
+    ctx = model.ctx
+    ctx.set_joint(False)
+    ctx.set_profile(1)
+    opt = dsm.ADAM()
+    hyp = dsm.getparams(model).copy()
+
+    def iteration(h):
+        t = {}
+        a = time.perf_counter()
+        dsm.setparams(model, h)
+        dsm.fit(model)
+        ell = dsm.mll(model)
+        b = time.perf_counter()
+        dsm.updategradients(model)
+        c_ = time.perf_counter()
+        g = dsm.grad_mll(model)
+        h = h + opt.apply(h, g)
+        d = time.perf_counter()
+        t.update(fit_wall=b - a, grad_wall=c_ - b, tree_wall=d - c_, mll=ell)
+        return h, t
+
+    t_first = time.perf_counter()
+    hyp, first = iteration(hyp)                      # builds the gradient plan and the L^-T arena
+    t_first = time.perf_counter() - t_first
+    for _ in range(max(0, args.warmup - 1)):
+        hyp, _t = iteration(hyp)
+    torch.cuda.synchronize()
+    if td is not None:
+        td.barrier()
+    t0 = time.perf_counter()
+    acc = {}
+    hist = []
+    for _ in range(args.steps):
+        hyp, t = iteration(hyp)
+        hist.append(t.pop("mll"))
+        for k, v in t.items():
+            acc[k] = acc.get(k, 0.0) + v
+        for k, v in ctx.timings().items():
+            acc["dev_" + k] = acc.get("dev_" + k, 0.0) + v
+    torch.cuda.synchronize()
+    if td is not None:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    if td is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    per = elapsed / args.steps
+    n = args.steps
+    fi, fc, ntiles = ctx.work_gradients() if hasattr(ctx, "work_gradients") else (0.0, 0.0, 0)
+    fl_upd, _ = ctx.work()
+    if rank == 0:
+        c = CONFIGS[args.config]
+        dev = {k[4:]: v / n for k, v in acc.items() if k.startswith("dev_") and v > 0}
+        out = {"metric": "train! iteration wall-clock, DSMGP N=%dk D=%d" % (c["N"] // 1000, c["D"]), "value": per, "unit": "s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3,
+               "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"one train! iteration (setparams!, fit!, mll, updategradients!, grad of the tree mll, "
+                                      f"stateless ADAM step) of buildDSMGP K=4 splits V=3 sum children M={c['M']} N={c['N']} "
+                                      f"D={c['D']} depth {c['depth']}: {model.L} leaf GPs",
+                          "parallelism": f"leaves sharded over {world} GPU(s)"},
+               "first_iteration_s": t_first,
+               "host_wall_per_iteration": {k: v / n for k, v in acc.items() if not k.startswith("dev_")},
+               "device_seconds_per_iteration": dev,
+               "host_overhead_per_iteration": per - dev.get("total_fit", 0.0) - dev.get("gradients", 0.0) - dev.get("alpha", 0.0),
+               "mll_history": hist}
+        if world == 1 and dev.get("grad_contraction", 0.0) > 0:
+            ach = fc / dev["grad_contraction"] / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / F64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                               "kernel": f"tile_graddot_kernel: {ntiles} contraction tiles in one launch, n^3/3 flops per IsoSE leaf "
+                                         "(epilogue: squared distance + exp per element)"}
+            out["roofline_inverse"] = {"bound": "mfma", "achieved": fi / dev["grad_inverse"] / 1e12, "peak": F64_MATRIX_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": fi / dev["grad_inverse"] / 1e12 / F64_MATRIX_PEAK_TFLOPS,
+                                       "kernel": "L^-T by blocked triangular inversion: tile_gemm_kernel_v2 + tile_trsm_kernel + "
+                                                 "tile_reduce_kernel launches of dsmgp_gradients, n^3/3 flops per factor"}
+            out["roofline_fit_update"] = {"achieved": fl_upd / dev["chol_update"] / 1e12 if dev.get("chol_update") else None,
+                                          "unit": "TFLOP/s", "kernel": "update launches of fit! inside the iteration"}
+        print(json.dumps(out))
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="dsmgp_n100k_d8", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="fit_predict", choices=["fit_predict", "train"],
+                    help="fit_predict: the BASELINE metric (default); train: one train! iteration per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
     ap.add_argument("--sub", type=int, default=None,
@@ -197,6 +292,8 @@ def main():
         n_sub = args.sub if args.sub is not None else default_sub(world)
         model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
     ctx = model.ctx
+    if args.mode == "train":
+        return bench_train(args, model, X, y, rank, world, td, torch)
     ctx.set_profile(0 if args.no_profile else 1)   # timed region: events around the update launches only
     # the evaluation loop knows its test set: register it before the first fit, so that warm-up and timed steps run
     # the same launches (and a process-wide rocprofv3 --stats average of the update kernel is the timed-region average)
@@ -208,9 +305,11 @@ def main():
             td.barrier()
             torch.cuda.synchronize()
 
+    root = [0.0]
+
     def step():
         dsm.fit(model)
-        dsm.update(model)
+        root[0] = dsm.update(model)
         return dsm.predict(model, Xt)
 
     for _ in range(args.warmup):
@@ -250,18 +349,40 @@ def main():
         avg_launch = cats["chol_update"] / max(1, upd_launches)
         flops_per_launch = alg_flops * args.steps / max(1, upd_launches)
         achieved = flops_per_launch / avg_launch / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_update_kernel_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard:   # from the committed rocprofv3 --pmc passes of this command
+        traffic = traffic_source = None
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if os.path.exists(tpath) and world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard:
+            # PMC counters cannot be collected inside this run: the figure is the one of the committed rocprofv3 --pmc
+            # passes of this same command (tools/profile_round.sh), NOT a measurement of this run
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/{TRAFFIC_FILE} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "tile_gemm_kernel_v2<false, 0, 0> (update launches of the factorisation, test rows riding along; "
-                          "panel solves run as <false, 0, 1>, split-K reduces as tile_reduce_kernel)",
+                "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "tile_gemm_kernel_v2<false, 0> (update launches of the factorisation, test rows riding along; "
+                          "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel; the reduce "
+                          "launches are timed apart: device_seconds_per_step.chol_reduce)",
                 "avg_launch_ms": avg_launch * 1e3, "launches_per_step": upd_launches // args.steps,
                 "alg_flops_per_step": alg_flops}
     nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)
     matrix_flops_total = float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2 * np.diff(ptr)))   # Cholesky + predict solves
+
+    # The drop-in call pattern of src/common.jl:304 -- fit! on a model that has never seen the test set, then
+    # predict(model, x) -- next to the joint step above (untimed extra; one GPU only).
+    standalone = None
+    if world == 1 and not args.simulate_shard and not CONFIGS[args.config].get("stream"):
+        ctx.set_profile(0)
+        ctx.set_joint(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dsm.fit(model)
+        dsm.update(model)
+        t1 = time.perf_counter()
+        mu_s, var_s = dsm.predict(model, Xt)
+        t2 = time.perf_counter()
+        ctx.set_joint(True)
+        assert np.allclose(mu_s, mu, rtol=1e-9, atol=1e-11) and np.allclose(var_s, var, rtol=1e-8, atol=1e-12)
+        standalone = {"fit_s": t1 - t0, "predict_s": t2 - t1,
+                      "note": "fit! + update! without a resident test set, then predict(model, Xt) running its own sweep"}
 
     if rank == 0:
         c = CONFIGS[args.config]
@@ -275,12 +396,17 @@ def main():
                                    f"depth {c['depth']}: {model.L} leaf GPs n={int(nobs.min())}..{int(nobs.max())}, "
                                    f"n_t={Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; "
                                    f"fit! (Gram+Cholesky+alpha+mll) + update! + predict",
-                       "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and (mu, var)"
+                       "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and of the aggregation's partial sums"
                                       + (f"; {n_sub} concurrent contexts per GPU" if n_sub > 1 else "")},
             "matrix_tflops_fit_predict": matrix_flops_total / ((cats.get("total_fit", 0.0) + cats.get("total_predict", 0.0))
                                                                / args.steps) / 1e12 if world == 1 else None,
             "device_seconds_per_step": {k: v / args.steps for k, v in cats.items() if v > 0},
+            "root_mll": root[0],
         }
+        if standalone is not None:
+            out["standalone_fit_s"] = standalone["fit_s"]
+            out["standalone_predict_s"] = standalone["predict_s"]
+            out["standalone_note"] = standalone["note"]
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:

@@ -1864,6 +1864,8 @@ int build_grad_plan(dsmgp_ctx* c) {
                 c->gdot_leaf.push_back(l);
             }
     }
+    // tiles that share a B operand (row tile j of L^-T) sit 8 apart so that they run on one XCD and share its L2
+    xcd_permute(gd, c->gdot_leaf, 0, gd.size(), c->xcd_order);
     if (int rc = dev_upload(c, c->gtrans, trans)) return rc;
     if (int rc = dev_upload(c, c->gfrob, frob)) return rc;
     if (int rc = dev_upload(c, c->gupd, U.upd)) return rc;
@@ -1896,6 +1898,10 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     HIPCHK(c, ev.init());
     const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
+    for (int i = 15; i < 18; ++i) c->timings[i] = 0.0;
+    EventPair e_inv, e_dot;     // three spans: L^-T | contraction | traces and dots
+    HIPCHK(c, e_inv.init());
+    HIPCHK(c, e_dot.init());
     // Xt = L^-T
     HIPCHK(c, hipMemsetAsync(c->arenaX, 0, c->arenaX_count * sizeof(double), c->stream));
     if (c->gtrans.count) transpose_tile_kernel<<<(int)c->gtrans.count * 16, 256, 0, c->stream>>>(c->gtrans.p);
@@ -1909,11 +1915,13 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
         const int ns = c->gtrsm_off[k + 1] - c->gtrsm_off[k];
         if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns, 1);
     }
+    HIPCHK(c, hipEventRecord(e_inv.a, c->stream));
     double* pfrob = c->d_gpart;
     double* pdot = pfrob + c->gfrob.count;
     double* pleaf = pdot + 2 * c->gdot.count;
-    if (c->gfrob.count) frob_kernel<<<(int)c->gfrob.count, 256, 0, c->stream>>>(c->gfrob.p, pfrob);
     if (c->gdot.count) tile_graddot_kernel<<<(int)c->gdot.count, 256, 0, c->stream>>>(c->gdot.p, c->d_kp, c->D, pdot);
+    HIPCHK(c, hipEventRecord(e_dot.a, c->stream));
+    if (c->gfrob.count) frob_kernel<<<(int)c->gfrob.count, 256, 0, c->stream>>>(c->gfrob.p, pfrob);
     dots_kernel<<<L, 256, 0, c->stream>>>(c->d_leaves, pleaf);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(t1, c->stream));
@@ -1921,6 +1929,12 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
     c->timings[10] = ms * 1e-3;
+    HIPCHK(c, hipEventElapsedTime(&ms, t0, e_inv.a));
+    c->timings[15] = ms * 1e-3;
+    HIPCHK(c, hipEventElapsedTime(&ms, e_inv.a, e_dot.a));
+    c->timings[16] = ms * 1e-3;
+    HIPCHK(c, hipEventElapsedTime(&ms, e_dot.a, t1));
+    c->timings[17] = ms * 1e-3;
     std::vector<double> part(c->gpart_count);
     HIPCHK(c, hipMemcpy(part.data(), c->d_gpart, c->gpart_count * sizeof(double), hipMemcpyDeviceToHost));
     // host assembly (fixed summation order -> reproducible)
@@ -2030,6 +2044,23 @@ int dsmgp_download_factor(dsmgp_ctx* c, int32_t leaf, double* F, double* alpha) 
 int dsmgp_timings(dsmgp_ctx* c, double* out) {
     if (!c || !out) return DSMGP_E_ARG;
     for (int i = 0; i < DSMGP_N_TIMINGS; ++i) out[i] = c->timings[i];
+    return 0;
+}
+
+int dsmgp_work_gradients(dsmgp_ctx* c, double* alg_flops_inverse, double* alg_flops_contraction, int32_t* n_contraction_tiles) {
+    if (!c) return DSMGP_E_ARG;
+    // L^-T of every factor owner: n^3/3; contraction (alpha alpha^T - K_y^-1) o K o P of every IsoSE leaf: the lower
+    // tiles of L^-T L^-1, n^3/3 again (2 x 128 x 128 x K per tile with K = n - 128 i)
+    double fi = 0.0, fc = 0.0;
+    for (int l = 0; l < c->L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        const double n = (double)lf.n;
+        if (lf.owner == l) fi += n * n * n / 3.0;
+        if (lf.kid < (int)c->hyper.size() && c->hyper[lf.kid].kind == DSMGP_KIND_ISO_SE) fc += n * n * n / 3.0;
+    }
+    if (alg_flops_inverse) *alg_flops_inverse = fi;
+    if (alg_flops_contraction) *alg_flops_contraction = fc;
+    if (n_contraction_tiles) *n_contraction_tiles = (int32_t)c->gdot.count;
     return 0;
 }
 

@@ -730,42 +730,89 @@ struct GradTask {
     int pad;
 };
 
+// The epilogue is a Gram tile of its own (squared distance + exp per element): the coordinates of the tile's 128 rows
+// and 128 columns and the two alpha blocks are staged once through the LDS the main loop no longer needs (D <= 35;
+// wider inputs read them from global memory, element by element).
+constexpr int GRADDOT_STAGE_D = 35;
 __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __restrict__ tasks,
                                                               const KParam* __restrict__ kp, int D,
                                                               double* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
-    __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
+    __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP];
     __shared__ double red[2][4];
+    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
+    double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem + NRING * KC2 * LDP);
     const GradTask g = tasks[blockIdx.x];
     const KParam p = kp[g.kid];
     d4 acc[4][4];
-    gemm_mainloop_v2<false>(g.gemm, acc, sA, sB, nullptr);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    gemm_mainloop_v2<false>(g.gemm, acc, sA, sB, nullptr);      // ends on a barrier: the ring is free
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
     const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
     const double l2 = p.l2[0];
     double s = 0.0, tr = 0.0;
+    if (D <= GRADDOT_STAGE_D) {
+        // smem: per dimension d 256 doubles (rows' coordinate | columns' coordinate), then alpha_a | alpha_b
+        double* xs = smem;
+        double* al = smem + (size_t)D * 256;
+        for (int e = t; e < D * 256; e += 256) {
+            const int d = e >> 8, rc = e & 255;
+            xs[e] = (rc < TB) ? ((rc < g.na) ? g.xa[rc + (size_t)d * g.ldx] : 0.0)
+                              : ((rc - TB < g.nb) ? g.xb[rc - TB + (size_t)d * g.ldx] : 0.0);
+        }
+        al[t] = (t < TB) ? ((t < g.na) ? g.alpha_a[t] : 0.0) : ((t - TB < g.nb) ? g.alpha_b[t - TB] : 0.0);
+        __syncthreads();
 #pragma unroll
-    for (int rn = 0; rn < 4; ++rn) {
-        const int r = wr * 64 + 16 * rn + l15;
-        const bool rv = r < g.na;
-        const double ar = rv ? g.alpha_a[r] : 0.0;
+        for (int rn = 0; rn < 4; ++rn) {
+            const int r = wr * 64 + 16 * rn + l15;
+            const bool rv = r < g.na;
+            const double ar = al[r];
+            double z[16];
 #pragma unroll
-        for (int cm = 0; cm < 4; ++cm)
+            for (int i = 0; i < 16; ++i) z[i] = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double a = xs[d * 256 + r];
+                const double* xb = xs + d * 256 + TB + wc * 64 + l4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = wc * 64 + 16 * cm + l4 + 4 * q;
-                if (rv && c < g.nb) {
-                    double z = 0.0;
-                    for (int d = 0; d < D; ++d) {
-                        const double u = g.xa[r + (size_t)d * g.ldx] - g.xb[c + (size_t)d * g.ldx];
-                        z = fma(u, u, z);
-                    }
-                    const double kv = p.sigma2 * exp(-0.5 * (z / l2));
-                    const double pre = ar * g.alpha_b[c] - acc[cm][rn][q];
-                    s = fma(pre * kv, z, s);
-                    if (g.diag && r == c) tr += acc[cm][rn][q];
+                for (int i = 0; i < 16; ++i) {
+                    const double u = a - xb[16 * (i >> 2) + 4 * (i & 3)];
+                    z[i] = fma(u, u, z[i]);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = wc * 64 + 16 * (i >> 2) + l4 + 4 * (i & 3);
+                if (rv && c < g.nb) {
+                    const double kv = p.sigma2 * exp(-0.5 * (z[i] / l2));
+                    const double pre = ar * al[TB + c] - acc[i >> 2][rn][i & 3];
+                    s = fma(pre * kv, z[i], s);
+                    if (g.diag && r == c) tr += acc[i >> 2][rn][i & 3];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn) {
+            const int r = wr * 64 + 16 * rn + l15;
+            const bool rv = r < g.na;
+            const double ar = rv ? g.alpha_a[r] : 0.0;
+#pragma unroll
+            for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = wc * 64 + 16 * cm + l4 + 4 * q;
+                    if (rv && c < g.nb) {
+                        double z = 0.0;
+                        for (int d = 0; d < D; ++d) {
+                            const double u = g.xa[r + (size_t)d * g.ldx] - g.xb[c + (size_t)d * g.ldx];
+                            z = fma(u, u, z);
+                        }
+                        const double kv = p.sigma2 * exp(-0.5 * (z / l2));
+                        const double pre = ar * g.alpha_b[c] - acc[cm][rn][q];
+                        s = fma(pre * kv, z, s);
+                        if (g.diag && r == c) tr += acc[cm][rn][q];
+                    }
+                }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_down(s, o);

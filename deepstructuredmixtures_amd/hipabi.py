@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 
-N_TIMINGS = 15
+N_TIMINGS = 18
 AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
@@ -19,7 +19,8 @@ def agg_width(family, n_groups=0):
     """Number of partial-sum vectors (of length n_t) the aggregation of a family exchanges."""
     return 3 if family == AGG_MIXTURE else (2 * int(n_groups) if family == AGG_RBCM else 2)
 TIMING_NAMES = ("gram", "chol_update", "chol_diag", "chol_trsm", "solve", "mll", "predict_gram",
-                "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce", "alpha")
+                "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce", "alpha",
+                "grad_inverse", "grad_contraction", "grad_traces")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -52,6 +53,7 @@ SIGNATURES = {
     "dsmgp_set_joint": (C.c_int, [_ctx, C.c_int32]),
     "dsmgp_timings": (C.c_int, [_ctx, _dp]),
     "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
+    "dsmgp_work_gradients": (C.c_int, [_ctx, _dp, _dp, _ip]),
     "dsmgp_release": (C.c_int, [_ctx]),
     "dsmgp_reserve": (C.c_int, [_ctx, C.c_int64]),
     "dsmgp_overlap_main": (C.c_int, [C.c_int32, _lp, _lp, C.c_int64, _lp, _lp]),
@@ -323,6 +325,12 @@ class Context:
         self._chk(self.lib.dsmgp_work(self.h, C.byref(f), C.byref(n)))
         return f.value, n.value
 
+    def work_gradients(self):
+        """(algorithmic flops of L^-T, of the contraction, number of contraction tiles) of dsmgp_gradients."""
+        a, b, n = C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
+        self._chk(self.lib.dsmgp_work_gradients(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def memory(self):
         a = C.c_int64(0)
         b = C.c_int64(0)
@@ -541,6 +549,10 @@ class MultiContext:
     def work(self):
         ws = [s.work() for s in self.act]
         return sum(w[0] for w in ws), max(w[1] for w in ws)
+
+    def work_gradients(self):
+        ws = [s.work_gradients() for s in self.act]
+        return sum(w[0] for w in ws), sum(w[1] for w in ws), sum(w[2] for w in ws)
 
     def probe_f64_mfma(self):
         return self.subs[0].probe_f64_mfma()

@@ -49,8 +49,9 @@ typedef struct dsmgp_ctx dsmgp_ctx;
 /* number of doubles dsmgp_timings() fills: gram, chol_update (the update launches of the tile kernel alone),
  * chol_diag, chol_trsm, solve (forward substitution of COPY / PREFIX leaves), mll, predict_gram, predict_update,
  * predict_trsm, predict_var, gradients, total_fit, total_predict, chol_reduce (split-K reduce launches of the
- * factorisation), alpha (the backward sweep alpha = L^-T z, run on first use after a fit: gradients, download_factor) */
-#define DSMGP_N_TIMINGS 15
+ * factorisation), alpha (the backward sweep alpha = L^-T z, run on first use after a fit: gradients, download_factor),
+ * grad_inverse (L^-T by blocked triangular inversion), grad_contraction (tile_graddot_kernel), grad_traces */
+#define DSMGP_N_TIMINGS 18
 
 /* kernel ids are dense small integers (one hyper-vector each; finetune! gives every leaf its own) */
 #define DSMGP_MAX_KERNEL_IDS (1 << 22)
@@ -152,6 +153,8 @@ int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the
  * all its launches (2*K per lower-triangle element of every block column, unpadded sizes) and the
  * number of launches */
 int dsmgp_work(dsmgp_ctx* ctx, double* alg_flops_update, int32_t* n_update_launches);
+/* algorithmic flops of the two matrix passes of dsmgp_gradients (n^3/3 each per leaf) and the number of contraction tiles */
+int dsmgp_work_gradients(dsmgp_ctx* ctx, double* alg_flops_inverse, double* alg_flops_contraction, int32_t* n_contraction_tiles);
 /* Reserve one device pool of `bytes` (0 = drop it): while a pool exists, the large arenas of every following leaf
  * table (factors, inverse blocks, K_tn rows, L^-1 for gradients, split-K slabs) are carved out of it instead of being
  * allocated and freed per table -- the driver clears memory on allocation, ~5 s per 230 GB.  Used by the

@@ -975,3 +975,30 @@ def test_throughput_and_latency_forms_of_the_diagonal_block_kernel_agree(ctx):
         assert abs(big[0][j] - g.mll()) <= RTOL * abs(g.mll())
         mo, vo = g.prediction(Xt)
         assert np.allclose(big[1][j], mo, rtol=RTOL, atol=1e-9) and np.allclose(big[2][j], vo, rtol=RTOL, atol=1e-10)
+
+
+def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
+    """bench.py's N > 1 path, rehearsed on this one GPU: two ranks under torch.distributed.run with the
+    gloo backend (DSMGP_BENCH_BACKEND=gloo; the launcher starts before anything touches the GPU), each with its leaf
+    shard in its own HIP contexts.  The JSON line must carry n_gpus = 2, a finite value and the root log-marginal of
+    the one-rank run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "dsmgp_n20k_d8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    port = str(29000 + (os.getpid() * 7) % 2000)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         env=dict(env, DSMGP_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    line = [ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1]
+    j2 = json.loads(line)
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert np.isfinite(j2["value"]) and j2["value"] > 0 and j2["unit"] == "s" and j2["metric"] == j1["metric"]
+    assert abs(j2["root_mll"] - j1["root_mll"]) <= 1e-10 * abs(j1["root_mll"])
+    assert "roofline" in j1 and "standalone_predict_s" in j1 and j1["roofline"]["bound"] == "mfma"
