@@ -1834,37 +1834,45 @@ int build_grad_plan(dsmgp_ctx* c) {
     U.bind(c->slabG);
 
     // contraction tiles: every IsoSE leaf (COPY leaves too: their alpha is their own)
+    // Order.  A 128x128 tile task moves 2 x 128 x K operand doubles for 2 x 128^2 x K flops: 8 flop/B, below the
+    // ridge of the chip unless operands are shared through L2.  Tasks that are adjacent in this list run at the same
+    // time on one XCD (xcd_permute below), so the lower tiles of a leaf are listed in super-tiles of GS x GS tiles:
+    // the GS^2 tasks of a super-tile read GS row panels and GS column panels of L^-T between them (measured: tiles
+    // listed row by row 55 TFLOP/s; sorted by depth across leaves, i.e. no sharing at all, 26).
+    constexpr int GS = 4;
     std::vector<GradTask> gd;
     c->gdot_leaf.clear();
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
         if (c->hyper[lf.kid].kind != DSMGP_KIND_ISO_SE) continue;
         const LeafDev& d = c->h_leaves[l];
-        for (int j = 0; j < lf.nb; ++j)
-            for (int i = j; i < lf.nb; ++i) {
-                GradTask g{};
-                g.gemm.A = Xt(l) + (size_t)i * TB;
-                g.gemm.B = Xt(l) + (size_t)j * TB;
-                g.gemm.C = nullptr;
-                g.gemm.lda = g.gemm.ldb = lf.npad;
-                g.gemm.ldc = TB;
-                g.gemm.k0 = i * TB;
-                g.gemm.k1 = lf.npad;
-                g.gemm.update = 0;
-                g.xa = d.Xg + (size_t)i * TB;
-                g.xb = d.Xg + (size_t)j * TB;
-                g.alpha_a = d.alpha + (size_t)i * TB;
-                g.alpha_b = d.alpha + (size_t)j * TB;
-                g.ldx = lf.npad;
-                g.na = std::max(0, std::min(TB, lf.n - i * TB));
-                g.nb = std::max(0, std::min(TB, lf.n - j * TB));
-                g.diag = (i == j);
-                g.kid = lf.kid;
-                gd.push_back(g);
-                c->gdot_leaf.push_back(l);
-            }
+        for (int ib = 0; ib < lf.nb; ib += GS)
+            for (int jb = 0; jb <= ib; jb += GS)
+                for (int i = ib; i < std::min(ib + GS, lf.nb); ++i)
+                    for (int j = jb; j < std::min(jb + GS, i + 1); ++j) {
+                        GradTask g{};
+                        g.gemm.A = Xt(l) + (size_t)i * TB;
+                        g.gemm.B = Xt(l) + (size_t)j * TB;
+                        g.gemm.C = nullptr;
+                        g.gemm.lda = g.gemm.ldb = lf.npad;
+                        g.gemm.ldc = TB;
+                        g.gemm.k0 = i * TB;
+                        g.gemm.k1 = lf.npad;
+                        g.gemm.update = 0;
+                        g.xa = d.Xg + (size_t)i * TB;
+                        g.xb = d.Xg + (size_t)j * TB;
+                        g.alpha_a = d.alpha + (size_t)i * TB;
+                        g.alpha_b = d.alpha + (size_t)j * TB;
+                        g.ldx = lf.npad;
+                        g.na = std::max(0, std::min(TB, lf.n - i * TB));
+                        g.nb = std::max(0, std::min(TB, lf.n - j * TB));
+                        g.diag = (i == j);
+                        g.kid = lf.kid;
+                        gd.push_back(g);
+                        c->gdot_leaf.push_back(l);
+                    }
     }
-    // tiles that share a B operand (row tile j of L^-T) sit 8 apart so that they run on one XCD and share its L2
+    // neighbours in the list sit 8 apart in the launch: they run on one XCD and share its L2
     xcd_permute(gd, c->gdot_leaf, 0, gd.size(), c->xcd_order);
     if (int rc = dev_upload(c, c->gtrans, trans)) return rc;
     if (int rc = dev_upload(c, c->gfrob, frob)) return rc;

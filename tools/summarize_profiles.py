@@ -7,7 +7,7 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 base = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_round"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(newest(f"{base}/stats/runc/*_kernel_stats.csv"), f"profiles/{tag}_bench_n100k_kernel_stats.csv")
 shutil.copy(f"{base}/stats/bench.log", f"profiles/{tag}_bench_n100k_rocprof_run.log")
@@ -47,7 +47,7 @@ def update_launches(d, counter):
     rows = [r for r in rows_of(d) if r["Counter_Name"] == counter]
     mll = [i for i, r in enumerate(rows) if "mll_kernel" in r["Kernel_Name"]]
     seq = rows[(mll[-2] + 1 if len(mll) > 1 else 0):mll[-1]]
-    named = [r for r in seq if "tile_gemm_kernel_v2<false, 0, 0>" in r["Kernel_Name"]]   # the update instantiation
+    named = [r for r in seq if "tile_gemm_kernel_v2<false, 0>" in r["Kernel_Name"]]   # the update instantiation
     if named:
         return named
     upd, prev = [], None          # older builds: one instantiation for update and panel-solve launches
@@ -67,7 +67,7 @@ def update_launches(d, counter):
 fu, wu = update_launches("pmc2", "FETCH_SIZE"), update_launches("pmc3", "WRITE_SIZE")
 fetch = sum(float(r["Counter_Value"]) for r in fu) * 1024 * 2     # KB -> B; gfx950 counts 128-B requests of wide reads as 64 B
 write = sum(float(r["Counter_Value"]) for r in wu) * 1024
-res = {"kernel": "tile_gemm_kernel_v2<false, 0, 0>: update launches of the last fit (test rows riding along)", "launches": len(fu),
+res = {"kernel": "tile_gemm_kernel_v2<false, 0>: update launches of the last fit (test rows riding along)", "launches": len(fu),
        "fetch_bytes_total": fetch, "write_bytes_total": write, "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)),
        "note": "FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024 over the update launches of one fit; separate --pmc passes of "
                "`python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile` (tools/profile_round.sh)"}
