@@ -57,6 +57,11 @@ SIGNATURES = {
     "dsmgp_release": (C.c_int, [_ctx]),
     "dsmgp_reserve": (C.c_int, [_ctx, C.c_int64]),
     "dsmgp_overlap_main": (C.c_int, [C.c_int32, _lp, _lp, C.c_int64, _lp, _lp]),
+    "dsmgp_tree_build": (C.c_int, [_dp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                   C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "dsmgp_tree_sizes": (C.c_int, [C.c_void_p, _lp, _lp, _lp, _lp]),
+    "dsmgp_tree_export": (C.c_int, [C.c_void_p, _ip, _ip, _ip, _dp, _dp, _lp, _dp, _lp, _lp, _dp]),
+    "dsmgp_tree_free": (C.c_int, [C.c_void_p]),
     "dsmgp_estimate_bytes": (C.c_int64, [C.c_int32, _lp, _lp, C.c_int32, C.c_int32]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
@@ -581,6 +586,36 @@ def overlap_main(obs_ptr, obs_idx, N):
     if rc != 0:
         raise DsmgpError(rc, "dsmgp_overlap_main: bad leaf table")
     return main, cm
+
+
+def tree_build(X, min_data, n_splits, n_sum_children, depth, bnoise, sum_root, n_kernels, seed):
+    """Node table of the random partition tree (host routine of the library, no device; include/dsmgp_hip.h
+    dsmgp_tree_build): dict of arrays kind / parent / split_dim / lb / ub / thr_ptr / thr / obs_ptr / obs / dir_u."""
+    lib = load_library()
+    X, px = _f64_fortran(X)
+    N, D = X.shape
+    h = C.c_void_p()
+    rc = lib.dsmgp_tree_build(px, N, D, int(min_data), int(n_splits), int(n_sum_children), int(depth), float(bnoise),
+                              1 if sum_root else 0, int(n_kernels), C.c_uint64(int(seed)), C.byref(h))
+    if rc != 0:
+        raise DsmgpError(rc, "dsmgp_tree_build: bad arguments (non-finite inputs?)")
+    try:
+        n, nthr, nobs, ndir = (C.c_int64(0) for _ in range(4))
+        lib.dsmgp_tree_sizes(h, C.byref(n), C.byref(nthr), C.byref(nobs), C.byref(ndir))
+        n, nthr, nobs, ndir = n.value, nthr.value, nobs.value, ndir.value
+        out = dict(kind=np.empty(n, np.int32), parent=np.empty(n, np.int32), split_dim=np.empty(n, np.int32),
+                   lb=np.empty((n, D)), ub=np.empty((n, D)), thr_ptr=np.empty(n + 1, np.int64), thr=np.empty(max(nthr, 1)),
+                   obs_ptr=np.empty(n + 1, np.int64), obs=np.empty(max(nobs, 1), np.int64), dir_u=np.empty(max(ndir, 1)))
+        rc = lib.dsmgp_tree_export(h, out["kind"].ctypes.data_as(_ip), out["parent"].ctypes.data_as(_ip),
+                                   out["split_dim"].ctypes.data_as(_ip), out["lb"].ctypes.data_as(_dp), out["ub"].ctypes.data_as(_dp),
+                                   out["thr_ptr"].ctypes.data_as(_lp), out["thr"].ctypes.data_as(_dp),
+                                   out["obs_ptr"].ctypes.data_as(_lp), out["obs"].ctypes.data_as(_lp), out["dir_u"].ctypes.data_as(_dp))
+        if rc != 0:
+            raise DsmgpError(rc, "dsmgp_tree_export failed")
+        out["thr"], out["obs"], out["dir_u"] = out["thr"][:nthr], out["obs"][:nobs], out["dir_u"][:ndir]
+        return out
+    finally:
+        lib.dsmgp_tree_free(h)
 
 
 class StreamingContext:

@@ -183,6 +183,24 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* ctx, int32_t blocks_per_cu, double* o
 int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx, int64_t N, int64_t* main_out,
                        int64_t* c_main_out);
 
+/* Host-only (no device): the random partition tree of buildTree (src/treeStructure.jl:4-307: getSplits, _buildSplit,
+ * _buildSum and the regions _buildGP turns into leaves) as one native recursion, drawing from the portable counter stream
+ * `seed` (SplitMix64 in counter mode, deepstructuredmixtures_amd/datagen.py) in the order of the interpreted builder
+ * (tree.py), with which it agrees bit for bit.  n_splits = config.K (cuts per split node follow the depth^2 rule of
+ * :33,69,83), n_sum_children = config.V, depth = config.depth, bnoise = the eps of :49-54, n_kernels > 0: every region is
+ * a sum over n_kernels GPs and n_kernels uniforms are drawn for its Dirichlet(1) weights (:258-261).
+ * Result: nodes in creation (pre-)order: kind 0 region / 1 split / 2 sum, parent, split dimension, bounds lb/ub (D per
+ * node), split thresholds (CSR, last = upper bound), observation lists of the regions (CSR, ascending row indices),
+ * and the Dirichlet uniforms in region order. */
+typedef struct dsmgp_tree dsmgp_tree;
+int dsmgp_tree_build(const double* X /* N x D */, int64_t N, int32_t D, int32_t min_data, int32_t n_splits,
+                     int32_t n_sum_children, int32_t depth, double bnoise, int32_t sum_root, int32_t n_kernels, uint64_t seed,
+                     dsmgp_tree** out);
+int dsmgp_tree_sizes(const dsmgp_tree* t, int64_t* n_nodes, int64_t* n_thr, int64_t* n_obs, int64_t* n_dir);
+int dsmgp_tree_export(const dsmgp_tree* t, int32_t* kind, int32_t* parent, int32_t* split_dim, double* lb, double* ub,
+                      int64_t* thr_ptr, double* thr, int64_t* obs_ptr, int64_t* obs, double* dir_u);
+int dsmgp_tree_free(dsmgp_tree* t);
+
 #ifdef __cplusplus
 }
 #endif

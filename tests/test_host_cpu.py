@@ -424,3 +424,46 @@ def test_finetune_follows_the_reference_loop():
         kv = dsm.buildDSMGP(X, y, 2, 3, M=40, kernel=[dsm.IsoSE(0.0, 0.0), dsm.IsoLinear(0.0)], fit_now=False,
                             ctx=OracleContext(), seed=6)
         dsm.finetune(kv, iterations=1)
+
+
+def _same_tree(a, b):
+    if a.kind != b.kind:
+        return False
+    if a.kind == "gp":
+        return (np.array_equal(a.obs, b.obs) and a.kernelid == b.kernelid and a.mean.m == b.mean.m and a.leaf == b.leaf
+                and np.array_equal(a.lb, b.lb) and np.array_equal(a.ub, b.ub) and a.logNoise == b.logNoise)
+    if len(a.children) != len(b.children):
+        return False
+    if a.kind == "split":
+        if a.split != b.split or not np.array_equal(a.lowerBound, b.lowerBound) or not np.array_equal(a.upperBound, b.upperBound):
+            return False
+    elif not np.array_equal(a.logweights, b.logweights) or a.of_gps != b.of_gps:
+        return False
+    return all(_same_tree(x, y) for x, y in zip(a.children, b.children))
+
+
+def test_native_tree_builder_equals_the_interpreted_builder_bit_for_bit():
+    """buildTree (src/treeStructure.jl:4-307) as one native recursion in the library's host code
+    (dsmgp_tree_build) against the interpreted line-by-line builder: same draws from the counter stream in the same
+    order, same floating-point evaluation -> identical structure, split thresholds, bounds, observation lists, means and
+    Dirichlet weights, for sum-rooted trees, PoE-style split trees, kernel vectors, D up to 16 and depth up to 4; and the
+    threaded overlap/schedule routine equals the dense path."""
+    cases = [dict(N=3000, D=3, K=3, V=4, M=20, depth=3, kern=dsm.IsoSE(0, 0), sum=True, eps=0.5),
+             dict(N=2500, D=16, K=3, V=4, M=15, depth=2, kern=[dsm.IsoSE(0, 0), dsm.IsoLinear(0)], sum=True, eps=0.5),
+             dict(N=4000, D=2, K=1, V=8, M=50, depth=2, kern=dsm.IsoSE(0, 0), sum=False, eps=0.0),
+             dict(N=100, D=1, K=3, V=4, M=10, depth=2, kern=dsm.IsoSE(1, 1), sum=True, eps=0.5),
+             dict(N=6000, D=8, K=3, V=4, M=60, depth=4, kern=dsm.IsoSE(0, 0), sum=True, eps=0.5),
+             dict(N=5000, D=9, K=2, V=5, M=30, depth=3, kern=dsm.IsoSE(0, 0), sum=True, eps=0.3)]
+    for i, c in enumerate(cases):
+        X = uniform(5 + i, 0, c["N"] * c["D"]).reshape((c["N"], c["D"]), order="F")
+        y = np.sin(3 * X[:, 0]) + 0.1 * normal(50 + i, 0, c["N"])
+        cfg = lambda: ptree.DSMGPConfig(None, c["kern"], 1.0, c["M"], c["V"], c["K"], c["depth"], c["eps"], c["sum"])  # noqa: E731
+        a = ptree.build_tree(X, y, cfg(), seed=11 + i, native=True)
+        b = ptree.build_tree(X, y, cfg(), seed=11 + i, native=False)
+        assert len(ptree.get_leaves(a)) == len(ptree.get_leaves(b)) > 1
+        assert _same_tree(a, b), i
+    # the committed leaf table of config 1 pins both builders
+    z = np.load(os.path.join(ROOT, "tests", "golden", "config1.npz"))
+    m = dsm.buildDSMGP(z["x"].reshape(-1, 1), z["y"], 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5), seed=11,
+                       fit_now=False)
+    assert np.array_equal(np.concatenate([lf.obs for lf in m.leaves]), z["obs_idx"])

@@ -7,11 +7,11 @@ out=gpurun_out/prof_round
 rm -rf $out && mkdir -p $out/stats $out/pmc1 $out/pmc2 $out/pmc3 $out/stats_d4 $out/stats_train
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > $out/stats/bench.log 2>&1
 echo stats done
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc1 -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile > $out/pmc1/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc1 -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline > $out/pmc1/bench.log 2>&1
 echo pmc1 done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc2 -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile > $out/pmc2/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc2 -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline > $out/pmc2/bench.log 2>&1
 echo pmc2 done
-rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc3 -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile > $out/pmc3/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc3 -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline > $out/pmc3/bench.log 2>&1
 echo pmc3 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_d4 -- python3 bench.py --config dsmgp_n100k_d8_depth4 --steps 2 --warmup 2 --no-cpu-baseline > $out/stats_d4/bench.log 2>&1
 echo d4 done

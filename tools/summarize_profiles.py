@@ -42,26 +42,12 @@ out["derived"] = derived
 json.dump(out, open(f"profiles/{tag}_bench_n100k_pmc_summary.json", "w"), indent=1)
 
 
-def update_launches(d, counter):
-    """tile_gemm dispatches of the LAST fit that are update launches (not the panel solves that follow chol_diag)."""
-    rows = [r for r in rows_of(d) if r["Counter_Name"] == counter]
-    mll = [i for i, r in enumerate(rows) if "mll_kernel" in r["Kernel_Name"]]
-    seq = rows[(mll[-2] + 1 if len(mll) > 1 else 0):mll[-1]]
-    named = [r for r in seq if "tile_gemm_kernel_v2<false, 0>" in r["Kernel_Name"]]   # the update instantiation
-    if named:
-        return named
-    upd, prev = [], None          # older builds: one instantiation for update and panel-solve launches
-    for r in seq:
-        nme = r["Kernel_Name"]
-        if "tile_gemm" in nme:
-            if prev != "diag":
-                upd.append(r)
-            prev = "gemm"
-        elif "reduce" in nme:
-            pass
-        else:
-            prev = "diag" if "chol_diag" in nme else "other"
-    return upd
+def update_launches(d, counter, per_step=103):
+    """tile_gemm dispatches of the last TIMED-kind step: the update launches run as tile_gemm_kernel_v2<false, 0> while
+    per-launch timing is on (warm-up, timed steps, the breakdown step) and as <false, 2> in bench.py's untimed
+    standalone fit/predict extra, so the last `per_step` dispatches of that name are one whole joint fit."""
+    rows = [r for r in rows_of(d) if r["Counter_Name"] == counter and "tile_gemm_kernel_v2<false, 0>" in r["Kernel_Name"]]
+    return rows[-per_step:]
 
 
 fu, wu = update_launches("pmc2", "FETCH_SIZE"), update_launches("pmc3", "WRITE_SIZE")
