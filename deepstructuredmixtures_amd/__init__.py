@@ -6,7 +6,7 @@ numerics run in libdsmgp_hip.so (hand-written HIP for gfx950) behind the C ABI o
 from .kernels import IsoSE, ArdSE, IsoLinear, ConstMean, KernelFunction
 from .model import (DSMGP, PoE, gPoE, rBCM, GaussianProcess, build, buildDSMGP, buildPoE, buildBCM, fit,
                     fit_naive, predict, prediction, update_cholesky, update, infer, mll, mll_table,
-                    reset_weights, getparams, setparams, mse, sse, mae, sae, nlpd, scores, updategradients, grad_mll, train, ADAM,
+                    reset_weights, getparams, setparams, mse, sse, mae, sae, nlpd, scores, updategradients, grad_mll, train, ADAM, RMSProp,
                     resident_test, finetune)
 from .tree import get_leaves, get_overlap, share_schedule, route
 from .datagen import regression_data

@@ -12,6 +12,6 @@ if [ "${1:-}" = "diag" ]; then
     out="$here/../libdsmgp_hip_diag.so"
     extra=(-DDSMGP_DIAG)
 fi
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -pthread \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -pthread -ldl \
       -I"$here/../../include" "${extra[@]}" "$here/dsmgp_hip.cpp" -o "$out" "$@"
 echo "built $out"

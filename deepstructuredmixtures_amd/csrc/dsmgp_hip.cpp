@@ -16,6 +16,7 @@
 #include <thread>
 #include <array>
 #include <chrono>
+#include <dlfcn.h>
 #include <limits>
 #include <vector>
 
@@ -305,6 +306,11 @@ struct dsmgp_ctx {
     double* d_gpart = nullptr;      // partial results: frob | graddot pairs | per-leaf dots
     size_t gpart_count = 0;
 
+    // multi-GPU exchange over RCCL (dsmgp_comm_*, dsmgp_allgather): librccl.so is loaded on first use
+    void* comm = nullptr;           // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    double* d_xchg = nullptr;       // send | recv staging
+    size_t xchg_cap = 0;
     double timings[DSMGP_N_TIMINGS] = {0};
     std::vector<hipEvent_t> event_pool;   // PhaseTimer's events, reused across calls
     double alg_flops_update = 0.0;  // algorithmic flops of the Cholesky update launches
@@ -1086,6 +1092,7 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->d_obs_idx);
     dev_free(c->d_kp);
     dev_free(c->d_l2);
+    (void)dsmgp_comm_destroy(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2493,6 +2500,111 @@ int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx
         }
         for (auto& x : th) x.join();
     }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// The one exchange step of the path when leaves are sharded over the GPUs of a node: an all-gather of
+// per-leaf log-marginals after fit! and of the aggregation's partial sums after predict, over RCCL (xGMI inside a node)
+// on the context's stream.  librccl.so is opened with dlopen on first use: a single-GPU process never loads it, and
+// the library itself has no link-time dependency on it.
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    struct UniqueId { char internal[128]; };                         // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            err = std::string("cannot load librccl.so: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) {
+            err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+    std::string what(int rc) { return GetErrorString ? GetErrorString(rc) : ("nccl error " + std::to_string(rc)); }
+};
+RcclApi g_rccl;
+constexpr int NCCL_FLOAT64 = 8;   // ncclDataType_t ncclFloat64 (rccl.h)
+}  // namespace
+
+int dsmgp_comm_unique_id(char* id_out) {
+    if (!id_out) return DSMGP_E_ARG;
+    if (!g_rccl.load()) return fail(nullptr, DSMGP_E_STATE, g_rccl.err);
+    RcclApi::UniqueId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return fail(nullptr, DSMGP_E_HIP, "ncclGetUniqueId: " + g_rccl.what(rc));
+    std::memcpy(id_out, id.internal, sizeof(id.internal));
+    return 0;
+}
+
+int dsmgp_comm_init(dsmgp_ctx* c, int32_t rank, int32_t world, const char* id) {
+    if (!c) return DSMGP_E_ARG;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(c, DSMGP_E_ARG, "comm_init: bad arguments");
+    if (c->comm) return fail(c, DSMGP_E_STATE, "comm_init: communicator already initialised");
+    if (!g_rccl.load()) return fail(c, DSMGP_E_STATE, g_rccl.err);
+    HIPCHK(c, hipSetDevice(c->device));
+    RcclApi::UniqueId uid;
+    std::memcpy(uid.internal, id, sizeof(uid.internal));
+    const int rc = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+    if (rc != 0) {
+        c->comm = nullptr;
+        return fail(c, DSMGP_E_HIP, "ncclCommInitRank: " + g_rccl.what(rc));
+    }
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return 0;
+}
+
+int dsmgp_allgather(dsmgp_ctx* c, const double* send, int64_t count, double* recv) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->comm) return fail(c, DSMGP_E_STATE, "allgather before comm_init");
+    if (!send || !recv || count <= 0) return fail(c, DSMGP_E_ARG, "allgather: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)count, need = n * (size_t)(c->comm_world + 1);
+    if (need > c->xchg_cap) {
+        dev_free(c->d_xchg);
+        HIPCHK(c, hipMalloc(&c->d_xchg, need * sizeof(double)));
+        c->xchg_cap = need;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_xchg, send, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int rc = g_rccl.AllGather(c->d_xchg, c->d_xchg + n, n, NCCL_FLOAT64, c->comm, c->stream);
+    if (rc != 0) return fail(c, DSMGP_E_HIP, "ncclAllGather: " + g_rccl.what(rc));
+    HIPCHK(c, hipMemcpyAsync(recv, c->d_xchg + n, n * (size_t)c->comm_world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dsmgp_comm_destroy(dsmgp_ctx* c) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    dev_free(c->d_xchg);
+    c->xchg_cap = 0;
+    c->comm_world = 1;
+    c->comm_rank = 0;
     return 0;
 }
 

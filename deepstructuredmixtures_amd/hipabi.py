@@ -57,6 +57,10 @@ SIGNATURES = {
     "dsmgp_release": (C.c_int, [_ctx]),
     "dsmgp_reserve": (C.c_int, [_ctx, C.c_int64]),
     "dsmgp_overlap_main": (C.c_int, [C.c_int32, _lp, _lp, C.c_int64, _lp, _lp]),
+    "dsmgp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "dsmgp_comm_init": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_char_p]),
+    "dsmgp_allgather": (C.c_int, [_ctx, _dp, C.c_int64, _dp]),
+    "dsmgp_comm_destroy": (C.c_int, [_ctx]),
     "dsmgp_tree_build": (C.c_int, [_dp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                    C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "dsmgp_tree_sizes": (C.c_int, [C.c_void_p, _lp, _lp, _lp, _lp]),
@@ -286,6 +290,30 @@ class Context:
         out = np.zeros(5)
         self._chk(self.lib.dsmgp_scores(self.h, py, out.ctypes.data_as(_dp)))
         return dict(zip(SCORE_NAMES, out.tolist()))
+
+    # ---- exchange over RCCL (what a Julia host binds for the multi-GPU path; the Python mirror itself exchanges
+    #      through torch.distributed, backend "nccl" = the same RCCL) ----
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load_library().dsmgp_comm_unique_id(buf)
+        if rc != 0:
+            raise DsmgpError(rc, load_library().dsmgp_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        assert len(unique_id) == 128
+        self._chk(self.lib.dsmgp_comm_init(self.h, int(rank), int(world), unique_id))
+        self.world = int(world)
+
+    def allgather(self, local):
+        local, p = _f64(local)
+        out = np.empty((self.world, local.size))
+        self._chk(self.lib.dsmgp_allgather(self.h, p, local.size, out.ctypes.data_as(_dp)))
+        return out
+
+    def comm_destroy(self):
+        self._chk(self.lib.dsmgp_comm_destroy(self.h))
 
     def kernel_matrix(self, kernel_id, x1, x2):
         x1, p1 = _f64_fortran(x1)

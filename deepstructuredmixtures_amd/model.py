@@ -550,10 +550,69 @@ class ADAM:
         return self.m / (1 - b1 ** self.t) / (np.sqrt(self.v / (1 - b2 ** self.t)) + self.eps) * self.eta
 
 
-def train(model, optim=None, *, iterations=10_000, lam=0.05, randinit=True, earlystop=10, seed=0, tau=0.05, verbose=False):
-    """`train!(model, optim; iterations, λ, randinit, earlystop)` (`src/optimisers.jl:4-87`): gradient ASCENT
-    on the tree log marginal over one shared hyper-vector.  Returns (model, history of root mll)."""
+class RMSProp:
+    """Flux.Optimise.RMSProp stand-in (default optimiser of `train!(gp)`, `src/optimisers.jl:91`); stateful=False
+    restarts the running average every step, which is what the reference's rebinding `hyp += grad` amounts to
+    (SURVEY F9): the step is eta * g / (sqrt(1 - rho) |g| + eps)."""
+
+    def __init__(self, eta=1e-3, rho=0.9, eps=1e-8, stateful=False):
+        self.eta, self.rho, self.eps, self.stateful = eta, rho, eps, stateful
+        self.acc = None
+
+    def apply(self, x, g):
+        if not self.stateful or self.acc is None:
+            self.acc = np.zeros_like(g)
+        self.acc = self.rho * self.acc + (1 - self.rho) * g * g
+        return g * (self.eta / (np.sqrt(self.acc) + self.eps))
+
+
+def _train_gp(gp, optim, iterations, lam, randinit, seed, verbose):
+    """`train!(gp::GaussianProcess; iterations, optim, λ)` (`src/optimisers.jl:89-145`): ascent on one GP's log
+    marginal; a NaN log marginal (or a factorisation that fails: LAPACK info > 0, which the reference's potrf! call
+    ignores and which then shows up as NaN) rolls back to the previous hyper-vector and returns; early stop when the
+    last value is within λ of the mean of the nine before it (`:118`, a single hit suffices here)."""
     from .datagen import normal
+    target = gp.model
+    n = getparams(target).size
+    hyp = normal(seed, 0, n) if randinit else getparams(target).copy()
+    old = hyp.copy()
+    hist = []
+    for it in range(1, iterations + 1):
+        setparams(target, hyp)
+        try:
+            update_cholesky(gp)
+            ell = mll(gp)
+        except (np.linalg.LinAlgError, ValueError, hipabi.DsmgpError):   # failed potrf / non-finite hyper-parameters
+            ell = float("nan")
+        hist.append(ell)
+        if np.isnan(ell):                                                     # :115-119
+            setparams(target, old)
+            update_cholesky(gp)
+            return gp, np.array(hist)
+        delta = abs(ell - np.mean(hist[-10:-1])) if it > 10 else np.inf        # :121
+        if verbose:
+            print(f"iter {it}: mll {ell:.6f} delta {delta:.3g}")
+        if delta < lam:                                                       # :125-128
+            return gp, np.array(hist)
+        updategradients(gp)
+        g = grad_mll(gp)
+        old = hyp.copy()
+        hyp = hyp + optim.apply(hyp, g)                                       # :135-137 (ascent)
+    setparams(target, hyp)
+    update_cholesky(gp)
+    return gp, np.array(hist)
+
+
+def train(model, optim=None, *, iterations=10_000, lam=None, randinit=True, earlystop=10, seed=0, tau=0.05, verbose=False):
+    """`train!(model, optim; iterations, λ, randinit, earlystop)` (`src/optimisers.jl:4-87`): gradient ASCENT
+    on the tree log marginal over one shared hyper-vector.  Returns (model, history of root mll).
+    For a single `GaussianProcess` it is `train!(gp; iterations, optim, λ)` (`src/optimisers.jl:89-145`:
+    RMSProp, λ = 0.1, rollback on a NaN log marginal)."""
+    from .datagen import normal
+    if isinstance(model, GaussianProcess):
+        return _train_gp(model, RMSProp() if optim is None else optim, iterations, 0.1 if lam is None else lam, randinit, seed,
+                         verbose)
+    lam = 0.05 if lam is None else lam
     optim = ADAM() if optim is None else optim
     n = getparams(model).size
     hyp = normal(seed, 0, n) if randinit else getparams(model)

@@ -183,6 +183,18 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* ctx, int32_t blocks_per_cu, double* o
 int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx, int64_t N, int64_t* main_out,
                        int64_t* c_main_out);
 
+/* ---- multi-GPU: the one exchange step of the path.  Leaves are independent, every rank (one process
+ *      per GPU, one context each) fits and predicts its own shard; what crosses GPUs is one all-gather of per-leaf
+ *      log-marginals after dsmgp_fit and one of the aggregation's partial sums after dsmgp_aggregate_partial, over RCCL
+ *      (xGMI inside a node) on the context's stream.  librccl.so is dlopen'ed on first use.
+ *      dsmgp_comm_unique_id: rank 0 obtains the 128-byte ncclUniqueId and hands it to the other ranks by whatever
+ *      channel the host has (MPI.jl bcast, a file, the Distributed stdlib); every rank then calls dsmgp_comm_init.
+ *      dsmgp_allgather: `count` doubles from every rank, recv[r * count ...] = rank r's block (host buffers; blocking). */
+int dsmgp_comm_unique_id(char* id_out /* 128 bytes */);
+int dsmgp_comm_init(dsmgp_ctx* ctx, int32_t rank, int32_t world, const char* id /* 128 bytes */);
+int dsmgp_allgather(dsmgp_ctx* ctx, const double* send, int64_t count, double* recv /* world x count */);
+int dsmgp_comm_destroy(dsmgp_ctx* ctx);
+
 /* Host-only (no device): the random partition tree of buildTree (src/treeStructure.jl:4-307: getSplits, _buildSplit,
  * _buildSum and the regions _buildGP turns into leaves) as one native recursion, drawing from the portable counter stream
  * `seed` (SplitMix64 in counter mode, deepstructuredmixtures_amd/datagen.py) in the order of the interpreted builder

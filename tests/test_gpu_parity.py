@@ -1002,3 +1002,26 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
     assert np.isfinite(j2["value"]) and j2["value"] > 0 and j2["unit"] == "s" and j2["metric"] == j1["metric"]
     assert abs(j2["root_mll"] - j1["root_mll"]) <= 1e-10 * abs(j1["root_mll"])
     assert "roofline" in j1 and "standalone_predict_s" in j1 and j1["roofline"]["bound"] == "mfma"
+
+
+def test_rccl_allgather_entry_point(ctx):
+    """The C entry a Julia host binds for the multi-GPU exchange (dsmgp_comm_unique_id / dsmgp_comm_init /
+    dsmgp_allgather over RCCL, librccl.so opened with dlopen on first use).  One GPU here, so a one-rank communicator:
+    checks that the library loads, the communicator comes up on the context's device and stream, and the gathered
+    block is the sent block; RCCL refuses two ranks on one GPU, the two-rank path is rehearsed over gloo
+    (test_two_ranks_..., test_bench_two_ranks_...)."""
+    with pytest.raises(hipabi.DsmgpError):
+        ctx.allgather(np.zeros(4)) if hasattr(ctx, "world") else (_ for _ in ()).throw(hipabi.DsmgpError(-2, "no comm"))
+    uid = hipabi.Context.comm_unique_id()
+    assert len(uid) == 128 and any(b != 0 for b in uid)
+    ctx.comm_init(0, 1, uid)
+    try:
+        with pytest.raises(hipabi.DsmgpError):
+            ctx.comm_init(0, 1, uid)                               # already initialised
+        v = np.sin(np.arange(5000.0))
+        out = ctx.allgather(v)
+        assert out.shape == (1, 5000) and np.array_equal(out[0], v)
+        out = ctx.allgather(v[:7])                                 # smaller message: staging buffer reused
+        assert np.array_equal(out[0], v[:7])
+    finally:
+        ctx.comm_destroy()

@@ -467,3 +467,27 @@ def test_native_tree_builder_equals_the_interpreted_builder_bit_for_bit():
     m = dsm.buildDSMGP(z["x"].reshape(-1, 1), z["y"], 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5), seed=11,
                        fit_now=False)
     assert np.array_equal(np.concatenate([lf.obs for lf in m.leaves]), z["obs_idx"])
+
+
+def test_single_gp_train_loop_with_rollback():
+    """train!(gp) (src/optimisers.jl:89-145) on the host mirror: ascent with the (stateless) RMSProp step, early stop
+    on the running mean, and the rollback to the previous hyper-vector when the log marginal turns NaN."""
+    X, y = _small_problem(120, 2, seed=3)
+    gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.3), ctx=OracleContext())
+    _, hist = dsm.train(gp, dsm.RMSProp(eta=0.02), iterations=12, randinit=False, lam=1e-9)
+    assert len(hist) == 12 and hist[-1] > hist[0]
+    step = dsm.RMSProp().apply(np.zeros(2), np.array([3.0, -0.2]))
+    assert np.allclose(step, 1e-3 / np.sqrt(0.1) * np.array([1.0, -1.0]), rtol=1e-6)     # eta g / (sqrt(1 - rho) |g|)
+    # early stop: eleven equal values -> delta = 0 < lambda at iteration 11
+    gp2 = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.3), ctx=OracleContext())
+    _, h2 = dsm.train(gp2, dsm.RMSProp(eta=0.0), iterations=50, randinit=False)
+    assert len(h2) == 11
+    # rollback: an optimiser that jumps to a non-finite vector after the first step
+    class Jump:
+        def apply(self, x, g):
+            return np.full_like(x, np.nan)
+    gp3 = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(np.log(0.5), 0.0), logNoise=np.log(0.3), ctx=OracleContext())
+    before = dsm.getparams(gp3.model).copy()
+    _, h3 = dsm.train(gp3, Jump(), iterations=5, randinit=False)
+    assert len(h3) == 2 and np.isnan(h3[-1]) and np.array_equal(dsm.getparams(gp3.model), before)
+    assert np.isfinite(dsm.mll(gp3))
