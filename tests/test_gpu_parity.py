@@ -1010,8 +1010,9 @@ def test_rccl_allgather_entry_point(ctx):
     checks that the library loads, the communicator comes up on the context's device and stream, and the gathered
     block is the sent block; RCCL refuses two ranks on one GPU, the two-rank path is rehearsed over gloo
     (test_two_ranks_..., test_bench_two_ranks_...)."""
+    ctx.world = 1
     with pytest.raises(hipabi.DsmgpError):
-        ctx.allgather(np.zeros(4)) if hasattr(ctx, "world") else (_ for _ in ()).throw(hipabi.DsmgpError(-2, "no comm"))
+        ctx.allgather(np.zeros(4))                                 # before comm_init
     uid = hipabi.Context.comm_unique_id()
     assert len(uid) == 128 and any(b != 0 for b in uid)
     ctx.comm_init(0, 1, uid)
