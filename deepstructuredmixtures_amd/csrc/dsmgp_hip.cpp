@@ -2406,21 +2406,34 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     *seconds_per_launch = ms * 1e-3 / reps;
     if (std::getenv("DSMGP_STAMPS")) {
         unsigned long long* st = nullptr;
-        HIPCHK(c, hipMalloc(&st, (size_t)ntiles * 16 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(&st, (size_t)ntiles * 32 * sizeof(unsigned long long)));
         tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        std::vector<unsigned long long> hs((size_t)ntiles * 16);
+        std::vector<unsigned long long> hs((size_t)ntiles * 32);
         HIPCHK(c, hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         dev_free(st);
-        double tot = 0, mf = 0, bd = 0, nchs = 0;
+        double tot = 0, mf = 0, bd = 0, nchs = 0, pro = 0, loop = 0, epi = 0;
+        unsigned long long first = ~0ull, last = 0;
         for (size_t i = 0; i < (size_t)ntiles * 4; ++i) {
-            tot += (double)hs[4 * i];
-            mf += (double)hs[4 * i + 1];
-            bd += (double)hs[4 * i + 2];
-            nchs += (double)hs[4 * i + 3];
+            const unsigned long long* h = hs.data() + 8 * i;
+            tot += (double)h[0];
+            mf += (double)h[1];
+            bd += (double)h[2];
+            nchs += (double)h[3];
+            pro += (double)(h[4] - h[6]);
+            loop += (double)(h[5] - h[4]);
+            epi += (double)(h[7] - h[5]);
+            first = std::min(first, h[6]);
+            last = std::max(last, h[7]);
         }
-        std::fprintf(stderr, "  stamps: cycles/chunk total %.0f  mfma-span %.0f  boundary %.0f (per wave, mean)\n",
-                         tot / nchs, mf / nchs, bd / nchs);
+        const double nw = (double)ntiles * 4.0;
+        std::fprintf(stderr,
+                     "  stamps: cycles/chunk-pair total %.0f  mfma-span %.0f  boundary %.0f (per wave, mean); per wave us: "
+                     "prologue %.2f  loop %.2f  epilogue %.2f  -> loop clock %.3f GHz; launch span %.1f us, sum of wave "
+                     "times / (span x slots) = %.3f\n",
+                     tot / nchs, mf / nchs, bd / nchs, pro / nw * 0.01, loop / nw * 0.01, epi / nw * 0.01,
+                     tot / loop / 10.0, (double)(last - first) * 0.01,
+                     (pro + loop + epi) / ((double)(last - first) * std::min<double>(2.0 * c->ncu * 4.0, nw)));
     }
     dev_free(dt.p);
     dev_free(A);

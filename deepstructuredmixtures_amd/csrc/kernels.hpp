@@ -342,8 +342,11 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
 
     double fa0[4], fb0[4], fa1[4], fb1[4];
     if (nch > 0) FRAGS(fa0, fb0, 0, 0);
-    unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0;
-    if (STAMP) tin = stamp_now();
+    unsigned long long tin = 0, tmf = 0, tbd = 0, ta = 0, tb = 0, rin = 0;
+    if (STAMP) {
+        tin = stamp_now();
+        rin = __builtin_amdgcn_s_memrealtime();
+    }
 
     // one chunk: LOADSET receives chunk c+4, WRITESET (holding chunk c+3) goes to the ring
     // Issue order inside a chunk: every memory instruction sits in the shadow of an MFMA (64 cycles in the
@@ -398,11 +401,13 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
 
     if (STAMP && (t & 63) == 0) {
         const unsigned long long tout = stamp_now();
-        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + w) * 4;
+        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + w) * 8;
         s[0] = tout - tin;
         s[1] = tmf;
         s[2] = tbd;
         s[3] = nch / 2;
+        s[4] = rin;                                   // 100 MHz wall ticks: loop start / loop end
+        s[5] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -576,6 +581,8 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
                                                               unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
     __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
+    unsigned long long r0 = 0;
+    if (STAMP) r0 = __builtin_amdgcn_s_memrealtime();
     const TileTask tk = tasks[blockIdx.x];
     if (tk.sym) {       // diagonal tile of the factorisation: lower blocks only (workgroup-uniform branch)
         tile_syrk_body(tk, sA);
@@ -584,6 +591,11 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
     d4 acc[4][4];
     gemm_mainloop_v2<STAMP>(tk, acc, sA, sB, stamps);
     tile_epilogue(tk, acc, &sA[0][0]);
+    if (STAMP && (threadIdx.x & 63) == 0) {
+        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+        s[6] = r0;                                    // kernel entry / exit of this wave (100 MHz wall ticks)
+        s[7] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
