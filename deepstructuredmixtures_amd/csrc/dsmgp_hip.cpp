@@ -470,7 +470,7 @@ int upload_hyper(dsmgp_ctx* c) {
         const HyperHost& h = c->hyper[k];
         off[k] = l2pool.size();
         if (h.kind < 0) {   // id never set: no leaf may use it (check_hyper)
-            kp[k] = KParam{0, 0, 1.0, 1.0, 1.0, nullptr};
+            kp[k] = KParam{0, 0, 1.0, 1.0, 1.0, nullptr, nullptr, 0.0, 1.0};
             continue;
         }
         const int nl = (int)h.loghyp.size() - 2;
@@ -487,6 +487,8 @@ int upload_hyper(dsmgp_ctx* c) {
         kp[k].sigma = (h.kind == DSMGP_KIND_ISO_LINEAR) ? 1.0 : std::exp(logs);
         kp[k].noise = std::exp(2.0 * logn);
     }
+    const size_t nslots = l2pool.size();
+    for (size_t i = 0; i < nslots; ++i) l2pool.push_back(-0.5 / l2pool[i]);   // second half: the exponent's factor
     if (l2pool.size() > c->l2_cap || !c->d_l2) {   // (re)allocate only when the table grows: fit is called in loops
         dev_free(c->d_l2);
         c->l2_cap = std::max<size_t>(16, 2 * l2pool.size());
@@ -498,7 +500,14 @@ int upload_hyper(dsmgp_ctx* c) {
         HIPCHK(c, hipMalloc(&c->d_kp, c->kp_cap * sizeof(KParam)));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_l2, l2pool.data(), l2pool.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    for (int k = 0; k < nk; ++k) kp[k].l2 = c->d_l2 + off[k];
+    for (int k = 0; k < nk; ++k) {
+        kp[k].l2 = c->d_l2 + off[k];
+        kp[k].nh = c->d_l2 + nslots + off[k];
+        if (c->hyper[k].kind >= 0) {
+            kp[k].nh0 = l2pool[nslots + off[k]];
+            kp[k].il2 = 1.0 / l2pool[off[k]];
+        }
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_kp, kp.data(), nk * sizeof(KParam), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // l2pool / kp are stack storage
     return 0;

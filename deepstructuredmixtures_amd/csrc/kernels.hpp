@@ -40,7 +40,33 @@ struct KParam {
     double sigma;       // exp(logs)
     double noise;       // exp(2 logNoise)
     const double* l2;   // device: lengthscale^2 per slot
+    const double* nh;   // device: -0.5 / lengthscale^2 per slot (the factor of the exponent)
+    double nh0;         // nh[0]
+    double il2;         // 1 / l2[0]
 };
+
+// exp(x) for finite x <= 0: the argument reduction and degree-12 polynomial of the device library's exp
+// (n = rint(x log2 e), r = x - n ln2 in two pieces, Horner, ldexp) without its overflow / underflow selects --
+// the argument of a squared-exponential kernel is never positive, and ldexp underflows to 0 by itself.
+// Same bits as exp() on (-745, 0].
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(n, -0x1.62e42fefa39efp-1, x);
+    r = fma(n, -0x1.abc9e3b39803fp-56, r);
+    double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma(r, p, 0x1.71dee623fde64p-19);
+    p = fma(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma(r, p, 0x1.a01a014761f6ep-13);
+    p = fma(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma(r, p, 0x1.1111111122322p-7);
+    p = fma(r, p, 0x1.55555555502a1p-5);
+    p = fma(r, p, 0x1.5555555555511p-3);
+    p = fma(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)n);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Gram tiles.  out(r,c) = k(a_r, b_c); rows/cols beyond the valid counts are 0, and with `sym` the
@@ -60,7 +86,8 @@ struct GramTask {
 // One 256-thread workgroup per 128x64 half tile (blockIdx = 2*task + half): thread t owns rows
 // 4*(t&31)..+3 and columns 64*half + (t>>5) + 8q, q<8, so every column is written as 32 threads x 32 B =
 // 1 KiB contiguous, and the 32 accumulators keep the kernel at 4 waves per SIMD.
-// IsoSE follows src/kernels.jl:21-27,78-83 as exp(-0.5*(z/l^2)) then * sigma^2, with z accumulated
+// IsoSE follows src/kernels.jl:21-27,78-83 as exp(z * (-0.5/l^2)) then * sigma^2 (the reference divides by l^2 per entry;
+// one rounding of the exponent's argument apart: <= 4e-15 relative on the kernel value), with z accumulated
 // from direct differences (the reference's Distances.pairwise uses |a|^2+|b|^2-2a.b; same value up to
 // rounding).  ArdSE is the additive form sigma^2 * sum_d exp(-0.5 (a_d-b_d)^2 / l_d^2)
 // (src/kernels.jl:39-49).  IsoLinear is a.b / l^2 (src/kernels.jl:189-194).
@@ -91,7 +118,7 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
         __syncthreads();
         for (int d = 0; d < dn; ++d) {
             const double a0 = sa[d][r0], a1 = sa[d][r0 + 1], a2 = sa[d][r0 + 2], a3 = sa[d][r0 + 3];
-            const double l2d = (KIND == 1) ? p.l2[d0 + d] : 1.0;
+            const double nhd = (KIND == 1) ? p.nh[d0 + d] : 0.0;   // -0.5 / l_d^2
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const double b = sb[d][cb + 8 * q];
@@ -103,10 +130,10 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
                     u = a3 - b; acc[q][3] = fma(u, u, acc[q][3]);
                 } else if (KIND == 1) {
                     double u;
-                    u = a0 - b; acc[q][0] += exp(-0.5 * ((u * u) / l2d));
-                    u = a1 - b; acc[q][1] += exp(-0.5 * ((u * u) / l2d));
-                    u = a2 - b; acc[q][2] += exp(-0.5 * ((u * u) / l2d));
-                    u = a3 - b; acc[q][3] += exp(-0.5 * ((u * u) / l2d));
+                    u = a0 - b; acc[q][0] += exp_nonpos((u * u) * nhd);
+                    u = a1 - b; acc[q][1] += exp_nonpos((u * u) * nhd);
+                    u = a2 - b; acc[q][2] += exp_nonpos((u * u) * nhd);
+                    u = a3 - b; acc[q][3] += exp_nonpos((u * u) * nhd);
                 } else {
                     acc[q][0] = fma(a0, b, acc[q][0]);
                     acc[q][1] = fma(a1, b, acc[q][1]);
@@ -116,7 +143,7 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
             }
         }
     }
-    const double l2 = p.l2[0];
+    const double nh = p.nh0, il2 = p.il2;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = c0 + cb + 8 * q;
@@ -125,9 +152,9 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
         for (int j = 0; j < 4; ++j) {
             const int r = r0 + j;
             double kv;
-            if (KIND == 0) kv = p.sigma2 * exp(-0.5 * (acc[q][j] / l2));
+            if (KIND == 0) kv = p.sigma2 * exp_nonpos(acc[q][j] * nh);
             else if (KIND == 1) kv = p.sigma2 * acc[q][j];
-            else kv = acc[q][j] / l2;
+            else kv = acc[q][j] * il2;
             const bool valid = (r < tk.na) && (c < tk.nb);
             if (!valid) kv = 0.0;
             if (tk.sym && tk.diag && r == c) kv = valid ? kv + (p.noise + 1e-8) : 1.0;
@@ -760,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
-    const double l2 = p.l2[0];
+    const double nh = p.nh0;
     double s = 0.0, tr = 0.0;
     if (D <= GRADDOT_STAGE_D) {
         // smem: per dimension d 256 doubles (rows' coordinate | columns' coordinate), then alpha_a | alpha_b
@@ -794,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __
             for (int i = 0; i < 16; ++i) {
                 const int c = wc * 64 + 16 * (i >> 2) + l4 + 4 * (i & 3);
                 if (rv && c < g.nb) {
-                    const double kv = p.sigma2 * exp(-0.5 * (z[i] / l2));
+                    const double kv = p.sigma2 * exp_nonpos(z[i] * nh);
                     const double pre = ar * al[TB + c] - acc[i >> 2][rn][i & 3];
                     s = fma(pre * kv, z[i], s);
                     if (g.diag && r == c) tr += acc[i >> 2][rn][i & 3];
@@ -818,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __
                             const double u = g.xa[r + (size_t)d * g.ldx] - g.xb[c + (size_t)d * g.ldx];
                             z = fma(u, u, z);
                         }
-                        const double kv = p.sigma2 * exp(-0.5 * (z / l2));
+                        const double kv = p.sigma2 * exp_nonpos(z * nh);
                         const double pre = ar * g.alpha_b[c] - acc[cm][rn][q];
                         s = fma(pre * kv, z, s);
                         if (g.diag && r == c) tr += acc[cm][rn][q];
