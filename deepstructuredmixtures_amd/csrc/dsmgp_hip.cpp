@@ -303,6 +303,9 @@ struct dsmgp_ctx {
     std::vector<int> gfrob_leaf;    // owner leaf of each frob task
     DevBuf<GradTask> gdot;
     std::vector<int> gdot_leaf;     // leaf of each graddot task
+    bool ard_true_gradient = false; // DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT
+    int gstride = 2;                // doubles per contraction task in d_gpart
+    std::vector<int> grad_src;      // per leaf: the leaf whose contraction it shares (COPY leaf with the same mean), or -1
     double* d_gpart = nullptr;      // partial results: frob | graddot pairs | per-leaf dots
     size_t gpart_count = 0;
 
@@ -1124,6 +1127,19 @@ int dsmgp_set_joint(dsmgp_ctx* c, int32_t on) {
     return 0;
 }
 
+int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
+    if (!c) return DSMGP_E_ARG;
+    if (option == DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT) {
+        if ((value != 0) != c->ard_true_gradient) {
+            HIPCHK(c, hipSetDevice(c->device));
+            free_grad(c);     // the contraction tile list depends on it
+        }
+        c->ard_true_gradient = value != 0;
+        return 0;
+    }
+    return fail(c, DSMGP_E_ARG, "set_option: unknown option");
+}
+
 int dsmgp_set_profile(dsmgp_ctx* c, int32_t on) {
     if (!c) return DSMGP_E_ARG;
     c->profile = on < 0 ? 0 : (on > 2 ? 2 : on);
@@ -1863,9 +1879,21 @@ int build_grad_plan(dsmgp_ctx* c) {
     constexpr int GS = 4;
     std::vector<GradTask> gd;
     c->gdot_leaf.clear();
+    c->grad_src.assign(L, -1);
+    bool any_ard = false;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
-        if (c->hyper[lf.kid].kind != DSMGP_KIND_ISO_SE) continue;
+        const int kind_l = c->hyper[lf.kid].kind;
+        const bool ard = kind_l == DSMGP_KIND_ARD_SE && c->ard_true_gradient;
+        if (kind_l != DSMGP_KIND_ISO_SE && !ard) continue;
+        any_ard = any_ard || ard;
+        // Shared gradients (the idea of src/fit.jl:313-395: a leaf whose observation set equals its main leaf's takes
+        // that leaf's gradients, `copygradients`): a COPY leaf has its source's factor and kernel id; with the same
+        // ConstMean its alpha is the source's too, so its contraction is the source's and is not computed again.
+        if (lf.op == DSMGP_SHARE_COPY && lf.mean == c->leaves[lf.src].mean) {
+            c->grad_src[l] = lf.src;
+            continue;
+        }
         const LeafDev& d = c->h_leaves[l];
         for (int ib = 0; ib < lf.nb; ib += GS)
             for (int jb = 0; jb <= ib; jb += GS)
@@ -1901,7 +1929,10 @@ int build_grad_plan(dsmgp_ctx* c) {
     if (int rc = dev_upload(c, c->gred, U.red)) return rc;
     if (int rc = dev_upload(c, c->gtrsm, trsm)) return rc;
     if (int rc = dev_upload(c, c->gdot, gd)) return rc;
-    c->gpart_count = frob.size() + 2 * gd.size() + 2 * (size_t)L;
+    if (any_ard && c->D > GRADDOT_STAGE_D)
+        return fail(c, DSMGP_E_ARG, "ArdSE length-scale gradients need D <= " + std::to_string(GRADDOT_STAGE_D));
+    c->gstride = any_ard ? 2 + c->D : 2;
+    c->gpart_count = frob.size() + (size_t)c->gstride * gd.size() + 2 * (size_t)L;
     HIPCHK(c, hipMalloc(&c->d_gpart, std::max<size_t>(1, c->gpart_count) * sizeof(double)));
     c->grad_ready = true;
     return 0;
@@ -1947,8 +1978,9 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     HIPCHK(c, hipEventRecord(e_inv.a, c->stream));
     double* pfrob = c->d_gpart;
     double* pdot = pfrob + c->gfrob.count;
-    double* pleaf = pdot + 2 * c->gdot.count;
-    if (c->gdot.count) tile_graddot_kernel<<<(int)c->gdot.count, 256, 0, c->stream>>>(c->gdot.p, c->d_kp, c->D, pdot);
+    double* pleaf = pdot + (size_t)c->gstride * c->gdot.count;
+    if (c->gdot.count)
+        tile_graddot_kernel<<<(int)c->gdot.count, 256, 0, c->stream>>>(c->gdot.p, c->d_kp, c->D, pdot, c->gstride);
     HIPCHK(c, hipEventRecord(e_dot.a, c->stream));
     if (c->gfrob.count) frob_kernel<<<(int)c->gfrob.count, 256, 0, c->stream>>>(c->gfrob.p, pfrob);
     dots_kernel<<<L, 256, 0, c->stream>>>(c->d_leaves, pleaf);
@@ -1972,8 +2004,24 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     for (int l = 0; l < L; ++l)
         if (c->leaves[l].owner != l) trK[l] = trK[c->leaves[l].owner];
     const double* pd = part.data() + c->gfrob.count;
-    for (size_t i = 0; i < c->gdot.count; ++i) S1[c->gdot_leaf[i]] += pd[2 * i];
-    const double* pl = pd + 2 * c->gdot.count;
+    const size_t gs = (size_t)c->gstride;
+    std::vector<double> Sd;           // per leaf and dimension: contraction with dK / dlog l_d (ArdSE option)
+    if (gs > 2) Sd.assign((size_t)L * c->D, 0.0);
+    for (size_t i = 0; i < c->gdot.count; ++i) {
+        const int l = c->gdot_leaf[i];
+        if (c->hyper[c->leaves[l].kid].kind == DSMGP_KIND_ARD_SE) {
+            for (int d = 0; d < c->D; ++d) Sd[(size_t)l * c->D + d] += pd[gs * i + 2 + d];
+        } else {
+            S1[l] += pd[gs * i];
+        }
+    }
+    for (int l = 0; l < L; ++l)
+        if (c->grad_src[l] >= 0) {   // copygradients (src/fit.jl:352-356)
+            S1[l] = S1[c->grad_src[l]];
+            if (gs > 2)
+                for (int d = 0; d < c->D; ++d) Sd[(size_t)l * c->D + d] = Sd[(size_t)c->grad_src[l] * c->D + d];
+        }
+    const double* pl = pd + gs * c->gdot.count;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
         const HyperHost& h = c->hyper[lf.kid];
@@ -1993,7 +2041,8 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
             g[1] = sigma * trPK;                              // src/kernels.jl:90-93
         } else if (h.kind == DSMGP_KIND_ARD_SE) {
             const double sigma = std::exp(h.loghyp[nl]);
-            for (int d = 0; d < nl; ++d) g[d] = 0.0;          // src/kernels.jl:161 (identically zero)
+            for (int d = 0; d < nl; ++d)                      // src/kernels.jl:161: identically zero unless the
+                g[d] = (c->ard_true_gradient && gs > 2) ? 0.5 * Sd[(size_t)l * c->D + d] : 0.0;   // true gradient is asked for
             g[nl] = sigma * trPK;                             // src/kernels.jl:157
         } else {
             g[0] = -trPK;                                     // src/kernels.jl:198

@@ -773,9 +773,12 @@ struct GradTask {
 // and 128 columns and the two alpha blocks are staged once through the LDS the main loop no longer needs (D <= 35;
 // wider inputs read them from global memory, element by element).
 constexpr int GRADDOT_STAGE_D = 35;
+// ostride = doubles per task in `out`: 2, or 2 + D when the per-dimension sums of the additive ArdSE kernel are
+// asked for (dsmgp_set_option DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT): out[2 + d] = sum_rc (alpha_r alpha_c - G_rc) *
+// sigma^2 exp(-u_d^2 / 2 l_d^2) * u_d^2 / l_d^2, u_d = x_rd - x_cd -- the contraction with dK / dlog l_d.
 __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __restrict__ tasks,
                                                               const KParam* __restrict__ kp, int D,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out, int ostride) {
     __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP];
     __shared__ double red[2][4];
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
@@ -789,7 +792,54 @@ __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __
     const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
     const double nh = p.nh0;
     double s = 0.0, tr = 0.0;
-    if (D <= GRADDOT_STAGE_D) {
+    if (p.kind == 1) {
+        // additive ArdSE (needs D <= GRADDOT_STAGE_D, checked by the host): one dimension at a time
+        double* xs = smem;
+        double* al = smem + (size_t)D * 256;
+        for (int e = t; e < D * 256; e += 256) {
+            const int d = e >> 8, rc = e & 255;
+            xs[e] = (rc < TB) ? ((rc < g.na) ? g.xa[rc + (size_t)d * g.ldx] : 0.0)
+                              : ((rc - TB < g.nb) ? g.xb[rc - TB + (size_t)d * g.ldx] : 0.0);
+        }
+        al[t] = (t < TB) ? ((t < g.na) ? g.alpha_a[t] : 0.0) : ((t - TB < g.nb) ? g.alpha_b[t - TB] : 0.0);
+        __syncthreads();
+        const double wgt = g.diag ? 1.0 : 2.0;
+        for (int d = 0; d < D; ++d) {
+            const double nhd = p.nh[d];
+            double sd = 0.0;
+#pragma unroll
+            for (int rn = 0; rn < 4; ++rn) {
+                const int r = wr * 64 + 16 * rn + l15;
+                const bool rv = r < g.na;
+                const double ar = al[r], a = xs[d * 256 + r];
+                const double* xb = xs + d * 256 + TB + wc * 64 + l4;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = wc * 64 + 16 * (i >> 2) + l4 + 4 * (i & 3);
+                    const double u = a - xb[16 * (i >> 2) + 4 * (i & 3)];
+                    const double q = u * u;
+                    const double pre = ar * al[TB + c] - acc[i >> 2][rn][i & 3];
+                    if (rv && c < g.nb) sd = fma(pre * exp_nonpos(q * nhd), q, sd);
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) sd += __shfl_down(sd, o);
+            __syncthreads();
+            if (lane == 0) red[0][w] = sd;
+            __syncthreads();
+            if (t == 0)   // u^2 / l_d^2 = -2 nh_d u^2
+                out[(size_t)ostride * blockIdx.x + 2 + d] = wgt * p.sigma2 * (-2.0 * nhd) * (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        }
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn) {
+            const int r = wr * 64 + 16 * rn + l15;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = wc * 64 + 16 * (i >> 2) + l4 + 4 * (i & 3);
+                if (g.diag && r == c && r < g.na) tr += acc[i >> 2][rn][i & 3];
+            }
+        }
+        __syncthreads();
+    } else if (D <= GRADDOT_STAGE_D) {
         // smem: per dimension d 256 doubles (rows' coordinate | columns' coordinate), then alpha_a | alpha_b
         double* xs = smem;
         double* al = smem + (size_t)D * 256;
@@ -864,8 +914,8 @@ __global__ __launch_bounds__(256, 2) void tile_graddot_kernel(const GradTask* __
     __syncthreads();
     if (threadIdx.x == 0) {
         const double wgt = g.diag ? 1.0 : 2.0;
-        out[2 * blockIdx.x] = wgt * (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        out[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        out[(size_t)ostride * blockIdx.x] = wgt * (red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        out[(size_t)ostride * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 
 N_TIMINGS = 18
 AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
+OPT_ARD_LENGTHSCALE_GRADIENT = 1
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
 
@@ -43,6 +44,7 @@ SIGNATURES = {
     "dsmgp_predict_fetch": (C.c_int, [_ctx, _dp, _dp]),
     "dsmgp_predict_leaves": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp, _dp, _dp]),
     "dsmgp_gradients": (C.c_int, [_ctx, _dp, C.c_int32]),
+    "dsmgp_set_option": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "dsmgp_aggregate": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "dsmgp_aggregate_partial": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, _dp]),
     "dsmgp_aggregate_finish": (C.c_int, [_ctx, _dp, C.c_int32, C.c_int32, _dp, _dp]),
@@ -238,6 +240,10 @@ class Context:
         self.set_test(Xt, route_ptr, route_idx)
         self.predict_run()
         return self.predict_fetch()
+
+    def set_option(self, option, value):
+        """include/dsmgp_hip.h DSMGP_OPT_*; OPT_ARD_LENGTHSCALE_GRADIENT = 1."""
+        self._chk(self.lib.dsmgp_set_option(self.h, int(option), int(value)))
 
     def gradients(self, stride):
         g = np.zeros((self.L, stride))

@@ -136,6 +136,13 @@ int dsmgp_scores(dsmgp_ctx* ctx, const double* y_test /* n_t */, double* out /* 
  *      grad_out[l*stride + j], j over [dl..., ds, dnoise] (reference order, src/gaussianprocess.jl:212-214),
  *      reproducing the reference's scaling and ArdSE dl == 0. */
 int dsmgp_gradients(dsmgp_ctx* ctx, double* grad_out, int32_t stride);
+/* Options.  DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT: 0 (default) = ArdSE length-scale gradients exactly as the reference
+ * computes them, i.e. identically zero (`precomp * K .* (p/ls[d])` parses as `(precomp*K) .* (p/ls[d])` and p has a zero
+ * diagonal, src/kernels.jl:161: train!/finetune! never move ARD length-scales); 1 = the true derivative of the
+ * log-marginal, dl_d = 0.5 tr((alpha alpha^T - K_y^-1) dK/dlog l_d) with dK/dlog l_d = sigma^2 exp(-u_d^2/2l_d^2) u_d^2/l_d^2
+ * of the additive kernel (no extra factor sigma; costs the contraction pass, n^3/3 flops per leaf; D <= 35). */
+#define DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT 1
+int dsmgp_set_option(dsmgp_ctx* ctx, int32_t option, int32_t value);
 
 /* ---- inspection ------------------------------------------------------------------------------- */
 /* kernelmatrix(kernel, x1, x2) (src/kernels.jl:15-18) through the same device code as the fit path */

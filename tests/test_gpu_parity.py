@@ -1026,3 +1026,72 @@ def test_rccl_allgather_entry_point(ctx):
         assert np.array_equal(out[0], v[:7])
     finally:
         ctx.comm_destroy()
+
+
+def test_copy_leaves_share_their_gradient_contraction():
+    """SURVEY 8(f).4, the shared-gradient idea of src/fit.jl:313-395: a leaf whose observation set equals its main
+    leaf's takes that leaf's gradients (`copygradients`, :352-356).  Here a COPY leaf (same factor, same kernel id, same
+    ConstMean) skips its contraction tiles and reads its source's sum.  BASELINE config 1 has many such leaves: the
+    gradients with sharing equal those of the naive schedule (every leaf on its own) and the oracle's."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "config1.npz"))
+    X, y = z["x"].reshape(-1, 1), z["y"]
+    kw = dict(M=10, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.2), seed=11)
+    m = dsm.buildDSMGP(X, y, 3, 4, **kw)
+    assert np.count_nonzero(m.share_op == ptree.SHARE_COPY) > 3
+    g_shared = dsm.updategradients(m).copy()
+    grad_shared = dsm.grad_mll(m)
+    dsm.fit_naive(m)
+    g_naive = dsm.updategradients(m).copy()
+    assert np.allclose(g_shared, g_naive, rtol=1e-9, atol=1e-11)
+    assert np.allclose(grad_shared, dsm.grad_mll(m), rtol=1e-9, atol=1e-11)
+    gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+    ospn.fit_naive(m.root, gps)
+    go = np.array([g.grad() for g in gps])
+    assert np.allclose(g_shared, go, rtol=1e-7, atol=1e-8)
+    # a COPY leaf with a mean of its own must NOT share (its alpha differs): two leaves over the same rows, means 0 and 1
+    c = hipabi.Context(0)
+    Xs, ys, _ = regression_data(300, 2, n_test=4, seed=5)
+    c.set_train(Xs, ys)
+    c.set_leaves([0, 300, 600], np.tile(np.arange(300), 2), [0, 0], [0.0, 1.0])
+    c.set_hyper(0, 0, [np.log(0.4), 0.0, np.log(0.2)])
+    c.set_sharing([0, 1], [-1, 0], [0, 0])
+    c.fit()
+    g2 = c.gradients(3)
+    c.set_sharing(None, None, None)
+    c.fit()
+    g2n = c.gradients(3)
+    c.close()
+    assert np.allclose(g2, g2n, rtol=1e-9, atol=1e-11) and abs(g2[0, 0] - g2[1, 0]) > 1e-6
+
+
+def test_ardse_true_lengthscale_gradient_option(ctx):
+    """the reference's ArdSE length-scale gradients are identically zero (a parse accident) and
+    that is the default here too.  dsmgp_set_option(DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT, 1) switches to the true
+    derivative of the log-marginal w.r.t. log l_d of the additive kernel: checked against central finite differences of
+    the device's own log-marginal; ds and dnoise do not change with the option."""
+    n, D = 420, 3
+    X = uniform(95, 0, n * D).reshape((n, D), order="F")
+    y = np.sin(4 * X[:, 0]) + np.cos(3 * X[:, 1]) + 0.1 * normal(96, 0, n)
+    h = np.array(list(np.log([0.4, 0.6, 0.9])) + [0.1])
+    ln = np.log(0.25)
+    mean = float(np.mean(y))
+    _single(ctx, X, y, mean, 1, h, ln)
+    g0 = ctx.gradients(D + 2)[0]
+    assert np.all(g0[:D] == 0.0)
+    ctx.set_option(hipabi.OPT_ARD_LENGTHSCALE_GRADIENT, 1)
+    try:
+        g1 = ctx.gradients(D + 2)[0]
+        assert g1[D] == g0[D] and g1[D + 1] == g0[D + 1]
+        eps = 1e-5
+        for d in range(D):
+            hp, hm = h.copy(), h.copy()
+            hp[d] += eps
+            hm[d] -= eps
+            fp = _single(ctx, X, y, mean, 1, hp, ln)[0][0]
+            fm = _single(ctx, X, y, mean, 1, hm, ln)[0][0]
+            fd = (fp - fm) / (2 * eps)
+            assert abs(g1[d] - fd) <= 2e-6 * max(1.0, abs(fd)), (d, g1[d], fd)
+    finally:
+        ctx.set_option(hipabi.OPT_ARD_LENGTHSCALE_GRADIENT, 0)
+    _single(ctx, X, y, mean, 1, h, ln)
+    assert np.all(ctx.gradients(D + 2)[0][:D] == 0.0)
