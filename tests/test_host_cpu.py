@@ -491,3 +491,23 @@ def test_single_gp_train_loop_with_rollback():
     _, h3 = dsm.train(gp3, Jump(), iterations=5, randinit=False)
     assert len(h3) == 2 and np.isnan(h3[-1]) and np.array_equal(dsm.getparams(gp3.model), before)
     assert np.isfinite(dsm.mll(gp3))
+
+
+def test_host_only_entry_points_reject_bad_arguments():
+    """dsmgp_tree_build / dsmgp_overlap_main / dsmgp_estimate_bytes are host routines of the library: argument errors come
+    back as error codes (no device needed), never as crashes."""
+    lib = hipabi.load_library()
+    X = np.asfortranarray(np.random.default_rng(0).random((50, 2)))
+    with pytest.raises(hipabi.DsmgpError):
+        hipabi.tree_build(np.full((10, 2), np.nan), 5, 4, 3, 2, 0.5, True, 0, 1)
+    tab = hipabi.tree_build(X, 5, 4, 3, 1, 0.5, True, 2, 7)
+    assert tab["kind"][0] == 2 and tab["dir_u"].size == 2 * int(np.sum(tab["kind"] == 0))
+    assert np.all(np.diff(tab["obs_ptr"]) >= 0) and tab["obs_ptr"][-1] == tab["obs"].size
+    for i in np.flatnonzero(tab["kind"] == 0):
+        o = tab["obs"][tab["obs_ptr"][i]:tab["obs_ptr"][i + 1]]
+        assert np.all(np.diff(o) > 0)                                  # ascending row indices
+    h = ctypes.c_void_p()
+    assert lib.dsmgp_tree_build(None, 10, 2, 5, 4, 3, 2, 0.5, 1, 0, 1, ctypes.byref(h)) == -1
+    with pytest.raises(hipabi.DsmgpError):
+        hipabi.overlap_main(np.array([0, 2]), np.array([0, 99]), 10)   # observation index out of range
+    assert hipabi.estimate_bytes([128], [0], 3) == (128 * 128 + 128 * 128 + 128 * 7) * 8

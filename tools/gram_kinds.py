@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepstructuredmixtures_amd as dsm
 X, y, Xt = dsm.regression_data(100000, 8, seed=20204)
 for name, kern in (("IsoSE", dsm.IsoSE(np.log(0.3), 0.0)), ("IsoLinear", dsm.IsoLinear(np.log(1.5))), ("ArdSE", dsm.ArdSE(np.log(np.full(8, 0.3)), 0.0))):

@@ -1,5 +1,5 @@
 import os, sys, time, cProfile, pstats
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import deepstructuredmixtures_amd as dsm
 model, X, y, Xt, ptr, idx = bench.build_model("dsmgp_n100k_d8", 0, 1, 0)

@@ -19,7 +19,8 @@ for r in rows:
         last = r[1]
     cur.append(r)
 fits.append(cur)
-fit = [f for f in fits if any(r[0] == 2 for r in f)][-1]
+# the fit with the most update launches among the fully logged ones (a PREFIX phase logs a short second sequence)
+fit = max([f for f in fits if any(r[0] == 2 for r in f)], key=lambda f: sum(1 for r in f if r[0] == 1))
 tot = collections.defaultdict(float)
 print("step  tiles  tasks  rounds   ms     TF/s(exec)")
 fl_all = t_all = 0.0

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deepstructuredmixtures_amd as dsm
 X, y, Xt = dsm.regression_data(4096, 4, seed=20202)
 gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1))
