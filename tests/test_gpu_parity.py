@@ -1095,3 +1095,20 @@ def test_ardse_true_lengthscale_gradient_option(ctx):
         ctx.set_option(hipabi.OPT_ARD_LENGTHSCALE_GRADIENT, 0)
     _single(ctx, X, y, mean, 1, h, ln)
     assert np.all(ctx.gradients(D + 2)[0][:D] == 0.0)
+
+
+def test_bench_train_mode_line():
+    """`bench.py --mode train` on the small config: one JSON line with the device split of a train! iteration and the
+    rooflines of the two gradient passes; the log-marginal rises under the ascent steps."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "train", "--config", "dsmgp_n20k_d8", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["metric"].startswith("train! iteration") and j["unit"] == "s" and j["value"] > 0 and j["higher_is_better"] is False
+    dev = j["device_seconds_per_iteration"]
+    assert dev["grad_inverse"] > 0 and dev["grad_contraction"] > 0 and dev["total_fit"] > 0
+    assert 0 < j["roofline"]["frac"] < 1 and 0 < j["roofline_inverse"]["frac"] < 1
+    assert len(j["mll_history"]) == 3 and j["mll_history"][-1] > j["mll_history"][0]
