@@ -3,13 +3,17 @@
 // Everything here works on 128x128 Float64 tiles of column-major matrices whose dimensions are
 // padded to multiples of 128 (padding = identity block, see gram_tile_kernel).  One leaf GP's
 // factor F (npad x npad) is produced by a LEFT-LOOKING blocked Cholesky, batched over all leaves:
-//   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel_v2, update tasks, v_mfma_f64_16x16x4_f64)
-//            F[k,k]  = chol(F[k,k]), Dinv_k = F[k,k]^-1   (chol_diag_kernel)
-//            F[i,k]  = F[i,k] Dinv_k^T       (tile_gemm_kernel_v2, solve tasks; fused forward solve)
+//   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel_v2, v_mfma_f64_16x16x4_f64; diagonal tiles optionally by
+//                                              tile_syrk_body; K-split pieces summed by tile_reduce_kernel)
+//            F[k,k]  = chol(F[k,k]), Dinv_k = F[k,k]^-1   (chol_diag_kernel: one block per CU, latency form;
+//                                              chol_diag_packed_kernel: two per CU, throughput form)
+//            F[i,k]  = F[i,k] Dinv_k^T       (tile_trsm_kernel: triangular product; fused forward solve and, for test
+//                                              rows, the predictive moments)
 // which is update_cholesky!/potrf! of the reference (src/gaussianprocess.jl:82-108) and, started at
 // a later column with the leading block copied, chol_continue! (src/AdvancedCholeskey.jl:152-174).
 // prediction() (src/gaussianprocess.jl:110-137) appends the test rows below the factor: V^T = K_tn L^-T
-// is the same two tile kernels run on the rows of K_tn.
+// is the same two tile kernels run on the rows of K_tn.  Aggregation over the leaves of a test row and the score
+// functions (src/common.jl:134-302, src/scorefunctions.jl) are the agg_* kernels at the end of this file.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
