@@ -361,7 +361,8 @@ def main():
             traffic_source = f"profiles/{TRAFFIC_FILE} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "tile_gemm_kernel_v2<false, 0> (update launches of the factorisation, test rows riding along; "
+                "kernel": "tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along; <false, 0, true> "
+                          "in launches with >= 10 % padding-row tiles; "
                           "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel; the reduce "
                           "launches are timed apart: device_seconds_per_step.chol_reduce)",
                 "avg_launch_ms": avg_launch * 1e3, "launches_per_step": upd_launches // args.steps,
@@ -374,7 +375,7 @@ def main():
     standalone = None
     if world == 1 and not args.simulate_shard and not CONFIGS[args.config].get("stream"):
         ctx.set_profile(0)      # also renames the update kernel's instantiation: these launches stay out of the profiler's
-                                # average of tile_gemm_kernel_v2<false, 0> (the kernel of the roofline block)
+                                # average of tile_gemm_kernel_v2<false, 0, *> (the kernel of the roofline block)
         ctx.set_joint(False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

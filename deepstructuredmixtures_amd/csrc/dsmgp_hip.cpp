@@ -69,6 +69,7 @@ struct StepLists {
     // one phase (wave) of factorisation: per block step k the tasks for update / split-K reduce / diag / trsm
     std::vector<int> upd_off, red_off, diag_off, trsm_off;   // size nsteps+1
     std::vector<int> step_tiles;                             // whole update tiles per step (before split-K)
+    std::vector<char> pad;                                   // per step: >= 10 % of the tiles have rows 64.. all padding
     DevBuf<TileTask> upd, trsm;
     DevBuf<ReduceTask> red;
     DevBuf<DiagTask> diag;
@@ -466,6 +467,11 @@ void free_test(dsmgp_ctx* c) {
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// TileTask.mrows of a row tile with `valid` data rows: rounded up to the MFMA tile height; 0 = the whole tile
+inline int tile_mrows(int valid) {
+    const int m = round_up(std::max(0, std::min(TB, valid)), 16);
+    return m >= TB ? 0 : std::max(16, m);
+}
 
 // Upload the KParam table from the host hyper-parameters.
 int upload_hyper(dsmgp_ctx* c) {
@@ -590,6 +596,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.trsm_off.assign(nsteps + 1, 0);
         S.diag_off.assign(nsteps + 1, 0);
         S.step_tiles.assign(nsteps, 0);
+        S.pad.assign(nsteps, 0);
         for (int k = 0; k < nsteps; ++k) {
             S.upd_off[k] = (int)U.upd.size();
             S.red_off[k] = (int)U.red.size();
@@ -616,6 +623,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             u.k0 = 0;
                             u.k1 = k * TB;
                             u.update = 1;
+                            u.mrows = tile_mrows(lf.n - i * TB);
                             u.sym = (i == k) ? 1 : 0;   // diagonal tile: A == B, lower blocks only
                             nsym += (size_t)u.sym;
                             tiles.push_back(u);
@@ -631,6 +639,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             s.k0 = 0;
                             s.k1 = TB;
                             s.update = 0;
+                            s.mrows = tile_mrows(lf.n - i * TB);
                             if (ph == 0) {   // fused forward substitution for leaves factorised in full
                                 s.zk = d.z + (size_t)k * TB;
                                 s.wi = d.w + (size_t)i * TB;
@@ -667,6 +676,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             u.k0 = 0;
                             u.k1 = k * TB;
                             u.update = 1;
+                            u.mrows = tile_mrows(lf.nt - ti * TB);
                             tiles.push_back(u);
                         }
                         TileTask s{};
@@ -679,6 +689,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         s.k0 = 0;
                         s.k1 = TB;
                         s.update = 0;
+                        s.mrows = tile_mrows(lf.nt - ti * TB);
                         if (d.zfused) {   // z_k exists by the time this launch runs: accumulate mu and the variance term
                             s.zk = d.z + (size_t)k * TB;
                             s.wi = d.macc + (size_t)ti * TB;
@@ -696,6 +707,11 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             // diagonal tiles stay full tiles.
             if (nsym * 5 < tiles.size())
                 for (auto& u : tiles) u.sym = 0;
+            {   // padding-row tiles: worth the PAD instantiations of the kernels from a 10 % share on
+                size_t npad = 0;
+                for (const auto& u : tiles) npad += (u.mrows != 0 && u.mrows <= 64) ? 1 : 0;
+                S.pad[k] = (npad * 10 >= tiles.size() && npad > 0) ? 1 : 0;
+            }
             U.add_step(tiles, k * TB);
             S.step_tiles[k] = (int)tiles.size();
         }
@@ -922,10 +938,16 @@ int build_plan(dsmgp_ctx* c) {
     return 0;
 }
 
-void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */) {
+void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */, bool pad = false) {
+    if (pad) {   // launches with many padding-row tiles (small leaves): waves without data rows stay off the matrix pipe
+        if (role == 1) tile_trsm_kernel<true><<<n, 256, 0, c->stream>>>(tasks);
+        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+        else tile_gemm_kernel_v2<false, 0, true><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+        return;
+    }
     // ROLE only names the instantiation: with per-launch timing switched off (dsmgp_set_profile(ctx, 0)) the same code
     // runs as <false, 2>, so that a profiler's per-kernel average of <false, 0> covers exactly the launches bench.py times
-    if (role == 1) tile_trsm_kernel<<<n, 256, 0, c->stream>>>(tasks);   // B = inverse of a diagonal block, K = 128
+    if (role == 1) tile_trsm_kernel<false><<<n, 256, 0, c->stream>>>(tasks);   // B = inverse of a diagonal block, K = 128
     else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr);
     else tile_gemm_kernel_v2<false, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr);
 }
@@ -1002,7 +1024,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
         if (nu > 0) {
             pt.begin(1);
-            launch_tiles(c, S.upd.p + S.upd_off[k], nu);
+            launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0);
             pt.note(k, nu, S.step_tiles[k]);
             pt.end();
             const int nr = S.red_off[k + 1] - S.red_off[k];
@@ -1025,7 +1047,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
         if (ns > 0) {
             pt.begin(3);
-            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns, 1);
+            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns, 1, S.pad[k] != 0);
             pt.note(k, ns, 0);
             pt.end();
         }
@@ -1521,6 +1543,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                     u.k0 = 0;
                     u.k1 = k * TB;
                     u.update = 1;
+                    u.mrows = tile_mrows(lf.nt - ti * TB);
                     tiles.push_back(u);
                 }
                 TileTask s{};
@@ -1533,6 +1556,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                 s.k0 = 0;
                 s.k1 = TB;
                 s.update = 0;
+                s.mrows = tile_mrows(lf.nt - ti * TB);
                 s.zk = d.z + (size_t)k * TB;           // predictive mean and variance ride along
                 s.wi = d.macc + (size_t)ti * TB;
                 s.sq = d.sacc + (size_t)ti * TB;

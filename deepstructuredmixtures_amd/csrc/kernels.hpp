@@ -205,6 +205,9 @@ struct TileTask {
     int update;         // 0 = store the product, 1 = C - product
     int sym;            // 1: diagonal tile of the factorisation, B == A (C -= A A^T): only the lower 16x16 blocks are
                         //    computed and written (tile_syrk_body); the strictly upper blocks of C are left alone
+    int mrows;          // rows of the tile that hold data (rows >= mrows are padding: zero rows of A, whose product is
+                        //    zero); 0 = all 128.  Waves whose rows are all padding issue no MFMAs: a test-row tile of a
+                        //    small leaf (44 routed rows padded to 128) keeps two of its four waves off the matrix pipe
 };
 
 // diagnostic builds (-DDSMGP_DIAG, tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
@@ -604,10 +607,67 @@ __device__ __forceinline__ void tile_syrk_body(const TileTask& tk, double (*sA)[
     }
 }
 
+// The part of gemm_mainloop_v2 that a wave without data rows still has to do for its workgroup: its share of the global
+// loads and LDS writes of every chunk and all the barriers -- no fragment reads, no MFMAs, no epilogue (C - 0).
+// Used for whole-tile update tasks whose rows 64..127 are padding (TileTask.mrows <= 64) by the two waves that own them:
+// a test-row tile of a small leaf (44 routed rows padded to 128) then loads the matrix pipe of its CU half as much.
+__device__ __forceinline__ void gemm_staging_only(const TileTask& tk, double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP]) {
+    const int t = threadIdx.x;
+    const int scol = t >> 5, srow = 2 * (t & 31);
+    const double* gA = tk.A + srow + (size_t)(tk.k0 + scol) * tk.lda;
+    const double* gB = tk.B + srow + (size_t)(tk.k0 + scol) * tk.ldb;
+    const int sOff = scol * LDP + srow;
+    const int nch = (tk.k1 - tk.k0) / KC2;
+    d2 ra0[2], rb0[2], ra1[2], rb1[2];
+#define GLOAD(RA, RB, CH)                                                                        \
+    do {                                                                                         \
+        const size_t oa_ = (size_t)(CH) * KC2 * tk.lda, ob_ = (size_t)(CH) * KC2 * tk.ldb;       \
+        RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
+        RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                                    \
+        RB[0] = *AS_GLOBAL_D2(gB + ob_);                                                         \
+        RB[1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                                    \
+    } while (0)
+#define SWRITE(RA, RB, BUF)                                                                      \
+    do {                                                                                         \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA[0];                                          \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                                     \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff]) = RB[0];                                          \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = RB[1];                                     \
+    } while (0)
+    if (nch > 0) {   // same protocol as the prologue and the chunks of gemm_mainloop_v2
+        GLOAD(ra0, rb0, 0);
+        GLOAD(ra1, rb1, min(1, nch - 1));
+        SWRITE(ra0, rb0, 0);
+        GLOAD(ra0, rb0, min(2, nch - 1));
+        SWRITE(ra1, rb1, 1);
+        GLOAD(ra1, rb1, min(3, nch - 1));
+        SWRITE(ra0, rb0, 2);
+    }
+    __syncthreads();
+    int c = 0;
+    for (; c + 1 < nch; c += 2) {
+        GLOAD(ra0, rb0, min(c + 4, nch - 1));
+        SWRITE(ra1, rb1, (c + 3) & (NRING - 1));
+        __syncthreads();
+        GLOAD(ra1, rb1, min(c + 5, nch - 1));
+        SWRITE(ra0, rb0, (c + 4) & (NRING - 1));
+        __syncthreads();
+    }
+    if (c < nch) {
+        GLOAD(ra0, rb0, min(c + 4, nch - 1));
+        SWRITE(ra1, rb1, (c + 3) & (NRING - 1));
+        __syncthreads();
+    }
+#undef SWRITE
+#undef GLOAD
+}
+
 // ROLE only names the instantiation (same code): 0 = update launches (whole tiles and split-K pieces), 1 = panel
 // solves (K = 128), so that profilers report the two populations as two kernels
 // (tile_gemm_kernel_v2<false, 0> is the dominant kernel of bench.py's roofline).
-template <bool STAMP, int ROLE = 0>
+// PAD: the launch carries enough tiles with padding rows (TileTask.mrows) for the staging-only path to pay; without it the
+// check is compiled out (it costs the other launches ~0.3 % through the register allocation of the main path).
+template <bool STAMP, int ROLE = 0, bool PAD = false>
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
                                                               unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
@@ -617,6 +677,11 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
     const TileTask tk = tasks[blockIdx.x];
     if (tk.sym) {       // diagonal tile of the factorisation: lower blocks only (workgroup-uniform branch)
         tile_syrk_body(tk, sA);
+        return;
+    }
+    if (PAD && !STAMP && tk.update == 1 && tk.mrows != 0 && tk.wi == nullptr &&
+        ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) * 64 >= tk.mrows)) {
+        gemm_staging_only(tk, sA, sB);   // this wave's rows are padding: C - 0
         return;
     }
     d4 acc[4][4];
@@ -638,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
 // fully unrolled, which products exist is known at compile time: 288 MFMAs per wave instead of 512.
 // A wave holds whole rows of X, so the riders of the epilogue (forward substitution w_i -= X z_k for train rows,
 // predictive moments mu += X z_k, sum of squares for test rows) reduce inside the wave.
+template <bool PAD>
 __global__ __launch_bounds__(256, 2) void tile_trsm_kernel(const TileTask* __restrict__ tasks) {
     __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
     __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
@@ -682,6 +748,7 @@ __global__ __launch_bounds__(256, 2) void tile_trsm_kernel(const TileTask* __res
     TSWRITE(0, 2);
     __syncthreads();
     constexpr int NCH = TB / KC2;   // 16
+    const bool act = !PAD || tk.mrows == 0 || w * 32 < tk.mrows;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int buf = c & (NRING - 1);
@@ -689,6 +756,7 @@ __global__ __launch_bounds__(256, 2) void tile_trsm_kernel(const TileTask* __res
         const int cb0 = c / 2;      // column blocks below cb0 only see zeros of Dinv in this j range
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+            if (!act) continue;     // this wave's 32 rows are padding (zero rows of T): staging and barriers only
             double fb[2], fa[8];
             const double* pb = &sA[buf][(g * 4 + l4) * LDP + w * 32 + l15];
             const double* pa = &sB[buf][(g * 4 + l4) * LDP + l15];
@@ -708,6 +776,7 @@ __global__ __launch_bounds__(256, 2) void tile_trsm_kernel(const TileTask* __res
 #undef TSWRITE
 #undef TGLOAD
 
+    if (!act) return;   // padding rows: X = 0 is what the tile already holds there
     // store: register r of acc[cb][rn] is X(row = 32 w + 16 rn + l15, col = 16 cb + l4 + 4 r)
     const unsigned lofs = (unsigned)(w * 32 + l15) + (unsigned)l4 * (unsigned)tk.ldc;
     const size_t ldc = (size_t)tk.ldc;

@@ -43,17 +43,17 @@ json.dump(out, open(f"profiles/{tag}_bench_n100k_pmc_summary.json", "w"), indent
 
 
 def update_launches(d, counter, per_step=103):
-    """tile_gemm dispatches of the last TIMED-kind step: the update launches run as tile_gemm_kernel_v2<false, 0> while
-    per-launch timing is on (warm-up, timed steps, the breakdown step) and as <false, 2> in bench.py's untimed
+    """tile_gemm dispatches of the last TIMED-kind step: the update launches run as tile_gemm_kernel_v2<false, 0, *> while
+    per-launch timing is on (warm-up, timed steps, the breakdown step) and as <false, 2, *> in bench.py's untimed
     standalone fit/predict extra, so the last `per_step` dispatches of that name are one whole joint fit."""
-    rows = [r for r in rows_of(d) if r["Counter_Name"] == counter and "tile_gemm_kernel_v2<false, 0>" in r["Kernel_Name"]]
+    rows = [r for r in rows_of(d) if r["Counter_Name"] == counter and "tile_gemm_kernel_v2<false, 0," in r["Kernel_Name"]]
     return rows[-per_step:]
 
 
 fu, wu = update_launches("pmc2", "FETCH_SIZE"), update_launches("pmc3", "WRITE_SIZE")
 fetch = sum(float(r["Counter_Value"]) for r in fu) * 1024 * 2     # KB -> B; gfx950 counts 128-B requests of wide reads as 64 B
 write = sum(float(r["Counter_Value"]) for r in wu) * 1024
-res = {"kernel": "tile_gemm_kernel_v2<false, 0>: update launches of the last fit (test rows riding along)", "launches": len(fu),
+res = {"kernel": "tile_gemm_kernel_v2<false, 0, false>: update launches of the last fit (test rows riding along)", "launches": len(fu),
        "fetch_bytes_total": fetch, "write_bytes_total": write, "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)),
        "note": "FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024 over the update launches of one fit; separate --pmc passes of "
                "`python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile` (tools/profile_round.sh)"}
