@@ -1454,6 +1454,8 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (int rc = arena_get(c, c->arenaVt, vTot)) return rc;
     if (int rc = arena_get(c, c->arenaXt, xTot)) return rc;
     if (int rc = arena_get(c, c->arenaPV, pTot)) return rc;
+    // padding rows of the K_tn tiles: zero once, the Gram kernel writes data rows only (gram_half_tile)
+    if (vTot) HIPCHK(c, hipMemsetAsync(c->arenaVt, 0, vTot * sizeof(double), c->stream));
     int maxpad = 0;
     size_t accOff = 0;
     c->acc_off = 2 * (size_t)total;

@@ -102,6 +102,9 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
     const int r0 = (t & 31) * 4;
     const int cb = t >> 5;
     const int c0 = 64 * half;
+    // K_tn tiles (sym == 0): the four rows of this thread are all padding -> nothing to compute or store; the padding
+    // rows of the K_tn arena are zeroed once by dsmgp_set_test and every later kernel keeps zero rows zero
+    const bool rows_live = tk.sym != 0 || r0 < tk.na;
     double acc[8][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
@@ -120,6 +123,7 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
             sb[d][r] = (c0 + r < tk.nb) ? tk.xb[c0 + r + (size_t)(d0 + d) * tk.ldb] : 0.0;
         }
         __syncthreads();
+        if (!rows_live) continue;
         for (int d = 0; d < dn; ++d) {
             const double a0 = sa[d][r0], a1 = sa[d][r0 + 1], a2 = sa[d][r0 + 2], a3 = sa[d][r0 + 3];
             const double nhd = (KIND == 1) ? p.nh[d0 + d] : 0.0;   // -0.5 / l_d^2
@@ -147,6 +151,7 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
             }
         }
     }
+    if (!rows_live) return;
     const double nh = p.nh0, il2 = p.il2;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
