@@ -710,7 +710,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             {   // padding-row tiles: worth the PAD instantiations of the kernels from a 10 % share on
                 size_t npad = 0;
                 for (const auto& u : tiles) npad += (u.mrows != 0 && u.mrows <= 64) ? 1 : 0;
-                S.pad[k] = (npad * 10 >= tiles.size() && npad > 0) ? 1 : 0;
+                S.pad[k] = (npad * 10 >= tiles.size() && tiles.size() >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
             }
             U.add_step(tiles, k * TB);
             S.step_tiles[k] = (int)tiles.size();
