@@ -621,14 +621,25 @@ def train(model, optim=None, *, iterations=10_000, lam=None, randinit=True, earl
     has_leaves = len(model.shard.local) > 0
     if has_leaves:
         model.ctx.set_joint(False)     # fit is not followed by predict inside the loop: keep resident test rows out of it
+    # factor-and-discard context: a pass over the leaf groups cannot be revisited, so the loop's fit! asks for the
+    # gradients of the same pass up front (one pass per iteration instead of a fit pass plus a fit + gradient pass)
+    streaming = has_leaves and hasattr(model.ctx, "want_gradients")
+    if streaming:
+        model.ctx.want_gradients = max(lf.kernel.nparams() + 1 for lf in model.leaves)
+        model.ctx.groups = None
     try:
-        return _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose)
+        return _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose, streaming)
     finally:
         if has_leaves:
             model.ctx.set_joint(True)
 
 
-def _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose):
+def _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose, streaming=False):
+    def plain_fits():
+        if streaming:                  # the fits after the loop need no gradients: smaller groups, fewer passes
+            model.ctx.want_gradients = 0
+            model.ctx.groups = None
+
     for it in range(1, iterations + 1):
         setparams(model, hyp)
         fit(model, tau=tau)
@@ -639,10 +650,12 @@ def _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, ver
         if verbose:
             print(f"iter {it}: mll {ell:.6f} delta {delta:.3g}")
         if c >= earlystop:
+            plain_fits()
             return model, np.array(hist)
         updategradients(model)
         g = grad_mll(model)
         hyp = hyp + optim.apply(hyp, g)                                       # :78-79 (ascent)
+    plain_fits()
     setparams(model, hyp)
     fit(model, tau=tau)
     return model, np.array(hist)
