@@ -49,9 +49,11 @@ def build_model(cfg, rank, world, device, n_sub=1):
     kern = dsm.IsoSE(np.log(0.3), 0.0)
     if c.get("kvec"):
         kern = [kern, dsm.IsoLinear(np.log(1.5))]
+    t0 = time.perf_counter()
     model = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=kern,
                            logNoise=np.log(0.1), seed=20204, fit_now=False, device=device, n_sub=n_sub,
                            stream_budget=c.get("stream"))
+    model.build_seconds = time.perf_counter() - t0      # host only: tree + overlap (no device call yet)
     ptr, idx = ptree.route(model.root, Xt)
     if world > 1:
         op, src, _ = ptree.share_schedule(model.leaves, model.D, 0.05)
@@ -407,6 +409,7 @@ def main():
                                                                / args.steps) / 1e12 if world == 1 else None,
             "device_seconds_per_step": {k: v / args.steps for k, v in cats.items() if v > 0},
             "root_mll": root[0],
+            "model_build_s": model.build_seconds,
         }
         if standalone is not None:
             out["standalone_fit_s"] = standalone["fit_s"]

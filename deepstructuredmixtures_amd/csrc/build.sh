@@ -12,6 +12,12 @@ if [ "${1:-}" = "diag" ]; then
     out="$here/../libdsmgp_hip_diag.so"
     extra=(-DDSMGP_DIAG)
 fi
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -pthread -ldl \
-      -I"$here/../../include" "${extra[@]}" "$here/dsmgp_hip.cpp" -o "$out" "$@"
+# host_tree.cpp (tree builder, main-leaf search) is plain C++: no offload pass, and no fused multiply-add -- the builder
+# promises NumPy's floating-point results bit for bit
+obj="$(mktemp -d)"
+trap 'rm -rf "$obj"' EXIT
+/opt/rocm/lib/llvm/bin/clang++ -O3 -std=c++17 -fPIC -Wall -ffp-contract=off -pthread -c "$here/host_tree.cpp" -o "$obj/host_tree.o"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -pthread \
+      -I"$here/../../include" "${extra[@]}" -c "$here/dsmgp_hip.cpp" -o "$obj/dsmgp_hip.o" "$@"
+hipcc --offload-arch=gfx950 -fPIC -shared -pthread "$obj/dsmgp_hip.o" "$obj/host_tree.o" -ldl -o "$out"
 echo "built $out"

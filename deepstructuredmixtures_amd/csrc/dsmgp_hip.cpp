@@ -13,7 +13,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <array>
 #include <chrono>
 #include <dlfcn.h>
@@ -2531,79 +2530,6 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
 }
 #endif  // DSMGP_DIAG
 
-// Host-only helper of the sharing schedule (src/fit.jl:12-39,78-86) for leaf tables too large for the dense L x L
-// overlap matrix: for every leaf j, main[j] = argmax_i D[i,j] D[j,i] with D[a,b] = 1 - (|a| - |a n b|) / |a| for
-// overlapping a != b and 0 otherwise (first maximum; 0 when the leaf overlaps nothing, like argmax of a zero column),
-// and c_main[j] = |j n main[j]|.  Intersection counts come from an inverted index (point -> leaves), one leaf at a
-// time: O(sum_p deg(p)^2) work, O(L + sum n) memory, no L x L array.  No device is touched.
-int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx, int64_t N, int64_t* main_out,
-                       int64_t* c_main_out) {
-    if (L < 0 || !obs_ptr || (!obs_idx && L > 0 && obs_ptr[L] > 0) || N <= 0 || !main_out || !c_main_out) return DSMGP_E_ARG;
-    const int64_t total = L ? obs_ptr[L] : 0;
-    for (int64_t e = 0; e < total; ++e)
-        if (obs_idx[e] < 0 || obs_idx[e] >= N) return DSMGP_E_ARG;
-    // inverted index: leaves of every point, ascending leaf order
-    std::vector<int64_t> pptr(N + 1, 0);
-    for (int64_t e = 0; e < total; ++e) pptr[obs_idx[e] + 1]++;
-    for (int64_t p = 0; p < N; ++p) pptr[p + 1] += pptr[p];
-    std::vector<int32_t> pleaf(total);
-    {
-        std::vector<int64_t> fill(pptr.begin(), pptr.end() - 1);
-        for (int32_t l = 0; l < L; ++l)
-            for (int64_t e = obs_ptr[l]; e < obs_ptr[l + 1]; ++e) pleaf[fill[obs_idx[e]]++] = l;
-    }
-    // leaves are independent: split them over host threads (each with its own counter array)
-    const int nthr = (int)std::max(1u, std::min(16u, std::min(std::thread::hardware_concurrency(), (unsigned)(L / 512 + 1))));
-    auto work = [&](int32_t j0, int32_t j1) {
-    std::vector<int32_t> cnt(L, 0), touched;
-    for (int32_t j = j0; j < j1; ++j) {
-        touched.clear();
-        for (int64_t e = obs_ptr[j]; e < obs_ptr[j + 1]; ++e) {
-            const int64_t p = obs_idx[e];
-            for (int64_t q = pptr[p]; q < pptr[p + 1]; ++q) {
-                const int32_t l = pleaf[q];
-                if (cnt[l]++ == 0) touched.push_back(l);
-            }
-        }
-        const double nj = (double)(obs_ptr[j + 1] - obs_ptr[j]);
-        double best = 0.0;
-        int64_t bi = 0, bc = 0;
-        for (int32_t l : touched) {
-            const int32_t c = cnt[l];
-            cnt[l] = 0;
-            if (l == j) continue;
-            const double nl = (double)(obs_ptr[l + 1] - obs_ptr[l]);
-            const double d_jl = 1.0 - (nj - (double)c) / nj;      // D[j, l]
-            const double d_lj = 1.0 - (nl - (double)c) / nl;      // D[l, j]
-            const double prod = d_lj * d_jl;
-            if (prod > best || (prod == best && best > 0.0 && l < bi)) {
-                best = prod;
-                bi = l;
-                bc = c;
-            }
-        }
-        main_out[j] = best > 0.0 ? bi : 0;
-        c_main_out[j] = best > 0.0 ? bc : 0;
-    }
-    };
-    if (nthr == 1) work(0, L);
-    else {
-        // contiguous ranges of equal total size (a leaf costs ~ its size times the overlap degree)
-        std::vector<std::thread> th;
-        int32_t j0 = 0;
-        for (int t = 0; t < nthr; ++t) {
-            const int64_t target = total * (int64_t)(t + 1) / nthr;
-            int32_t j1 = j0;
-            while (j1 < L && obs_ptr[j1 + 1] <= target) ++j1;
-            if (t == nthr - 1) j1 = L;
-            th.emplace_back(work, j0, j1);
-            j0 = j1;
-        }
-        for (auto& x : th) x.join();
-    }
-    return 0;
-}
-
 // -------------------------------------------------------------------------------------------------
 // The one exchange step of the path when leaves are sharded over the GPUs of a node: an all-gather of
 // per-leaf log-marginals after fit! and of the aggregation's partial sums after predict, over RCCL (xGMI inside a node)
@@ -2706,283 +2632,6 @@ int dsmgp_comm_destroy(dsmgp_ctx* c) {
     c->xchg_cap = 0;
     c->comm_world = 1;
     c->comm_rank = 0;
-    return 0;
-}
-
-// -------------------------------------------------------------------------------------------------
-// Host-only: the random partition tree of buildTree (src/treeStructure.jl:4-307) -- getSplits (:23-129), _buildSplit
-// (:131-210), _buildSum (:212-243), the regions of _buildGP (:245-307) -- as one native recursion over index lists
-// instead of one interpreted call per node (26k nodes at depth 4).  Draws come from the portable
-// counter stream (deepstructuredmixtures_amd/datagen.py: SplitMix64, draw i = mix(seed + (i+1) GAMMA)) in exactly the
-// order of the Python builder tree.py, every floating-point expression is evaluated as NumPy evaluates it (pairwise
-// sum of the ranges, median of an even count = (a+b)/2, no fused multiply-add), so both builders return the same tree
-// bit for bit (tests/test_host_cpu.py).  No device is touched.
-namespace {
-#pragma clang fp contract(off)
-
-struct TreeBuild {
-    const double* X;
-    int64_t N;
-    int D, minData, K, V, maxDepth, nKernels;
-    double bnoise;
-    bool sumRoot;
-    uint64_t seed, pos = 0;
-    // node table (creation order = pre-order)
-    std::vector<int32_t> kind, split_dim, parent;        // kind: 0 region (GP or sum of GPs), 1 split, 2 sum
-    std::vector<double> lb, ub;                          // D per node
-    std::vector<int64_t> thr_ptr, obs_ptr;               // per node (+1)
-    std::vector<double> thr, dir_u;
-    std::vector<int64_t> obs;
-
-    double rand() {
-        uint64_t z = seed + (pos + 1) * 0x9E3779B97F4A7C15ull;
-        ++pos;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z = z ^ (z >> 31);
-        return (double)(z >> 11) * (1.0 / 9007199254740992.0);
-    }
-    double beta22() {
-        double a = rand(), b = rand(), c = rand();
-        if (a > b) std::swap(a, b);
-        if (b > c) std::swap(b, c);
-        if (a > b) std::swap(a, b);
-        return b;
-    }
-    int new_node(int k, int par, const std::vector<double>& l, const std::vector<double>& u) {
-        kind.push_back(k);
-        split_dim.push_back(-1);
-        parent.push_back(par);
-        lb.insert(lb.end(), l.begin(), l.end());
-        ub.insert(ub.end(), u.begin(), u.end());
-        thr_ptr.push_back((int64_t)thr.size());
-        obs_ptr.push_back((int64_t)obs.size());
-        return (int)kind.size() - 1;
-    }
-    // numpy's pairwise summation for n < 128 (add.reduce of a contiguous float64 vector)
-    static double np_sum(const std::vector<double>& a) {
-        const size_t n = a.size();
-        if (n < 8) {
-            double r = 0.0;
-            for (size_t i = 0; i < n; ++i) r += a[i];
-            return r;
-        }
-        double r[8];
-        for (int j = 0; j < 8; ++j) r[j] = a[j];
-        size_t i = 8;
-        for (; i + 8 <= n; i += 8)
-            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += a[i];
-        return res;
-    }
-    // getSplits (src/treeStructure.jl:23-129) on the coordinates `vals` of the region that lie inside the parent's
-    // (l, u]: the reference filters the whole region again at every recursion level, with l = max(lower, region min) and
-    // u = min(upper, region max); the bounds only shrink on the way down, so filtering the parent's selection gives the
-    // same set (rmin / rmax: extrema of the WHOLE region on this dimension, as the reference uses them).
-    void get_splits(const std::vector<double>& vals, double rmin, double rmax, double lower, double upper, int depth,
-                    std::vector<double>& s) {
-        int K_ = depth * depth;
-        const double l = std::max(lower, rmin), u = std::min(upper, rmax);
-        const double v = u - l;
-        std::vector<double> sel;
-        sel.reserve(vals.size());
-        for (double x : vals)
-            if (x > l && x <= u) sel.push_back(x);
-        if ((int64_t)sel.size() <= 2 * (int64_t)minData) return;
-        double m;
-        {
-            std::vector<double> t(sel);
-            const size_t h = t.size() / 2;
-            std::nth_element(t.begin(), t.begin() + h, t.end());
-            if (t.size() % 2) m = t[h];
-            else {
-                const double hi = t[h];
-                const double lo = *std::max_element(t.begin(), t.begin() + h);
-                m = (lo + hi) / 2.0;
-            }
-        }
-        int64_t z1 = 0, z2 = 0;
-        int cnt = 0;
-        double s_new = m;
-        while (z1 == 0 || z2 == 0) {
-            const double a = beta22() * v + l;
-            const double t1 = bnoise * a, t2 = (1.0 - bnoise) * m;
-            s_new = t1 + t2;
-            z1 = 0;
-            for (double x : sel) z1 += (x <= s_new) ? 1 : 0;
-            z2 = (int64_t)sel.size() - z1;
-            if (++cnt > 100) return;
-        }
-        const bool first_low = (1 + (int)(rand() * 2.0)) == 1;
-        for (int posn = 0; posn < 2; ++posn) {
-            const bool low = (posn == 0) == first_low;
-            const int64_t z = low ? z1 : z2;
-            if (z > minData && K_ < K) {
-                if (low) get_splits(sel, rmin, rmax, lower, s_new, depth + 1, s);
-                else get_splits(sel, rmin, rmax, s_new, upper, depth + 1, s);
-                if (posn == 0) K_ += 1;
-            }
-        }
-        s.push_back(s_new);
-    }
-    void build_gp(int par, const std::vector<int64_t>& idx, const std::vector<double>& l, const std::vector<double>& u) {
-        const int id = new_node(0, par, l, u);
-        (void)id;
-        obs.insert(obs.end(), idx.begin(), idx.end());
-        if (nKernels > 0)
-            for (int k = 0; k < nKernels; ++k) dir_u.push_back(rand());
-    }
-    void build_split(int par, const std::vector<int64_t>& idx, const std::vector<double>& lowerBound,
-                     const std::vector<double>& upperBound, int depth, int d) {
-        const double* xd = X + (size_t)d * N;
-        std::vector<double> vals(idx.size());
-        double rmin = xd[idx[0]], rmax = xd[idx[0]];
-        for (size_t q = 0; q < idx.size(); ++q) {
-            const double x = xd[idx[q]];
-            vals[q] = x;
-            rmin = std::min(rmin, x);
-            rmax = std::max(rmax, x);
-        }
-        std::vector<double> s;
-        get_splits(vals, rmin, rmax, lowerBound[d], upperBound[d], 1, s);
-        std::sort(s.begin(), s.end());
-        if (s.empty()) {
-            std::vector<int64_t> sub;
-            for (size_t q = 0; q < idx.size(); ++q)
-                if (vals[q] > lowerBound[d] && vals[q] <= upperBound[d]) sub.push_back(idx[q]);
-            build_gp(par, sub, lowerBound, upperBound);
-            return;
-        }
-        const int id = new_node(1, par, lowerBound, upperBound);
-        split_dim[id] = d;
-        s.push_back(upperBound[d]);
-        thr.insert(thr.end(), s.begin(), s.end());
-        // child k holds the points with s[k-1] < x <= s[k] (s[-1] = lowerBound[d]): one pass, first k with x <= s[k]
-        std::vector<std::vector<int64_t>> sub(s.size());
-        for (size_t q = 0; q < idx.size(); ++q) {
-            const double x = vals[q];
-            if (!(x > lowerBound[d])) continue;
-            const size_t k = (size_t)(std::lower_bound(s.begin(), s.end(), x) - s.begin());
-            if (k < s.size()) sub[k].push_back(idx[q]);
-        }
-        vals.clear();
-        vals.shrink_to_fit();
-        std::vector<double> lbv(lowerBound), ubv(upperBound);
-        for (size_t k = 0; k < s.size(); ++k) {
-            const double si = s[k];
-            std::vector<double> lb_(lbv), ub_(ubv);
-            ub_[d] = si;
-            if (depth < maxDepth && (int64_t)sub[k].size() > (int64_t)minData) {
-                if (sumRoot) build_sum(id, sub[k], lb_, ub_, depth);
-                else build_split(id, sub[k], lb_, ub_, depth, 0);
-            } else {
-                build_gp(id, sub[k], lb_, ub_);
-            }
-            std::vector<int64_t>().swap(sub[k]);
-            lbv[d] = si;
-        }
-    }
-    void build_sum(int par, const std::vector<int64_t>& idx, const std::vector<double>& lowerBound,
-                   const std::vector<double>& upperBound, int depth) {
-        const int id = new_node(2, par, lowerBound, upperBound);
-        std::vector<double> phi(D);
-        for (int d = 0; d < D; ++d) {
-            const double* xd = X + (size_t)d * N;
-            double mn = xd[idx[0]], mx = xd[idx[0]];
-            for (int64_t i : idx) {
-                mn = std::min(mn, xd[i]);
-                mx = std::max(mx, xd[i]);
-            }
-            phi[d] = mx - mn;
-        }
-        const double tot = np_sum(phi);
-        if (tot > 0.0)
-            for (int d = 0; d < D; ++d) phi[d] = phi[d] / tot;
-        else
-            for (int d = 0; d < D; ++d) phi[d] = 1.0 / (double)D;
-        for (int v = 0; v < V; ++v) {
-            // Categorical(phi): cumulative sums, first index with c[i] > u c[-1]
-            std::vector<double> cs(D);
-            double acc = 0.0;
-            for (int d = 0; d < D; ++d) {
-                acc += phi[d];
-                cs[d] = acc;
-            }
-            const double x = rand() * cs[D - 1];
-            int dsel = (int)(std::upper_bound(cs.begin(), cs.end(), x) - cs.begin());
-            dsel = std::min(dsel, D - 1);
-            build_split(id, idx, lowerBound, upperBound, depth + 1, dsel);
-        }
-    }
-};
-}  // namespace
-
-struct dsmgp_tree {
-    TreeBuild b;
-};
-
-int dsmgp_tree_build(const double* X, int64_t N, int32_t D, int32_t min_data, int32_t n_splits, int32_t n_sum_children,
-                     int32_t depth, double bnoise, int32_t sum_root, int32_t n_kernels, uint64_t seed, dsmgp_tree** out) {
-    if (!X || N <= 0 || D <= 0 || !out || min_data < 0 || n_splits < 1 || n_sum_children < 1 || depth < 0 || n_kernels < 0)
-        return DSMGP_E_ARG;
-    for (int64_t i = 0; i < N * (int64_t)D; ++i)
-        if (!std::isfinite(X[i])) return DSMGP_E_ARG;
-    dsmgp_tree* t = new dsmgp_tree();
-    TreeBuild& b = t->b;
-    b.X = X;
-    b.N = N;
-    b.D = D;
-    b.minData = min_data;
-    b.K = n_splits;
-    b.V = n_sum_children;
-    b.maxDepth = depth;
-    b.bnoise = bnoise;
-    b.sumRoot = sum_root != 0;
-    b.nKernels = n_kernels;
-    b.seed = seed;
-    std::vector<int64_t> all((size_t)N);
-    for (int64_t i = 0; i < N; ++i) all[i] = i;
-    const double inf = std::numeric_limits<double>::infinity();
-    std::vector<double> lbv(D, -inf), ubv(D, inf);
-    if (b.sumRoot) b.build_sum(-1, all, lbv, ubv, 0);
-    else b.build_split(-1, all, lbv, ubv, 0, 0);
-    b.thr_ptr.push_back((int64_t)b.thr.size());
-    b.obs_ptr.push_back((int64_t)b.obs.size());
-    b.X = nullptr;
-    *out = t;
-    return 0;
-}
-
-int dsmgp_tree_sizes(const dsmgp_tree* t, int64_t* n_nodes, int64_t* n_thr, int64_t* n_obs, int64_t* n_dir) {
-    if (!t) return DSMGP_E_ARG;
-    if (n_nodes) *n_nodes = (int64_t)t->b.kind.size();
-    if (n_thr) *n_thr = (int64_t)t->b.thr.size();
-    if (n_obs) *n_obs = (int64_t)t->b.obs.size();
-    if (n_dir) *n_dir = (int64_t)t->b.dir_u.size();
-    return 0;
-}
-
-int dsmgp_tree_export(const dsmgp_tree* t, int32_t* kind, int32_t* parent, int32_t* split_dim, double* lb, double* ub,
-                      int64_t* thr_ptr, double* thr, int64_t* obs_ptr, int64_t* obs, double* dir_u) {
-    if (!t || !kind || !parent || !split_dim || !lb || !ub || !thr_ptr || !obs_ptr) return DSMGP_E_ARG;
-    const TreeBuild& b = t->b;
-    const size_t n = b.kind.size();
-    std::memcpy(kind, b.kind.data(), n * sizeof(int32_t));
-    std::memcpy(parent, b.parent.data(), n * sizeof(int32_t));
-    std::memcpy(split_dim, b.split_dim.data(), n * sizeof(int32_t));
-    std::memcpy(lb, b.lb.data(), b.lb.size() * sizeof(double));
-    std::memcpy(ub, b.ub.data(), b.ub.size() * sizeof(double));
-    std::memcpy(thr_ptr, b.thr_ptr.data(), (n + 1) * sizeof(int64_t));
-    std::memcpy(obs_ptr, b.obs_ptr.data(), (n + 1) * sizeof(int64_t));
-    if (thr && !b.thr.empty()) std::memcpy(thr, b.thr.data(), b.thr.size() * sizeof(double));
-    if (obs && !b.obs.empty()) std::memcpy(obs, b.obs.data(), b.obs.size() * sizeof(int64_t));
-    if (dir_u && !b.dir_u.empty()) std::memcpy(dir_u, b.dir_u.data(), b.dir_u.size() * sizeof(double));
-    return 0;
-}
-
-int dsmgp_tree_free(dsmgp_tree* t) {
-    delete t;
     return 0;
 }
 

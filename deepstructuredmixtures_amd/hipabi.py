@@ -67,6 +67,7 @@ SIGNATURES = {
                                    C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "dsmgp_tree_sizes": (C.c_int, [C.c_void_p, _lp, _lp, _lp, _lp]),
     "dsmgp_tree_export": (C.c_int, [C.c_void_p, _ip, _ip, _ip, _dp, _dp, _lp, _dp, _lp, _lp, _dp]),
+    "dsmgp_tree_means": (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp]),
     "dsmgp_tree_free": (C.c_int, [C.c_void_p]),
     "dsmgp_estimate_bytes": (C.c_int64, [C.c_int32, _lp, _lp, C.c_int32, C.c_int32]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
@@ -622,9 +623,10 @@ def overlap_main(obs_ptr, obs_idx, N):
     return main, cm
 
 
-def tree_build(X, min_data, n_splits, n_sum_children, depth, bnoise, sum_root, n_kernels, seed):
+def tree_build(X, min_data, n_splits, n_sum_children, depth, bnoise, sum_root, n_kernels, seed, y=None):
     """Node table of the random partition tree (host routine of the library, no device; include/dsmgp_hip.h
-    dsmgp_tree_build): dict of arrays kind / parent / split_dim / lb / ub / thr_ptr / thr / obs_ptr / obs / dir_u."""
+    dsmgp_tree_build): dict of arrays kind / parent / split_dim / lb / ub / thr_ptr / thr / obs_ptr / obs / dir_u, and,
+    given y, `mean` = mean(y[obs]) per region (dsmgp_tree_means)."""
     lib = load_library()
     X, px = _f64_fortran(X)
     N, D = X.shape
@@ -647,6 +649,14 @@ def tree_build(X, min_data, n_splits, n_sum_children, depth, bnoise, sum_root, n
         if rc != 0:
             raise DsmgpError(rc, "dsmgp_tree_export failed")
         out["thr"], out["obs"], out["dir_u"] = out["thr"][:nthr], out["obs"][:nobs], out["dir_u"][:ndir]
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            if y.shape != (N,):
+                raise ValueError("tree_build: y must have one value per row of X")
+            out["mean"] = np.empty(max(int(np.count_nonzero(out["kind"] == 0)), 1))
+            rc = lib.dsmgp_tree_means(h, y.ctypes.data_as(_dp), N, out["mean"].ctypes.data_as(_dp))
+            if rc != 0:
+                raise DsmgpError(rc, "dsmgp_tree_means failed")
         return out
     finally:
         lib.dsmgp_tree_free(h)

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import hipabi
 from .kernels import IsoSE, ConstMean, KIND_ISO_SE, KIND_ARD_SE, KIND_ISO_LINEAR
-from .tree import (DSMGPConfig, GPSumNode, build_tree, get_leaves, get_overlap, share_schedule, route, route_all,
+from .tree import (DSMGPConfig, GPSumNode, build_tree, get_leaves, get_overlap, obs_table, share_schedule, route, route_all,
                    get_child, ordered_nodes, SHARE_COPY, SHARE_FULL, SHARE_PREFIX)
 from . import dist as _dist
 
@@ -210,10 +210,7 @@ class Model:
         if not self._uploaded:
             self.ctx.set_train(self.x, self.y)
         lv = [self.leaves[i] for i in loc]
-        ptr = np.zeros(len(lv) + 1, dtype=np.int64)
-        for i, lf in enumerate(lv):
-            ptr[i + 1] = ptr[i] + lf.nobs
-        idx = np.concatenate([lf.obs for lf in lv]) if lv else np.zeros(0, np.int64)
+        ptr, idx = obs_table(lv)
         self.ctx.set_leaves(ptr, idx, [lf.kernelid for lf in lv], [lf.mean.m for lf in lv])
         if self.D is not None and tau is not None:
             op, src, plen = share_schedule(self.leaves, self.D, tau)

@@ -223,43 +223,47 @@ def _build_tree_native(X, y, config, seed):
     N, D = X.shape
     assert N == y.shape[0] and np.all(np.isfinite(X))
     kvec = isinstance(config.kernels, (list, tuple))
-    tab = hipabi.tree_build(X, config.minData, config.K, config.V, config.depth, config.bnoise, config.sumRoot,
-                            len(config.kernels) if kvec else 0, seed)
-    n = tab["kind"].size
+    nk = len(config.kernels) if kvec else 0
+    tab = hipabi.tree_build(X, config.minData, config.K, config.V, config.depth, config.bnoise, config.sumRoot, nk, seed,
+                            y=y if config.meanFun is None else None)
+    kind, parent, sdim = tab["kind"].tolist(), tab["parent"].tolist(), tab["split_dim"].tolist()
+    tptr, optr = tab["thr_ptr"].tolist(), tab["obs_ptr"].tolist()
+    lbs, ubs, thr, obs_all = tab["lb"], tab["ub"], tab["thr"].tolist(), tab["obs"]
+    n = len(kind)
     nodes = [None] * n
     region = 0
-    nk = len(config.kernels) if kvec else 0
-    for i in range(n):                               # creation (pre-)order: parents come first
-        k = int(tab["kind"][i])
-        lb, ub = tab["lb"][i].copy(), tab["ub"][i].copy()
+    sum_lw = np.full(config.V, -np.log(config.V))        # what V calls of GPSumNode.add(child, -log V) build up
+    for i in range(n):                                    # creation (pre-)order: parents come first
+        k = kind[i]
         if k == 1:
-            d = int(tab["split_dim"][i])
-            node = GPSplitNode(lb, ub, [(d, float(t)) for t in tab["thr"][tab["thr_ptr"][i]:tab["thr_ptr"][i + 1]]])
+            d = sdim[i]
+            node = GPSplitNode(lbs[i], ubs[i], [(d, t) for t in thr[tptr[i]:tptr[i + 1]]])
         elif k == 2:
             node = GPSumNode()
         else:
-            obs = tab["obs"][tab["obs_ptr"][i]:tab["obs_ptr"][i + 1]].copy()
-            yy = y[obs]
-            ym = float(np.mean(yy)) if yy.size else 0.0
-            mfun = ConstMean(ym) if config.meanFun is None else config.meanFun
+            obs = obs_all[optr[i]:optr[i + 1]]            # views of the builder's tables: one allocation for all regions
+            if config.meanFun is None:
+                mfun = ConstMean(float(tab["mean"][region]) if obs.size else 0.0)
+            else:
+                mfun = config.meanFun
             if kvec:
                 u = tab["dir_u"][region * nk:(region + 1) * nk]
                 e = -np.log(1.0 - u)                     # Stream.dirichlet1 on the uniforms the builder drew
                 w = e / e.sum()
                 node = GPSumNode(of_gps=True)
                 for v, kern in enumerate(config.kernels):
-                    node.add(GPNode(obs, lb, ub, kern.copy(), v, mfun, config.observationNoise), np.log(w[v]))
+                    node.add(GPNode(obs, lbs[i], ubs[i], kern.copy(), v, mfun, config.observationNoise), np.log(w[v]))
             else:
-                node = GPNode(obs, lb, ub, config.kernels.copy(), 0, mfun, config.observationNoise)
+                node = GPNode(obs, lbs[i], ubs[i], config.kernels.copy(), 0, mfun, config.observationNoise)
             region += 1
         nodes[i] = node
-        par = int(tab["parent"][i])
+        par = parent[i]
         if par >= 0:
-            p = nodes[par]
-            if p.kind == "sum":
-                p.add(node, -np.log(config.V))
-            else:
-                p.children.append(node)
+            nodes[par].children.append(node)
+    for i in range(n):
+        if kind[i] == 2:                                  # every split call under a sum node returns exactly one child
+            assert len(nodes[i].children) == config.V
+            nodes[i].logweights = sum_lw.copy()
     root = nodes[0]
     for i, leaf in enumerate(get_leaves(root)):
         leaf.leaf = i
@@ -285,13 +289,34 @@ def build_tree_python(X, y, config, seed=7):
 
 # ----------------------------------------------------------------------------- overlap + schedule
 
+def obs_table(leaves):
+    """CSR (ptr, idx) of the leaves' observation lists.  Leaves of the native builder hold consecutive views of one table
+    (hipabi.tree_build): that table is returned as it is, without a copy; any other leaf list is concatenated."""
+    L = len(leaves)
+    ptr = np.zeros(L + 1, dtype=np.int64)
+    if L:
+        np.cumsum([lf.nobs for lf in leaves], out=ptr[1:])
+    if L == 0:
+        return ptr, np.zeros(0, np.int64)
+    base = leaves[0].obs.base
+    if (isinstance(base, np.ndarray) and base.ndim == 1 and base.dtype == np.int64 and base.flags.c_contiguous
+            and base.size >= ptr[-1]):
+        addr = base.__array_interface__["data"][0]
+        start = leaves[0].obs.__array_interface__["data"][0] - addr
+        if start >= 0 and start % 8 == 0 and start // 8 + ptr[-1] <= base.size and all(
+                lf.obs.base is base and lf.obs.__array_interface__["data"][0] == addr + start + 8 * int(p)
+                for lf, p in zip(leaves, ptr[:-1])):
+            return ptr, base[start // 8:start // 8 + int(ptr[-1])]
+    return ptr, np.concatenate([lf.obs for lf in leaves])
+
+
 def _membership(leaves):
     """Sparse leaf-membership matrix M (L x N, int32 ones) and the leaf sizes."""
     import scipy.sparse as sp
     L = len(leaves)
     nobs = np.array([lf.nobs for lf in leaves], dtype=np.int64)
     rows = np.repeat(np.arange(L), nobs)
-    cols = np.concatenate([lf.obs for lf in leaves]) if L else np.zeros(0, np.int64)
+    cols = obs_table(leaves)[1]
     N = int(cols.max()) + 1 if cols.size else 1
     return sp.csr_matrix((np.ones(rows.size, dtype=np.int32), (rows, cols)), shape=(L, N)), nobs
 
@@ -346,8 +371,7 @@ class LeafOverlap:
         if native:
             # host routine of libdsmgp_hip.so (inverted index, one leaf at a time; include/dsmgp_hip.h)
             from . import hipabi
-            ptr = np.concatenate([[0], np.cumsum(self.nobs)])
-            idx = np.concatenate([lf.obs for lf in self._leaves])
+            ptr, idx = obs_table(self._leaves)
             main, c = hipabi.overlap_main(ptr, idx, int(idx.max()) + 1)
             n = self.nobs.astype(np.float64)
             cf = c.astype(np.float64)

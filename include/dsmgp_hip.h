@@ -218,6 +218,10 @@ int dsmgp_tree_build(const double* X /* N x D */, int64_t N, int32_t D, int32_t 
 int dsmgp_tree_sizes(const dsmgp_tree* t, int64_t* n_nodes, int64_t* n_thr, int64_t* n_obs, int64_t* n_dir);
 int dsmgp_tree_export(const dsmgp_tree* t, int32_t* kind, int32_t* parent, int32_t* split_dim, double* lb, double* ub,
                       int64_t* thr_ptr, double* thr, int64_t* obs_ptr, int64_t* obs, double* dir_u);
+/* Mean of y over the observation list of every region, in region (creation) order: the ConstMean of a leaf built
+ * without a mean function (src/treeStructure.jl:253).  Summed as NumPy sums a contiguous vector (pairwise), so the
+ * value equals mean(y[obs]) of the interpreted builder bit for bit.  mean_out: one double per region (kind 0 node). */
+int dsmgp_tree_means(const dsmgp_tree* t, const double* y, int64_t N, double* mean_out);
 int dsmgp_tree_free(dsmgp_tree* t);
 
 #ifdef __cplusplus

@@ -506,8 +506,20 @@ def test_host_only_entry_points_reject_bad_arguments():
     for i in np.flatnonzero(tab["kind"] == 0):
         o = tab["obs"][tab["obs_ptr"][i]:tab["obs_ptr"][i + 1]]
         assert np.all(np.diff(o) > 0)                                  # ascending row indices
+    # dsmgp_tree_means: NumPy's own mean of every region, bit for bit (pairwise summation above 128 rows included)
+    big = np.asfortranarray(np.random.default_rng(1).random((3000, 2)))
+    yb = np.random.default_rng(2).normal(size=3000) * 1e3
+    tb = hipabi.tree_build(big, 400, 2, 2, 1, 0.5, True, 0, 3, y=yb)
+    reg = np.flatnonzero(tb["kind"] == 0)
+    sizes = np.diff(tb["obs_ptr"])[reg]
+    assert sizes.max() > 128 and tb["mean"].size == reg.size
+    for r, i in enumerate(reg):
+        assert tb["mean"][r] == np.mean(yb[tb["obs"][tb["obs_ptr"][i]:tb["obs_ptr"][i + 1]]])
+    with pytest.raises(ValueError):
+        hipabi.tree_build(big, 400, 2, 2, 1, 0.5, True, 0, 3, y=yb[:-1])
     h = ctypes.c_void_p()
     assert lib.dsmgp_tree_build(None, 10, 2, 5, 4, 3, 2, 0.5, 1, 0, 1, ctypes.byref(h)) == -1
+    assert lib.dsmgp_tree_means(None, None, 10, None) == -1
     with pytest.raises(hipabi.DsmgpError):
         hipabi.overlap_main(np.array([0, 2]), np.array([0, 99]), 10)   # observation index out of range
     assert hipabi.estimate_bytes([128], [0], 3) == (128 * 128 + 128 * 128 + 128 * 7) * 8
