@@ -233,6 +233,8 @@ def main():
                     help="fit_predict: the BASELINE metric (default); train: one train! iteration per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
+    ap.add_argument("--unfused-gram", action="store_true",
+                    help="diagnostic: every Gram tile through memory first (DSMGP_OPT_FUSED_GRAM = 0), for A/B runs")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
@@ -297,6 +299,8 @@ def main():
         n_sub = args.sub if args.sub is not None else default_sub(world)
         model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
     ctx = model.ctx
+    if args.unfused_gram:
+        ctx.set_option(dsm.hipabi.OPT_FUSED_GRAM, 0)
     if args.mode == "train":
         return bench_train(args, model, X, y, rank, world, td, torch)
     ctx.set_profile(0 if args.no_profile else 1)   # timed region: events around the update launches only

@@ -145,6 +145,7 @@ struct UpdateSplitter {
             r.C = tiles[i].C;
             r.ldc = tiles[i].ldc;
             r.nsplit = S;
+            r.fresh = tiles[i].gram != 0 ? 1 : 0;   // piece 0 stores product - Gram value: nothing to read from the tile
             red.push_back(r);
             red_slab.push_back((int64_t)(first + (i - from) * S));
         }
@@ -158,6 +159,7 @@ struct UpdateSplitter {
                 p.update = 0;
                 p.C = nullptr;
                 p.ldc = TB;
+                if (s != 0) p.gram = 0;
                 upd.push_back(p);
                 upd_slab.push_back((int64_t)(first + (i - from) * S + s));
             }
@@ -235,7 +237,8 @@ struct dsmgp_ctx {
     std::vector<LeafDev> h_leaves;
     size_t bytes_needed = 0;
 
-    DevBuf<GramTask> gram;
+    DevBuf<GramTask> gram;          // Gram launch of fit!: every lower tile, or (fused) the tiles no update task writes
+    bool fuse_gram = true;          // update tasks of fit! evaluate the Gram values of their tile themselves (TileTask.gram)
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
     // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
@@ -271,7 +274,8 @@ struct dsmgp_ctx {
     double* arenaPV = nullptr;      // mu | var (route order, unpadded) | macc | sacc (padded accumulators of the sweep)
     size_t acc_off = 0, acc_count = 0;
     DevBuf<PredTask> ptasks_slow;   // test tiles of leaves whose z is not produced during the factorisation
-    DevBuf<GramTask> pgram;
+    DevBuf<GramTask> pgram;         // K_tn tiles of the standalone sweep (all of them)
+    DevBuf<GramTask> pgram0;        // ... of the joint fit when the Gram is fused: block column 0 only
     DevBuf<PredTask> ptasks;
     std::vector<int> pupd_off, pred_off, ptrsm_off;
     DevBuf<TileTask> pupd, ptrsm;
@@ -446,6 +450,8 @@ void free_test(dsmgp_ctx* c) {
     arena_put(c, c->arenaXt);
     arena_put(c, c->arenaPV);
     dev_free(c->pgram.p);
+    dev_free(c->pgram0.p);
+    c->pgram0 = DevBuf<GramTask>{};
     dev_free(c->ptasks.p);
     dev_free(c->ptasks_slow.p);
     dev_free(c->pupd.p);
@@ -564,6 +570,10 @@ double predict_update_flops(int n, int nt) {
     return f;
 }
 
+// Gram values evaluated by the update tasks themselves (TileTask.gram) instead of written by the Gram launch and read
+// back: needs the coordinate image of a tile to fit the kernel's LDS ring.
+bool gram_fused(const dsmgp_ctx* c) { return c->fuse_gram && c->D <= GRAM_FUSE_MAX_D; }
+
 // Step lists of the batched left-looking factorisation.  phase[0]: leaves factorised in full (and, with
 // `with_test`, the test rows of those leaves and of the COPY leaves that alias them); phase[1]: PREFIX leaves.
 // with_test: the rows of K_tn (Vt) of every leaf are appended below its factor and advance through the same
@@ -572,6 +582,7 @@ double predict_update_flops(int n, int nt) {
 int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops) {
     const int L = c->L;
     alg_flops = 0.0;
+    const bool fused = gram_fused(c);
     UpdateSplitter split[2];
     for (int ph = 0; ph < 2; ++ph) {
         StepLists& S = phase[ph];
@@ -625,6 +636,15 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             u.mrows = tile_mrows(lf.n - i * TB);
                             u.sym = (i == k) ? 1 : 0;   // diagonal tile: A == B, lower blocks only
                             nsym += (size_t)u.sym;
+                            if (fused) {
+                                u.gram = 1 | (i == k ? 2 : 0);
+                                u.kid = lf.kid;
+                                u.gxa = d.Xg + (size_t)i * TB;
+                                u.gxb = d.Xg + (size_t)k * TB;
+                                u.glda = u.gldb = ld;
+                                u.gna = std::max(0, std::min(TB, lf.n - i * TB));
+                                u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                            }
                             tiles.push_back(u);
                         }
                         if (i > k) {
@@ -676,6 +696,16 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             u.k1 = k * TB;
                             u.update = 1;
                             u.mrows = tile_mrows(lf.nt - ti * TB);
+                            if (fused) {
+                                u.gram = 1;
+                                u.kid = lf.kid;
+                                u.gxa = d.Xtg + (size_t)ti * TB;
+                                u.gxb = d.Xg + (size_t)k * TB;
+                                u.glda = lf.ntpad;
+                                u.gldb = ld;
+                                u.gna = std::max(0, std::min(TB, lf.nt - ti * TB));
+                                u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                            }
                             tiles.push_back(u);
                         }
                         TileTask s{};
@@ -830,14 +860,16 @@ int build_plan(dsmgp_ctx* c) {
         HIPCHK(c, hipGetLastError());
     }
 
-    // Gram tasks: lower tiles of every owner
+    // Gram tasks: lower tiles of every owner; with the Gram fused into the update tasks only the tiles that have none --
+    // block column 0 (a PREFIX leaf: below the blocks it copies from its source; the copied blocks need no Gram at all)
     std::vector<GramTask> gram;
+    const bool fused = gram_fused(c);
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
         if (lf.owner != l) continue;
         const LeafDev& d = c->h_leaves[l];
-        for (int j = 0; j < lf.nb; ++j)
-            for (int i = j; i < lf.nb; ++i) {
+        for (int j = 0; j < (fused ? 1 : lf.nb); ++j)
+            for (int i = (fused ? std::max(j, lf.kb) : j); i < lf.nb; ++i) {
                 GramTask g{};
                 g.xa = d.Xg + (size_t)i * TB;
                 g.xb = d.Xg + (size_t)j * TB;
@@ -940,15 +972,15 @@ int build_plan(dsmgp_ctx* c) {
 void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */, bool pad = false) {
     if (pad) {   // launches with many padding-row tiles (small leaves): waves without data rows stay off the matrix pipe
         if (role == 1) tile_trsm_kernel<true><<<n, 256, 0, c->stream>>>(tasks);
-        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<n, 256, 0, c->stream>>>(tasks, nullptr);
-        else tile_gemm_kernel_v2<false, 0, true><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
+        else tile_gemm_kernel_v2<false, 0, true><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
         return;
     }
     // ROLE only names the instantiation: with per-launch timing switched off (dsmgp_set_profile(ctx, 0)) the same code
     // runs as <false, 2>, so that a profiler's per-kernel average of <false, 0> covers exactly the launches bench.py times
     if (role == 1) tile_trsm_kernel<false><<<n, 256, 0, c->stream>>>(tasks);   // B = inverse of a diagonal block, K = 128
-    else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr);
-    else tile_gemm_kernel_v2<false, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr);
+    else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
+    else tile_gemm_kernel_v2<false, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
 }
 
 // Two events bracketing a call on the context's stream; destroyed on every exit path.
@@ -1162,6 +1194,15 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
         c->ard_true_gradient = value != 0;
         return 0;
     }
+    if (option == DSMGP_OPT_FUSED_GRAM) {
+        if ((value != 0) != c->fuse_gram) {
+            HIPCHK(c, hipSetDevice(c->device));
+            free_plan(c);     // task lists of fit! (and, through the plan, of the resident test set) depend on it
+            free_test(c);
+        }
+        c->fuse_gram = value != 0;
+        return 0;
+    }
     return fail(c, DSMGP_E_ARG, "set_option: unknown option");
 }
 
@@ -1313,11 +1354,12 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     c->vt_valid = false;
     if (joint && c->acc_count) HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
     // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98) [+ K_tn tiles]
-    if (c->gram.count) {
+    //    (fused into the update tasks: only the tiles of block column 0 are written here)
+    {
+        const DevBuf<GramTask>& tg = (joint && gram_fused(c)) ? c->pgram0 : c->pgram;
         pt.begin(0);
-        gram_tile_kernel<<<2 * (int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
-        if (joint && c->pgram.count)
-            gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
+        if (c->gram.count) gram_tile_kernel<<<2 * (int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
+        if (joint && tg.count) gram_tile_kernel<<<2 * (int)tg.count, 256, 0, c->stream>>>(tg.p, c->d_kp, c->D);
         pt.end();
     }
     // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101); w = y - m rides along
@@ -1576,6 +1618,18 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (int rc = dev_upload(c, c->pred, U.red)) return rc;
     if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
     if (int rc = dev_upload(c, c->pgram, pg)) return rc;
+    {
+        std::vector<GramTask> pg0;      // the tasks of block column 0, in the order pg was filled above
+        size_t q = 0;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.nt == 0) continue;
+            for (int ti = 0; ti < lf.ntpad / TB; ++ti)
+                for (int j = 0; j < lf.nb; ++j, ++q)
+                    if (j == 0) pg0.push_back(pg[q]);
+        }
+        if (int rc = dev_upload(c, c->pgram0, pg0)) return rc;
+    }
     if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
     if (int rc = dev_upload(c, c->ptasks_slow, ptk_slow)) return rc;
     // the same test rows as riders of the factorisation launches (used by fit while this test set is resident)
@@ -2494,7 +2548,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     if (std::getenv("DSMGP_STAMPS")) {
         unsigned long long* st = nullptr;
         HIPCHK(c, hipMalloc(&st, (size_t)ntiles * 32 * sizeof(unsigned long long)));
-        tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st);
+        tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st, nullptr, 0);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<unsigned long long> hs((size_t)ntiles * 32);
         HIPCHK(c, hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

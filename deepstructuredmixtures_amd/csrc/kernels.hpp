@@ -213,7 +213,18 @@ struct TileTask {
     int mrows;          // rows of the tile that hold data (rows >= mrows are padding: zero rows of A, whose product is
                         //    zero); 0 = all 128.  Waves whose rows are all padding issue no MFMAs: a test-row tile of a
                         //    small leaf (44 routed rows padded to 128) keeps two of its four waves off the matrix pipe
+    // Gram matrix fused into the update (gram != 0): the tile is NOT read -- the kernel evaluates k(row, column) where
+    // it would have loaded C(row, column), with the operations of gram_half_tile in the same order (bit-identical
+    // values), and stores k - product (update = 1) or product - k (update = 0: first piece of a split tile, whose
+    // ReduceTask is `fresh`).  The Gram launch of fit! then covers only the tiles no update task writes (block column 0).
+    int gram;           // bit 0: on; bit 1: tile on the block diagonal of K_nn (noise + eps on the diagonal, identity padding)
+    int kid;            // kernel id of the leaf (index into the KParam table)
+    const double* gxa;  // coordinates of the tile's rows, column-major [glda x D], offset to the tile's first row
+    const double* gxb;  // ... of its columns
+    int glda, gldb;
+    int gna, gnb;       // valid rows / columns (<= 128)
 };
+constexpr int GRAM_FUSE_MAX_D = 32;   // the coordinates of 128 rows and 128 columns go through the ring's LDS
 
 // diagnostic builds (-DDSMGP_DIAG, tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -222,10 +233,134 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     return t;
 }
 
+// Coordinates of a fused-Gram tile -> LDS: sa[d * TB + r] = x_row(r)[d], sb likewise for the columns (zeros beyond the
+// valid counts).  The ring is free once the main loop has passed its last barrier.
+__device__ __forceinline__ void gram_stage_coords(const TileTask& tk, int D, double* sa, double* sb, bool cols) {
+    const int t = threadIdx.x;
+    for (int e = t; e < D * TB; e += 256) {
+        const int d = e >> 7, r = e & (TB - 1);
+        sa[e] = (r < tk.gna) ? tk.gxa[r + (size_t)d * tk.glda] : 0.0;
+        if (cols) sb[e] = (r < tk.gnb) ? tk.gxb[r + (size_t)d * tk.gldb] : 0.0;
+    }
+    __syncthreads();
+}
+
+// sum over the dimensions for one entry pair list: z[i][j] over rows a[i], columns b[j] (gram_half_tile's inner loop)
+template <int KIND, int NA, int NB>
+__device__ __forceinline__ void gram_accumulate(double (&z)[NA][NB], const double (&a)[NA], const double (&b)[NB], double nhd) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (KIND == 0) {
+                const double u = a[i] - b[j];
+                z[i][j] = fma(u, u, z[i][j]);
+            } else if (KIND == 1) {
+                const double u = a[i] - b[j];
+                z[i][j] += exp_nonpos((u * u) * nhd);
+            } else {
+                z[i][j] = fma(a[i], b[j], z[i][j]);
+            }
+        }
+}
+
+// kernel value from the accumulated sum, with the padding / diagonal rules of gram_half_tile (EDGE = false: a tile of
+// 128 valid rows and columns off the block diagonal -- the value as it is)
+template <int KIND, bool EDGE = true>
+__device__ __forceinline__ double gram_finish(double z, const KParam& p, int row, int col, int na, int nb, bool diag_tile) {
+    double kv;
+    if (KIND == 0) kv = p.sigma2 * exp_nonpos(z * p.nh0);
+    else if (KIND == 1) kv = p.sigma2 * z;
+    else kv = z * p.il2;
+    if (!EDGE) return kv;
+    const bool valid = (row < na) && (col < nb);
+    if (!valid) kv = 0.0;
+    if (diag_tile && row == col) kv = valid ? kv + (p.noise + 1e-8) : 1.0;
+    return kv;
+}
+
+// Full tile, accumulator layout of gemm_mainloop_v2: lane rows wr*64 + 16 rn + l15 (4), columns wc*64 + 16 cm + l4 + 4 r
+// (16), one cm (16 entries) at a time.
+template <int KIND, bool EDGE>
+__device__ __forceinline__ void gram_tile_epilogue(const TileTask& tk, const KParam& p, int D, d4 (&acc)[4][4], double* sa,
+                                                   double* sb) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
+    gram_stage_coords(tk, D, sa, sb, true);
+    const unsigned lofs = (unsigned)(wr * 64 + l15) + (unsigned)(wc * 64 + l4) * (unsigned)tk.ldc;
+    const size_t ldc = (size_t)tk.ldc;
+    const bool diag_tile = (tk.gram & 2) != 0;
+    const double* pa = sa + wr * 64 + l15;
+#pragma unroll          // (acc is indexed by cm: a rolled loop would put it in scratch memory)
+    for (int cm = 0; cm < 4; ++cm) {
+        const double* pb = sb + wc * 64 + 16 * cm + l4;
+        double z[4][4];
+#pragma unroll
+        for (int rn = 0; rn < 4; ++rn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[rn][r] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = pa[d * TB + 16 * i];
+                b[i] = pb[d * TB + 4 * i];
+            }
+            gram_accumulate<KIND, 4, 4>(z, a, b, (KIND == 1) ? p.nh[d] : 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cm + 4 * r) * ldc);
+            const int cidx = wc * 64 + 16 * cm + l4 + 4 * r;
+#pragma unroll
+            for (int rn = 0; rn < 4; ++rn) {
+                const double kv = gram_finish<KIND, EDGE>(z[rn][r], p, wr * 64 + 16 * rn + l15, cidx, tk.gna, tk.gnb, diag_tile);
+                col[lofs + 16 * rn] = (tk.update == 1) ? kv - acc[cm][rn][r] : acc[cm][rn][r] - kv;
+            }
+        }
+    }
+}
+
+// Rows 64..127 of a fused-Gram tile whose waves skipped the product (padding rows, gemm_staging_only): the Gram values
+// of padding rows -- zeros, ones on the diagonal of a K_nn diagonal tile.
+__device__ __forceinline__ void gram_pad_rows_store(const TileTask& tk) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
+    const bool diag_tile = (tk.gram & 2) != 0;
+#pragma unroll
+    for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cidx = wc * 64 + 16 * cm + l4 + 4 * r;
+            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)cidx * (size_t)tk.ldc);
+#pragma unroll
+            for (int rn = 0; rn < 4; ++rn) {
+                const int row = 64 + 16 * rn + l15;
+                col[row] = (diag_tile && row == cidx) ? 1.0 : 0.0;
+            }
+        }
+}
+
 // Epilogue shared by the tile kernels: register r of acc[cm][rn] is C(row = wr*64+16rn+l15, col = wc*64+16cm+l4+4r).
 // With tk.wi set (panel solve of the factorisation) the forward substitution y -> L^-1 y rides along:
 // w_i -= X z_k, summed per row over the 4 lanes l4, then over the two column halves through LDS (fixed order).
-__device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4], double* red /* >= 512 doubles of LDS */) {
+__device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4], double* red /* >= 512 doubles of LDS */,
+                                              const KParam* __restrict__ kp = nullptr, int D = 0, double* sb = nullptr) {
+    if (tk.gram != 0 && kp != nullptr) {      // Gram values instead of the tile read (update launches of fit!; no rider there)
+        const KParam p = kp[tk.kid];
+        const bool edge = tk.gna < TB || tk.gnb < TB || (tk.gram & 2) != 0;
+        if (p.kind == 0) {
+            if (edge) gram_tile_epilogue<0, true>(tk, p, D, acc, red, sb);
+            else gram_tile_epilogue<0, false>(tk, p, D, acc, red, sb);
+        } else if (p.kind == 1) {
+            if (edge) gram_tile_epilogue<1, true>(tk, p, D, acc, red, sb);
+            else gram_tile_epilogue<1, false>(tk, p, D, acc, red, sb);
+        } else {
+            if (edge) gram_tile_epilogue<2, true>(tk, p, D, acc, red, sb);
+            else gram_tile_epilogue<2, false>(tk, p, D, acc, red, sb);
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w & 1, wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
     // element (cm, rn, r) of this lane sits at C[lofs + 16 rn + (16 cm + 4 r) ldc]: uniform column base + 32-bit lane
@@ -597,18 +732,83 @@ __device__ __forceinline__ void syrk_epilogue(const TileTask& tk, d4 (&acc)[9], 
     }
 }
 
-__device__ __forceinline__ void tile_syrk_body(const TileTask& tk, double (*sA)[KC2 * LDP]) {
+// The same with the Gram values in place of the tile read (TileTask.gram; rows and columns of a diagonal tile are the
+// same 128 points: one coordinate image).
+template <int SHAPE, int KIND>
+__device__ __forceinline__ void syrk_gram_epilogue(const TileTask& tk, const KParam& p, int D, d4 (&acc)[9], const int (&blk)[6],
+                                                   const double* sa) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const size_t ldc = (size_t)tk.ldc;
+    const bool diag_tile = (tk.gram & 2) != 0;
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {
+        int rb[3], cb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (SHAPE == 0) {
+                rb[j] = blk[g3];
+                cb[j] = blk[3 + j];
+            } else {
+                rb[j] = blk[2 * g3 + (j > 0 ? 1 : 0)];
+                cb[j] = blk[2 * g3 + (j > 1 ? 1 : 0)];
+            }
+        }
+        double z[3][1][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[j][0][r] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double nhd = (KIND == 1) ? p.nh[d] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double a[1], b[4];
+                a[0] = sa[d * TB + 16 * rb[j] + l15];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = sa[d * TB + 16 * cb[j] + l4 + 4 * r];
+                gram_accumulate<KIND, 1, 4>(z[j], a, b, nhd);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rb[j] + l15, col = 16 * cb[j] + l4 + 4 * r;
+                const double kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, diag_tile);
+                const double v = acc[3 * g3 + j][r];
+                AS_GLOBAL_F64(tk.C)[(size_t)row + (size_t)col * ldc] = (tk.update == 1) ? kv - v : v - kv;
+            }
+    }
+}
+
+template <int SHAPE>
+__device__ __forceinline__ void syrk_finish(const TileTask& tk, d4 (&acc)[9], const int (&blk)[6], double* sa,
+                                            const KParam* __restrict__ kp, int D) {
+    if (tk.gram != 0 && kp != nullptr) {
+        const KParam p = kp[tk.kid];
+        gram_stage_coords(tk, D, sa, nullptr, false);
+        if (p.kind == 0) syrk_gram_epilogue<SHAPE, 0>(tk, p, D, acc, blk, sa);
+        else if (p.kind == 1) syrk_gram_epilogue<SHAPE, 1>(tk, p, D, acc, blk, sa);
+        else syrk_gram_epilogue<SHAPE, 2>(tk, p, D, acc, blk, sa);
+    } else {
+        syrk_epilogue<SHAPE>(tk, acc, blk);
+    }
+}
+
+__device__ __forceinline__ void tile_syrk_body(const TileTask& tk, double (*sA)[KC2 * LDP], const KParam* __restrict__ kp = nullptr,
+                                               int D = 0) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     d4 acc[9];
     if (w == 3) {
         const int blk[6] = {0, 1, 3, 4, 6, 7};
         syrk_mainloop<1>(tk, acc, sA, blk);
-        syrk_epilogue<1>(tk, acc, blk);
+        syrk_finish<1>(tk, acc, blk, &sA[0][0], kp, D);
     } else {
         const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
         const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
         syrk_mainloop<0>(tk, acc, sA, blk);
-        syrk_epilogue<0>(tk, acc, blk);
+        syrk_finish<0>(tk, acc, blk, &sA[0][0], kp, D);
     }
 }
 
@@ -674,24 +874,30 @@ __device__ __forceinline__ void gemm_staging_only(const TileTask& tk, double (*s
 // check is compiled out (it costs the other launches ~0.3 % through the register allocation of the main path).
 template <bool STAMP, int ROLE = 0, bool PAD = false>
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
-                                                              unsigned long long* __restrict__ stamps) {
+                                                              unsigned long long* __restrict__ stamps,
+                                                              const KParam* __restrict__ kp, int D) {
     __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
     __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
+    static_assert(GRAM_FUSE_MAX_D * TB <= NRING * KC2 * LDP, "coordinate image of a fused-Gram tile must fit the ring");
     unsigned long long r0 = 0;
     if (STAMP) r0 = __builtin_amdgcn_s_memrealtime();
     const TileTask tk = tasks[blockIdx.x];
     if (tk.sym) {       // diagonal tile of the factorisation: lower blocks only (workgroup-uniform branch)
-        tile_syrk_body(tk, sA);
+        tile_syrk_body(tk, sA, kp, D);
         return;
     }
     if (PAD && !STAMP && tk.update == 1 && tk.mrows != 0 && tk.wi == nullptr &&
         ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) * 64 >= tk.mrows)) {
         gemm_staging_only(tk, sA, sB);   // this wave's rows are padding: C - 0
+        if (tk.gram != 0) {              // ... and with the Gram fused, C's padding rows are this wave's to write, after
+            gram_stage_coords(tk, D, &sA[0][0], &sB[0][0], true);   // its share of the coordinate staging of the other two
+            gram_pad_rows_store(tk);
+        }
         return;
     }
     d4 acc[4][4];
     gemm_mainloop_v2<STAMP>(tk, acc, sA, sB, stamps);
-    tile_epilogue(tk, acc, &sA[0][0]);
+    tile_epilogue(tk, acc, &sA[0][0], kp, D, &sB[0][0]);
     if (STAMP && (threadIdx.x & 63) == 0) {
         unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
         s[6] = r0;                                    // kernel entry / exit of this wave (100 MHz wall ticks)
@@ -1052,6 +1258,7 @@ struct ReduceTask {
     const double* slabs;   // nsplit consecutive 128x128 slabs, ld 128
     int ldc;
     int nsplit;
+    int fresh;             // 1: the tile is not read (C = -(slab_0 + ...)): slab 0 already holds product - Gram value
 };
 
 // REDUCE_WGS workgroups per tile (16 columns each); a thread owns two rows of four columns and keeps the loads of
@@ -1073,7 +1280,7 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(const ReduceTask* __re
         for (int i = 0; i < 4; ++i) s[i] += sl[((size_t)q * TB * TB + (size_t)(4 * i) * TB) >> 1];
     d2 cv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cv[i] = *reinterpret_cast<const d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc);
+    for (int i = 0; i < 4; ++i) cv[i] = tk.fresh ? d2{0.0, 0.0} : *reinterpret_cast<const d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc);
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc) = cv[i] - s[i];
 }

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 N_TIMINGS = 18
 AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
 OPT_ARD_LENGTHSCALE_GRADIENT = 1
+OPT_FUSED_GRAM = 2
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
 
@@ -243,7 +244,7 @@ class Context:
         return self.predict_fetch()
 
     def set_option(self, option, value):
-        """include/dsmgp_hip.h DSMGP_OPT_*; OPT_ARD_LENGTHSCALE_GRADIENT = 1."""
+        """include/dsmgp_hip.h DSMGP_OPT_*: OPT_ARD_LENGTHSCALE_GRADIENT = 1, OPT_FUSED_GRAM = 2."""
         self._chk(self.lib.dsmgp_set_option(self.h, int(option), int(value)))
 
     def gradients(self, stride):

@@ -142,6 +142,11 @@ int dsmgp_gradients(dsmgp_ctx* ctx, double* grad_out, int32_t stride);
  * log-marginal, dl_d = 0.5 tr((alpha alpha^T - K_y^-1) dK/dlog l_d) with dK/dlog l_d = sigma^2 exp(-u_d^2/2l_d^2) u_d^2/l_d^2
  * of the additive kernel (no extra factor sigma; costs the contraction pass, n^3/3 flops per leaf; D <= 35). */
 #define DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT 1
+/* DSMGP_OPT_FUSED_GRAM: 1 (default) = the update tasks of fit! evaluate the kernel function for their tile themselves
+ * (same operations as the Gram launch, bit-identical values) instead of reading what a Gram launch wrote, which then
+ * covers block column 0 only (D <= 32; above that the option has no effect); 0 = every lower tile of K_y goes through
+ * memory first.  Changing it discards the leaf plan and a registered test set: set it before dsmgp_set_test. */
+#define DSMGP_OPT_FUSED_GRAM 2
 int dsmgp_set_option(dsmgp_ctx* ctx, int32_t option, int32_t value);
 
 /* ---- inspection ------------------------------------------------------------------------------- */

@@ -1112,3 +1112,58 @@ def test_bench_train_mode_line():
     assert dev["grad_inverse"] > 0 and dev["grad_contraction"] > 0 and dev["total_fit"] > 0
     assert 0 < j["roofline"]["frac"] < 1 and 0 < j["roofline_inverse"]["frac"] < 1
     assert len(j["mll_history"]) == 3 and j["mll_history"][-1] > j["mll_history"][0]
+
+
+@pytest.mark.gpu
+def test_gram_fused_into_the_update_tasks_equals_the_gram_launch():
+    """DSMGP_OPT_FUSED_GRAM (default on): the update tasks evaluate the kernel function for their tile with the operations
+    of the Gram launch in the same order, so a factor whose tiles were not split along K comes out bit for bit the same
+    as with every tile written by the Gram launch first; split tiles sum `product - Gram` instead of `Gram - product`
+    (rounding only).  All three kernel kinds, COPY / PREFIX leaves, test rows riding along, padding-row tiles."""
+    X, y, Xt = regression_data(6000, 4, n_test=500, seed=4321)
+    cases = [lambda **kw: dsm.buildDSMGP(X, y, 3, 4, M=120, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=8, **kw),
+             lambda **kw: dsm.buildPoE(X, y, 4, M=700, kernel=dsm.ArdSE(np.log([0.3, 0.4, 0.5, 0.6]), 0.0), logNoise=np.log(0.2),
+                                       meanFun=dsm.ConstMean(0.1), seed=8, **kw),
+             lambda **kw: dsm.buildDSMGP(X, y, 2, 3, M=400, D=1, kernel=[dsm.IsoSE(np.log(0.4), 0.0), dsm.IsoLinear(np.log(2.0))],
+                                         logNoise=np.log(0.3), seed=5, **kw),
+             lambda **kw: dsm.buildDSMGP(X[:3000], y[:3000], 2, 5, M=8, D=4, kernel=dsm.IsoSE(np.log(0.3), 0.0),
+                                         logNoise=np.log(0.1), seed=9, **kw)]
+    for make in cases:
+        res = []
+        for fused in (1, 0):
+            m = make(fit_now=False)
+            m.ctx.set_option(hipabi.OPT_FUSED_GRAM, fused)
+            m.ctx.set_profile(True)
+            dsm.resident_test(m, Xt)
+            dsm.fit(m)
+            t = m.ctx.timings()
+            mu, var = dsm.predict(m, Xt)
+            big = int(np.argmax([lf.nobs for lf in m.leaves]))
+            F, alpha = m.ctx.download_factor(big, m.leaves[big].nobs)
+            res.append((m.leaf_mll.copy(), mu, var, np.tril(F), alpha, t["gram"], m.share_op.copy()))
+            assert np.all(m.leaf_info == 0)
+        (ml1, mu1, v1, F1, a1, g1, op1), (ml0, mu0, v0, F0, a0, g0, op0) = res
+        assert np.array_equal(op1, op0)
+        assert np.allclose(ml1, ml0, rtol=1e-12, atol=1e-9)
+        assert np.allclose(mu1, mu0, rtol=1e-10, atol=1e-11) and np.allclose(v1, v0, rtol=1e-9, atol=1e-12)
+        assert np.allclose(F1, F0, rtol=1e-10, atol=1e-12) and np.allclose(a1, a0, rtol=1e-8, atol=1e-10)
+        if max(lf.nobs for lf in m.leaves) > 1024:
+            assert g1 < 0.8 * g0            # the Gram launch shrank to block column 0 (leaves of 9+ blocks: visible in its time)
+    # a single GP of 8 blocks, one leaf per launch: every update launch has fewer tiles than CUs -> all split; and one
+    # of 3 blocks next to it whose launches are not split on their own
+    Xs, ys, _ = regression_data(1000, 3, n_test=10, seed=99)
+    out = []
+    for fused in (1, 0):
+        c = hipabi.Context(0)
+        c.set_option(hipabi.OPT_FUSED_GRAM, fused)
+        c.set_train(Xs, ys)
+        c.set_leaves(np.array([0, 1000]), np.arange(1000), [0], [float(ys.mean())])
+        c.set_hyper(0, 0, [np.log(0.5), 0.0, np.log(0.2)])
+        mll, info, _ = c.fit()
+        F, alpha = c.download_factor(0, 1000)
+        out.append((mll[0], np.tril(F), alpha))
+        assert info[0] == 0
+    assert abs(out[0][0] - out[1][0]) <= 1e-12 * abs(out[1][0])
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-11, atol=1e-13)
+    Ky = out[1][1] @ out[1][1].T
+    assert np.linalg.norm(out[0][1] @ out[0][1].T - Ky) <= 1e-14 * np.linalg.norm(Ky)
