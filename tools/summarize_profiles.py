@@ -56,7 +56,7 @@ write = sum(float(r["Counter_Value"]) for r in wu) * 1024
 res = {"kernel": "tile_gemm_kernel_v2<false, 0, false>: update launches of the last fit (test rows riding along)", "launches": len(fu),
        "fetch_bytes_total": fetch, "write_bytes_total": write, "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)),
        "note": "FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024 over the update launches of one fit; separate --pmc passes of "
-               "`python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-profile` (tools/profile_round.sh)"}
+               "`python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline` (tools/profile_round.sh)"}
 json.dump(res, open(f"profiles/{tag}_update_kernel_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 for k, v in derived.items():
