@@ -1167,3 +1167,32 @@ def test_gram_fused_into_the_update_tasks_equals_the_gram_launch():
     assert np.allclose(out[0][1], out[1][1], rtol=1e-11, atol=1e-13)
     Ky = out[1][1] @ out[1][1].T
     assert np.linalg.norm(out[0][1] @ out[0][1].T - Ky) <= 1e-14 * np.linalg.norm(Ky)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,kind", [(1, 0), (17, 0), (32, 0), (33, 0), (40, 1), (32, 1), (31, 2), (48, 2)])
+def test_input_dimension_around_the_fused_gram_limit(ctx, D, kind):
+    """The update tasks stage the coordinates of 128 rows and 128 columns through the ring's LDS up to D = 32
+    (GRAM_FUSE_MAX_D); above that fit! falls back to the Gram launch for every tile.  Both sides of the limit, every
+    kernel kind, a ragged leaf of 6 blocks with test rows riding along, against the oracle."""
+    n, nt = 700, 150
+    X = uniform(400 + D, 0, n * D).reshape((n, D), order="F")
+    y = np.sin(4 * X[:, 0]) + 0.1 * normal(401 + D, 0, n)
+    Xt = uniform(402 + D, 0, nt * D).reshape((nt, D), order="F")
+    s = np.sqrt(D)                      # keep the kernel values away from 0 and 1 as D grows
+    h = {0: [np.log(0.4 * s), 0.0], 1: list(np.log(np.linspace(0.3, 0.8, D))) + [0.1], 2: [np.log(0.9 * s), 0.0]}[kind]
+    logNoise, mean = np.log(0.1), float(np.mean(y))
+    ctx.set_train(X, y)
+    ctx.set_leaves([0, n], np.arange(n), [0], [mean])
+    ctx.set_hyper(0, kind, np.concatenate([h, [logNoise]]))
+    ctx.set_test(Xt, [0, nt], np.arange(nt))
+    mll, info, _ = ctx.fit()
+    g = ogp.GaussianProcess(X, y, mean, ogp.make_kernel(kind, h), logNoise, exact_dist=True).update_cholesky()
+    assert info[0] == 0 and g.info == 0
+    assert abs(mll[0] - g.mll()) <= RTOL * max(1.0, abs(g.mll()))
+    F, alpha = ctx.download_factor(0, n)
+    assert np.max(np.abs(F - g.L())) <= 1e-9 * np.max(np.abs(g.L()))
+    ctx.predict_run()
+    mu, var = ctx.predict_fetch()
+    mo, vo = g.prediction(Xt)
+    assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9) and np.allclose(var, vo, rtol=RTOL, atol=1e-10)
