@@ -466,6 +466,11 @@ class MultiContext:
         for s in self.subs:
             s.set_joint(on)
 
+    def set_option(self, option, value):
+        for s in self.subs:
+            s.set_option(option, value)
+        self._test_dirty = self._test is not None     # OPT_FUSED_GRAM drops a registered test set with the plan
+
     def set_profile(self, on):
         for s in self.subs:
             s.set_profile(on)
@@ -722,6 +727,10 @@ class StreamingContext:
 
     def set_joint(self, on):
         pass                           # the test rows always ride along here: factors do not outlive their group
+
+    def set_option(self, option, value):
+        self.ctx.set_option(option, value)   # every group registers its leaves and test rows again anyway
+        self._res = None
 
     def set_profile(self, on):
         self.ctx.set_profile(on)
