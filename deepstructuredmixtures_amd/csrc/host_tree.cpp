@@ -14,6 +14,7 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
 
 namespace {
 // Worker threads of the host routines, one per allowed CPU at most, each pinned to its own CPU: left alone, the
@@ -40,13 +41,16 @@ void run_spread(int nthr, F&& work) {
     }
     std::vector<int> cpus;
     allowed_cpus(&cpus);
+    // several processes of one node (one per GPU) share an affinity mask: each takes its own group of CPUs
+    const size_t groups = std::max<size_t>(1, cpus.size() / (size_t)nthr);
+    const size_t first = ((size_t)getpid() % groups) * (size_t)nthr;
     std::vector<std::thread> th;
     for (int t = 0; t < nthr; ++t) {
         th.emplace_back(work, t);
         if ((int)cpus.size() >= nthr) {
             cpu_set_t one;
             CPU_ZERO(&one);
-            CPU_SET(cpus[(size_t)t], &one);
+            CPU_SET(cpus[first + (size_t)t], &one);
             (void)pthread_setaffinity_np(th.back().native_handle(), sizeof(one), &one);
         }
     }
