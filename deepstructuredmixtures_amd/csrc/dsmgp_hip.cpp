@@ -145,7 +145,8 @@ struct UpdateSplitter {
             r.C = tiles[i].C;
             r.ldc = tiles[i].ldc;
             r.nsplit = S;
-            r.fresh = tiles[i].gram != 0 ? 1 : 0;   // piece 0 stores product - Gram value: nothing to read from the tile
+            // piece 0 stores product - Gram value, or the tile is defined as -product: nothing to read from it
+            r.fresh = (tiles[i].gram != 0 || tiles[i].update == 2) ? 1 : 0;
             red.push_back(r);
             red_slab.push_back((int64_t)(first + (i - from) * S));
         }
@@ -1137,7 +1138,7 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             c->ncu = prop.multiProcessorCount;
     }
-#ifdef DSMGP_DIAG   // scheduling knobs of the diagnostic build (tools/sweep_env.sh); the product build reads no tuning variables
+#ifdef DSMGP_DIAG   // scheduling knobs of the diagnostic build (DSMGP_XCD, DSMGP_TAIL_SPLIT, DSMGP_TAIL_ROUNDS); the product build reads no tuning variables
     if (const char* s = std::getenv("DSMGP_XCD")) c->xcd_order = std::atoi(s) != 0;
     if (const char* s = std::getenv("DSMGP_TAIL_SPLIT")) c->tail_split = std::max(1, std::atoi(s));
     if (const char* s = std::getenv("DSMGP_TAIL_ROUNDS")) c->tail_rounds = std::max(0, std::atoi(s));
@@ -1924,8 +1925,8 @@ int build_grad_plan(dsmgp_ctx* c) {
                 u.lda = u.ldb = u.ldc = lf.npad;
                 u.k0 = t * TB;
                 u.k1 = k * TB;
-                u.update = 1;            // Xt was zero-filled: 0 - product
-                tiles.push_back(u);
+                u.update = 2;            // the block is defined here: -product, nothing to read (Xt needs no zero fill:
+                tiles.push_back(u);      //   every later task reads row tile t from column 128 t on only)
                 depth += u.k1 - u.k0;
                 TileTask s{};
                 s.A = tile;
@@ -2045,8 +2046,7 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     EventPair e_inv, e_dot;     // three spans: L^-T | contraction | traces and dots
     HIPCHK(c, e_inv.init());
     HIPCHK(c, e_dot.init());
-    // Xt = L^-T
-    HIPCHK(c, hipMemsetAsync(c->arenaX, 0, c->arenaX_count * sizeof(double), c->stream));
+    // Xt = L^-T (blocks left of the diagonal are never written and never read)
     if (c->gtrans.count) transpose_tile_kernel<<<(int)c->gtrans.count * 16, 256, 0, c->stream>>>(c->gtrans.p);
     for (int k = 1; k < c->gsteps; ++k) {
         const int nu = c->gupd_off[k + 1] - c->gupd_off[k];

@@ -207,7 +207,7 @@ struct TileTask {
     double* sq;         // test rows: running sum of squares of the solved row, sq += rowsumsq(X); else NULL
     int lda, ldb, ldc;
     int k0, k1;         // K range, multiples of 8
-    int update;         // 0 = store the product, 1 = C - product
+    int update;         // 0 = store the product, 1 = C - product, 2 = -product (C is not read)
     int sym;            // 1: diagonal tile of the factorisation, B == A (C -= A A^T): only the lower 16x16 blocks are
                         //    computed and written (tile_syrk_body); the strictly upper blocks of C are left alone
     int mrows;          // rows of the tile that hold data (rows >= mrows are padding: zero rows of A, whose product is
@@ -386,6 +386,15 @@ __device__ __forceinline__ void tile_epilogue(const TileTask& tk, d4 (&acc)[4][4
                 for (int rn = 0; rn < 4; ++rn) col[lofs + 16 * rn] = cv[rn][r] - acc[cm][rn][r];
             }
         }
+    } else if (tk.update == 2) {      // C = -product: the tile holds nothing yet (blocks of L^-T), no read
+#pragma unroll
+        for (int cm = 0; cm < 4; ++cm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cm + 4 * r) * ldc);
+#pragma unroll
+                for (int rn = 0; rn < 4; ++rn) col[lofs + 16 * rn] = -acc[cm][rn][r];
+            }
     } else {
 #pragma unroll
         for (int cm = 0; cm < 4; ++cm)
