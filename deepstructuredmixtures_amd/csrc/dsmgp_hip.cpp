@@ -196,6 +196,32 @@ struct UpdateSplitter {
         }
         max_slabs = std::max(max_slabs, slab);
     }
+    // A step whose tiles have every depth from 1 to `kblocks` blocks (the blocks of L^-T), listed leaf by leaf, deepest
+    // first.  Tasks are dispatched in list order, so the deepest tiles of the last leaves start when the launch is nearly
+    // over and the chip waits for them (15 % of a launch at k = 41).  Reordering by depth is not an option -- the tiles
+    // of a leaf must run together to share their B panel through L2 (passes over the leaves by depth class: 35 % slower)
+    // -- so the last two rounds' worth of tiles are cut along K into pieces of at most a quarter of the step's depth.
+    int ragged_rounds = 2, ragged_div = 4;
+    void add_step_ragged(const std::vector<TileTask>& tiles, int Kavg, int kblocks) {
+        const size_t T = tiles.size();
+        if (T < (size_t)((ragged_rounds + 2) * ncu) || kblocks < 8) {
+            add_step(tiles, Kavg);
+            return;
+        }
+        size_t slab = 0;
+        const size_t cut = T - (size_t)(ragged_rounds * ncu);
+        emit(tiles, 0, cut, 1, slab);
+        const int maxb = std::max(1, kblocks / ragged_div);
+        auto pieces = [&](const TileTask& u) { return std::max(1, ((u.k1 - u.k0) / TB + maxb - 1) / maxb); };
+        for (size_t i = cut; i < T;) {
+            const int S = pieces(tiles[i]);
+            size_t j = i + 1;
+            while (j < T && pieces(tiles[j]) == S) ++j;
+            emit(tiles, i, j, S, slab);
+            i = j;
+        }
+        max_slabs = std::max(max_slabs, slab);
+    }
     void bind(double* workspace) {
         for (size_t i = 0; i < upd.size(); ++i)
             if (upd_slab[i] >= 0) upd[i].C = workspace + (size_t)upd_slab[i] * TB * TB;
@@ -258,6 +284,7 @@ struct dsmgp_ctx {
     int ncu = 256;
     bool xcd_order = true;          // XCD-aware task order (speed only)
     int tail_split = 4, tail_rounds = 1;
+    int ragged_rounds = 2, ragged_div = 4;   // UpdateSplitter::add_step_ragged (launches of the gradient pass)
     std::vector<int> fwd_off, bwd_off;
     DevBuf<SolveTask> fwd, bwd;
     int solve_steps = 0;
@@ -1142,6 +1169,8 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     if (const char* s = std::getenv("DSMGP_XCD")) c->xcd_order = std::atoi(s) != 0;
     if (const char* s = std::getenv("DSMGP_TAIL_SPLIT")) c->tail_split = std::max(1, std::atoi(s));
     if (const char* s = std::getenv("DSMGP_TAIL_ROUNDS")) c->tail_rounds = std::max(0, std::atoi(s));
+    if (const char* s = std::getenv("DSMGP_RAGGED_ROUNDS")) c->ragged_rounds = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("DSMGP_RAGGED_DIV")) c->ragged_div = std::max(1, std::atoi(s));
 #endif
     const char* p = std::getenv("DSMGP_PROFILE");
     c->profile = p ? std::atoi(p) * 2 : 0;   // DSMGP_PROFILE=1 -> every category
@@ -1902,6 +1931,8 @@ int build_grad_plan(dsmgp_ctx* c) {
     U.xcd = c->xcd_order;
     U.tail_split = c->tail_split;
     U.tail_rounds = c->tail_rounds;
+    U.ragged_rounds = c->ragged_rounds;
+    U.ragged_div = c->ragged_div;
     std::vector<TileTask> trsm;
     c->gupd_off.assign(nsteps + 1, 0);
     c->gred_off.assign(nsteps + 1, 0);
@@ -1926,7 +1957,8 @@ int build_grad_plan(dsmgp_ctx* c) {
                 u.k0 = t * TB;
                 u.k1 = k * TB;
                 u.update = 2;            // the block is defined here: -product, nothing to read (Xt needs no zero fill:
-                tiles.push_back(u);      //   every later task reads row tile t from column 128 t on only)
+                u.rev = 1;               //   every later task reads row tile t from column 128 t on only)
+                tiles.push_back(u);
                 depth += u.k1 - u.k0;
                 TileTask s{};
                 s.A = tile;
@@ -1942,7 +1974,7 @@ int build_grad_plan(dsmgp_ctx* c) {
             }
         }
         const int Kavg = tiles.empty() ? 0 : (int)(depth / tiles.size()) / TB * TB;
-        U.add_step(tiles, std::max(TB, Kavg));
+        U.add_step_ragged(tiles, std::max(TB, Kavg), k);
     }
     c->gupd_off[0] = c->gred_off[0] = c->gtrsm_off[0] = 0;
     if (nsteps > 0) {

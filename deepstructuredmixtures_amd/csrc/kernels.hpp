@@ -217,6 +217,10 @@ struct TileTask {
     // it would have loaded C(row, column), with the operations of gram_half_tile in the same order (bit-identical
     // values), and stores k - product (update = 1) or product - k (update = 0: first piece of a split tile, whose
     // ReduceTask is `fresh`).  The Gram launch of fit! then covers only the tiles no update task writes (block column 0).
+    int rev;            // 1: the K range is streamed from its END (chunks k1-8, k1-16, ...).  Tiles that share a B panel
+                        //    but start at different columns (the blocks of L^-T: row tile t starts at column 128 t, all end
+                        //    at the step's column) then read the same chunks of it at the same time and share them through
+                        //    L2; streamed from their own first columns they never meet
     int gram;           // bit 0: on; bit 1: tile on the block diagonal of K_nn (noise + eps on the diagonal, identity padding)
     int kid;            // kernel id of the leaf (index into the KParam table)
     const double* gxa;  // coordinates of the tile's rows, column-major [glda x D], offset to the tile's first row
@@ -473,14 +477,18 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
 
     // staging: thread t moves column (t>>5) of the chunk, rows 2*(t&31) + 64j, j<2 (512 B per half wave)
     const int scol = t >> 5, srow = 2 * (t & 31);
-    const double* gA = tk.A + srow + (size_t)(tk.k0 + scol) * tk.lda;
-    const double* gB = tk.B + srow + (size_t)(tk.k0 + scol) * tk.ldb;
+    // chunk CH holds columns kfirst + CH * kstep .. + 7: ascending from k0, or (TileTask.rev) descending from k1 - 8
+    const int kfirst = tk.rev ? tk.k1 - KC2 : tk.k0;
+    const ptrdiff_t stepA = (tk.rev ? -(ptrdiff_t)KC2 : (ptrdiff_t)KC2) * tk.lda;
+    const ptrdiff_t stepB = (tk.rev ? -(ptrdiff_t)KC2 : (ptrdiff_t)KC2) * tk.ldb;
+    const double* gA = tk.A + srow + (size_t)(kfirst + scol) * tk.lda;
+    const double* gB = tk.B + srow + (size_t)(kfirst + scol) * tk.ldb;
     const int sOff = scol * LDP + srow;
     d2 ra0[2], rb0[2], ra1[2], rb1[2];
 
 #define GLOAD(RA, RB, CH)                                                                        \
     do {                                                                                         \
-        const size_t oa_ = (size_t)(CH) * KC2 * tk.lda, ob_ = (size_t)(CH) * KC2 * tk.ldb;       \
+        const ptrdiff_t oa_ = (ptrdiff_t)(CH) * stepA, ob_ = (ptrdiff_t)(CH) * stepB;            \
         RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
         RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                                    \
         RB[0] = *AS_GLOBAL_D2(gB + ob_);                                                         \
