@@ -764,10 +764,15 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             // diagonal tiles stay full tiles.
             if (nsym * 5 < tiles.size())
                 for (auto& u : tiles) u.sym = 0;
-            {   // padding-row tiles: worth the PAD instantiations of the kernels from a 10 % share on
-                size_t npad = 0;
+            {   // padding-row tiles: worth the PAD instantiations of the kernels from a 10 % share on (step 0 has no
+                // update launch: its panel solves decide)
+                size_t npad = 0, ntot = tiles.size();
                 for (const auto& u : tiles) npad += (u.mrows != 0 && u.mrows <= 64) ? 1 : 0;
-                S.pad[k] = (npad * 10 >= tiles.size() && tiles.size() >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
+                if (tiles.empty()) {
+                    ntot = trsm.size() - (size_t)S.trsm_off[k];
+                    for (size_t q = (size_t)S.trsm_off[k]; q < trsm.size(); ++q) npad += (trsm[q].mrows != 0 && trsm[q].mrows <= 64) ? 1 : 0;
+                }
+                S.pad[k] = (npad * 10 >= ntot && ntot >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
             }
             U.add_step(tiles, k * TB);
             S.step_tiles[k] = (int)tiles.size();
