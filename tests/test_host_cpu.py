@@ -523,3 +523,54 @@ def test_host_only_entry_points_reject_bad_arguments():
     with pytest.raises(hipabi.DsmgpError):
         hipabi.overlap_main(np.array([0, 2]), np.array([0, 99]), 10)   # observation index out of range
     assert hipabi.estimate_bytes([128], [0], 3) == (128 * 128 + 128 * 128 + 128 * 7) * 8
+
+
+def test_overlap_main_counter_widths_threads_and_observation_table():
+    """dsmgp_overlap_main counts each overlapping pair once, with 16-bit counters while every leaf is below 65,536
+    observations and 32-bit ones above; candidate tables of the worker threads are merged by (larger product, lower
+    index).  Both counter widths against a direct evaluation, ties included; and tree.obs_table returns the builder's
+    table itself (no copy) for leaves that are consecutive views of it, a concatenation otherwise."""
+    def direct(sets):
+        L = len(sets)
+        main, cm = np.zeros(L, np.int64), np.zeros(L, np.int64)
+        for j in range(L):
+            best = 0.0
+            for i in range(L):
+                if i == j:
+                    continue
+                c = len(sets[i] & sets[j])
+                if c == 0:
+                    continue
+                ni, nj = float(len(sets[i])), float(len(sets[j]))
+                prod = (1.0 - (ni - c) / ni) * (1.0 - (nj - c) / nj)
+                if prod > best:
+                    best, main[j], cm[j] = prod, i, c
+        return main, cm
+
+    rng = np.random.default_rng(12)
+    for N, sizes in ((5000, [2500, 2500, 1200, 1300, 5000, 700, 700, 40]), (70000, [70000, 35000, 35000, 66000, 300])):
+        lists = []
+        for q, n in enumerate(sizes):
+            if q == 1:
+                lists.append(np.arange(n))                       # two disjoint halves: equal products with leaf 0 ...
+            elif q == 2:
+                lists.append(np.arange(N - n, N))                # ... so the tie rule (lower index) decides
+            else:
+                lists.append(np.sort(rng.choice(N, size=n, replace=False)))
+        ptr = np.concatenate([[0], np.cumsum([len(v) for v in lists])])
+        main, cm = hipabi.overlap_main(ptr, np.concatenate(lists), N)
+        dm, dc = direct([set(v.tolist()) for v in lists])
+        assert np.array_equal(main, dm) and np.array_equal(cm, dc)
+    # observation table: zero-copy for the native builder's leaves, concatenation for anything else
+    X, y = _small_problem(1500, 2, seed=77)
+    m = dsm.buildDSMGP(X, y, 3, 4, M=30, kernel=dsm.IsoSE(0.0, 0.0), fit_now=False, seed=4)
+    ptr, idx = ptree.obs_table(m.leaves)
+    assert np.shares_memory(idx, m.leaves[0].obs) and np.array_equal(idx, np.concatenate([lf.obs for lf in m.leaves]))
+    assert np.array_equal(np.diff(ptr), [lf.nobs for lf in m.leaves])
+    sub = m.leaves[3:9]
+    p2, i2 = ptree.obs_table(sub)
+    assert np.shares_memory(i2, sub[0].obs) and np.array_equal(i2, np.concatenate([lf.obs for lf in sub]))
+    shuffled = [m.leaves[5], m.leaves[2], m.leaves[7]]
+    p3, i3 = ptree.obs_table(shuffled)
+    assert not np.shares_memory(i3, m.leaves[5].obs) and np.array_equal(i3, np.concatenate([lf.obs for lf in shuffled]))
+    assert ptree.obs_table([])[1].size == 0
