@@ -367,7 +367,8 @@ def main():
             traffic_source = f"profiles/{TRAFFIC_FILE} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along; <false, 0, true> "
+                "kernel": "tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along, each task "
+                          "evaluating the kernel function of its own tile; <false, 0, true> "
                           "in launches with >= 10 % padding-row tiles; "
                           "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel; the reduce "
                           "launches are timed apart: device_seconds_per_step.chol_reduce)",
