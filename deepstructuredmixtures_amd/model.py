@@ -326,11 +326,13 @@ def update_cholesky(gp):
 def prediction(gp, xtest):
     """`prediction(gp, xtest)` -> (mu, diag of Sigma) (`src/gaussianprocess.jl:110-137`; only the
     diagonal of Sigma is ever consumed, `src/common.jl:136,147`)."""
-    xt = np.asarray(xtest, dtype=np.float64)
+    xt = np.asfortranarray(xtest, dtype=np.float64)
     if xt.ndim == 1:
         xt = xt.reshape(-1, 1)
-    n = xt.shape[0]
-    mu, var = gp.model.ctx.predict_leaves(xt, np.array([0, n]), np.arange(n))
+    # registered like the test set of a tree model (cached by content): a loop of update_cholesky! + prediction on the same
+    # rows carries them through the factorisation launches from its second pass on, and prediction only finishes the moments
+    rc = _routing(gp.model, xt)
+    mu, var = _leaf_moments(gp.model, xt, rc)
     return mu, var
 
 

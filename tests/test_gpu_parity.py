@@ -1196,3 +1196,30 @@ def test_input_dimension_around_the_fused_gram_limit(ctx, D, kind):
     mu, var = ctx.predict_fetch()
     mo, vo = g.prediction(Xt)
     assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9) and np.allclose(var, vo, rtol=RTOL, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_single_gp_prediction_registers_its_rows_once():
+    """`prediction(gp, x)` (src/gaussianprocess.jl:110-137) on the host mirror keeps x registered (by content): the next
+    `update_cholesky!` carries those rows through its launches and `prediction` on the same rows only finishes the
+    moments; other rows are registered afresh.  Same numbers on every path, against the oracle."""
+    X, y, Xt = regression_data(1500, 3, n_test=200, seed=31)
+    h, ln = [np.log(0.4), 0.1], np.log(0.15)
+    gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(*h), logNoise=ln)
+    gp.model.ctx.set_profile(True)
+    dsm.update_cholesky(gp)
+    mu0, v0 = dsm.prediction(gp, Xt)                    # standalone sweep
+    assert gp.model.ctx.timings()["predict_trsm"] > 0
+    dsm.update_cholesky(gp)                             # Xt rides along
+    mu1, v1 = dsm.prediction(gp, Xt)
+    t = gp.model.ctx.timings()
+    assert t["predict_update"] == 0.0 and t["predict_trsm"] == 0.0
+    assert np.allclose(mu1, mu0, rtol=1e-11, atol=1e-12) and np.allclose(v1, v0, rtol=1e-10, atol=1e-13)
+    go = ogp.GaussianProcess(X, y, float(np.mean(y)), ogp.IsoSE(*h), ln, True).update_cholesky()
+    mo, vo = go.prediction(Xt)
+    assert np.allclose(mu1, mo, rtol=RTOL, atol=1e-9) and np.allclose(v1, vo, rtol=RTOL, atol=1e-10)
+    mu2, v2 = dsm.prediction(gp, Xt[:50])               # another test set: registered afresh
+    mo2, vo2 = go.prediction(Xt[:50])
+    assert np.allclose(mu2, mo2, rtol=RTOL, atol=1e-9) and np.allclose(v2, vo2, rtol=RTOL, atol=1e-10)
+    mu3, v3 = dsm.predict(gp, Xt[:50])                  # predict(gp, x) clamps the variance like the tree models
+    assert np.array_equal(mu3, mu2) and np.all(v3 > 0)
