@@ -204,14 +204,24 @@ struct UpdateSplitter {
     int ragged_rounds = 2, ragged_div = 4;
     void add_step_ragged(const std::vector<TileTask>& tiles, int Kavg, int kblocks) {
         const size_t T = tiles.size();
-        if (T < (size_t)((ragged_rounds + 2) * ncu) || kblocks < 8) {
+        if (kblocks < 8) {
             add_step(tiles, Kavg);
             return;
         }
         size_t slab = 0;
-        const size_t cut = T - (size_t)(ragged_rounds * ncu);
-        emit(tiles, 0, cut, 1, slab);
-        const int maxb = std::max(1, kblocks / ragged_div);
+        size_t cut = 0;
+        int maxb;
+        if (T < (size_t)((ragged_rounds + 2) * ncu)) {
+            // few tiles (the late steps: a handful of leaves, every depth): all of them in pieces of equal depth, about
+            // three pieces per workgroup slot of the chip
+            long W = 0;
+            for (const TileTask& u : tiles) W += (u.k1 - u.k0) / TB;
+            maxb = (int)std::min<long>(kblocks, std::max<long>(2, W / (long)(2 * ncu * 3)));
+        } else {
+            cut = T - (size_t)(ragged_rounds * ncu);
+            emit(tiles, 0, cut, 1, slab);
+            maxb = std::max(1, kblocks / ragged_div);
+        }
         auto pieces = [&](const TileTask& u) { return std::max(1, ((u.k1 - u.k0) / TB + maxb - 1) / maxb); };
         for (size_t i = cut; i < T;) {
             const int S = pieces(tiles[i]);
