@@ -98,6 +98,52 @@ void xcd_permute(std::vector<T>& a, std::vector<U>& b, size_t begin, size_t end,
     }
 }
 
+// The same for a launch whose tasks differ in depth (the contraction tiles of the gradient pass: one launch, depths from
+// 1 to nb blocks).  An XCD slot works through its share of the list on its own, so equal COUNTS per slot leave the slots
+// with unequal work and the launch waits for the slowest eighth of the chip.  Blocks of tasks that share operands
+// (`block_start`, natural order = deepest first) are dealt to the slot with the least work so far; the counts are then
+// evened out (the positions of a slot are x, x+8, ...: every slot needs n/8 tasks) by moving tasks from the ends of the
+// fuller slots, which are the shallowest.
+template <class T, class U>
+void xcd_deal_by_work(std::vector<T>& a, std::vector<U>& b, size_t begin, size_t end, const std::vector<size_t>& block_start,
+                      const std::vector<double>& work, bool enable) {   // block_start / work: relative to `begin`
+    const size_t n = end - begin;
+    if (!enable || n < 16) return;
+    std::vector<std::vector<size_t>> q(8);
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t bi = 0; bi + 1 < block_start.size(); ++bi) {
+        int x = 0;
+        for (int y = 1; y < 8; ++y)
+            if (load[y] < load[x]) x = y;
+        for (size_t i = block_start[bi]; i < block_start[bi + 1]; ++i) {
+            q[x].push_back(i);
+            load[x] += work[i];
+        }
+    }
+    std::vector<size_t> pool;
+    for (size_t x = 0; x < 8; ++x) {
+        const size_t target = n / 8 + (x < n % 8 ? 1 : 0);
+        while (q[x].size() > target) {
+            pool.push_back(q[x].back());
+            q[x].pop_back();
+        }
+    }
+    for (size_t x = 0; x < 8; ++x) {
+        const size_t target = n / 8 + (x < n % 8 ? 1 : 0);
+        while (q[x].size() < target) {
+            q[x].push_back(pool.back());
+            pool.pop_back();
+        }
+    }
+    const std::vector<T> ta(a.begin() + begin, a.begin() + end);
+    const std::vector<U> tb(b.begin() + begin, b.begin() + end);
+    for (size_t x = 0; x < 8; ++x)
+        for (size_t j = 0; j < q[x].size(); ++j) {
+            a[begin + x + 8 * j] = ta[q[x][j]];
+            b[begin + x + 8 * j] = tb[q[x][j]];
+        }
+}
+
 struct UpdateSplitter {
     int ncu = 256;
     bool xcd = true;
@@ -2009,6 +2055,7 @@ int build_grad_plan(dsmgp_ctx* c) {
     // listed row by row 55 TFLOP/s; sorted by depth across leaves, i.e. no sharing at all, 26).
     constexpr int GS = 4;
     std::vector<GradTask> gd;
+    std::vector<size_t> gblock;
     c->gdot_leaf.clear();
     c->grad_src.assign(L, -1);
     bool any_ard = false;
@@ -2026,7 +2073,8 @@ int build_grad_plan(dsmgp_ctx* c) {
             continue;
         }
         const LeafDev& d = c->h_leaves[l];
-        for (int ib = 0; ib < lf.nb; ib += GS)
+        for (int ib = 0; ib < lf.nb; ib += GS) {
+            gblock.push_back(gd.size());           // one block per (leaf, GS tile rows): these tasks share their A panels
             for (int jb = 0; jb <= ib; jb += GS)
                 for (int i = ib; i < std::min(ib + GS, lf.nb); ++i)
                     for (int j = jb; j < std::min(jb + GS, i + 1); ++j) {
@@ -2051,9 +2099,15 @@ int build_grad_plan(dsmgp_ctx* c) {
                         gd.push_back(g);
                         c->gdot_leaf.push_back(l);
                     }
+        }
     }
-    // neighbours in the list sit 8 apart in the launch: they run on one XCD and share its L2
-    xcd_permute(gd, c->gdot_leaf, 0, gd.size(), c->xcd_order);
+    // neighbours in the list sit 8 apart in the launch: they run on one XCD and share its L2; the XCD slots get equal work
+    {
+        gblock.push_back(gd.size());
+        std::vector<double> work(gd.size());
+        for (size_t i = 0; i < gd.size(); ++i) work[i] = (double)(gd[i].gemm.k1 - gd[i].gemm.k0) + 64.0;   // + per-task overhead
+        xcd_deal_by_work(gd, c->gdot_leaf, 0, gd.size(), gblock, work, c->xcd_order);
+    }
     if (int rc = dev_upload(c, c->gtrans, trans)) return rc;
     if (int rc = dev_upload(c, c->gfrob, frob)) return rc;
     if (int rc = dev_upload(c, c->gupd, U.upd)) return rc;
