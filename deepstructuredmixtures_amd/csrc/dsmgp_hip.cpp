@@ -409,6 +409,7 @@ struct dsmgp_ctx {
     double timings[DSMGP_N_TIMINGS] = {0};
     std::vector<hipEvent_t> event_pool;   // PhaseTimer's events, reused across calls
     double alg_flops_update = 0.0;  // algorithmic flops of the Cholesky update launches
+    bool phase_ready = false;       // `phase` (fit! without resident test rows) has been built for the current plan
     int n_update_launches = 0;
 };
 
@@ -510,6 +511,7 @@ void free_plan(dsmgp_ctx* c) {
     dev_free(c->bwd.p);
     free_grad(c);
     c->plan_ready = false;
+    c->phase_ready = false;
     c->fitted = false;
 }
 
@@ -663,7 +665,8 @@ bool gram_fused(const dsmgp_ctx* c) { return c->fuse_gram && c->D <= GRAM_FUSE_M
 // with_test: the rows of K_tn (Vt) of every leaf are appended below its factor and advance through the same
 // update / panel-solve launches -- prediction's triangular solves (src/gaussianprocess.jl:120) cost no launches
 // of their own when the test set is resident at fit time.
-int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops) {
+int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops,
+                       bool slab_outside_pool = false) {
     const int L = c->L;
     alg_flops = 0.0;
     const bool fused = gram_fused(c);
@@ -843,8 +846,10 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
     {
         const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
         arena_put(c, slab_ws);
-        if (slabs)
-            if (int rc = arena_get(c, slab_ws, slabs * TB * TB)) return rc;
+        if (slabs) {
+            if (slab_outside_pool && c->pool_base) HIPCHK(c, hipMalloc(&slab_ws, slabs * TB * TB * sizeof(double)));
+            else if (int rc = arena_get(c, slab_ws, slabs * TB * TB)) return rc;
+        }
         for (int ph = 0; ph < 2; ++ph) {
             split[ph].bind(slab_ws);
             if (int rc = dev_upload(c, phase[ph].upd, split[ph].upd)) return rc;
@@ -974,11 +979,10 @@ int build_plan(dsmgp_ctx* c) {
     }
     if (int rc = dev_upload(c, c->gram, gram)) return rc;
 
-    // factorisation phases (train rows only; set_test adds a second set with the test rows riding along)
-    {
-        HostLog hl("build_plan: factor steps");
-        if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update)) return rc;
-    }
+    // The step lists of the factorisation are built on first use: those for the train rows alone by the first fit! without a
+    // resident test set (ensure_phase), those with the test rows riding along by dsmgp_set_test -- a context that only ever
+    // fits with its test set resident (the streaming mode: 20 million tile tasks over the groups of config 5) builds one set.
+    c->phase_ready = false;
 
     // solve sweeps.  Forward: only leaves whose factor came from elsewhere (COPY, PREFIX) -- leaves factorised
     // in full get z = L^-1 y from the factorisation itself (chol_diag_kernel + the panel-solve epilogue).
@@ -1055,6 +1059,17 @@ int build_plan(dsmgp_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->plan_ready = true;
     c->pool_mark_plan = c->pool_top;
+    return 0;
+}
+
+// Step lists of a fit! without resident test rows.  Built after the plan, possibly after the test arenas: with a device pool
+// its split-K workspace is allocated outside the pool (the pool is a stack: plan < test < gradients).
+int ensure_phase(dsmgp_ctx* c) {
+    if (c->phase_ready) return 0;
+    HostLog hl("ensure_phase: factor steps");
+    if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update, true)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->phase_ready = true;
     return 0;
 }
 
@@ -1426,6 +1441,10 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     if (!c->plan_ready)
         if (int rc = build_plan(c)) return rc;
     if (int rc = upload_hyper(c)) return rc;
+    // With a resident test set the rows of K_tn ride through the same launches (build_factor_steps).
+    const bool joint = c->joint && c->test_ready && c->joint_ready;
+    if (!joint)
+        if (int rc = ensure_phase(c)) return rc;
     const int L = c->L;
     for (int i = 0; i < 6; ++i) c->timings[i] = 0.0;
     c->timings[11] = 0.0;
@@ -1439,8 +1458,6 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     HIPCHK(c, hipEventRecord(t0, c->stream));
 
     HIPCHK(c, hipMemsetAsync(c->d_info, 0, L * sizeof(int), c->stream));
-    // With a resident test set the rows of K_tn ride through the same launches (build_factor_steps).
-    const bool joint = c->joint && c->test_ready && c->joint_ready;
     StepLists* phases = joint ? c->phaseJ : c->phase;
     c->vt_valid = false;
     if (joint && c->acc_count) HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
