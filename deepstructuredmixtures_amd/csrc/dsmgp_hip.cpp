@@ -835,6 +835,12 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             }
             U.add_step(tiles, k * TB);
             S.step_tiles[k] = (int)tiles.size();
+            {   // panel solves of a leaf read the same Dinv_k: keep them on one XCD (small leaves have 3-4 of them per
+                // step; dealt round-robin every one of them fetched the 128 KB block from HBM on its own: the depth-4
+                // model's panel-solve launches fetched 2.6x their tile bytes)
+                std::vector<int> unused(trsm.size());
+                xcd_permute(trsm, unused, (size_t)S.trsm_off[k], trsm.size(), c->xcd_order);
+            }
         }
         S.upd_off[nsteps] = (int)U.upd.size();
         S.red_off[nsteps] = (int)U.red.size();
