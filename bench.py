@@ -6,8 +6,9 @@
 
 Workload (BASELINE.json configs[3], fits one GPU): buildDSMGP K=4 splits, V=3 sum children, M=200,
 N=100k, D=8, IsoSE, tree depth 2 (reference default) -> 144 leaf GPs, n ~ 1.5k-14k; n_t = N/10 test rows.
-One step = fit! (Gram assembly + batched Cholesky + alpha + per-leaf mll) + update! + predict
-(K_tn assembly, triangular solves, predictive moments, sum/product aggregation), inputs resident in HBM.
+One step = fit! (Gram assembly + batched Cholesky + forward substitution z = L^-1 (y - m) + per-leaf mll from z.z) +
+update! + predict (K_tn assembly, triangular solves, predictive moments from V^T z, sum/product aggregation), inputs
+resident in HBM; alpha = L^-T z is materialised on first use (gradients, download), not by fit!.
 With N > 1 the SAME model is sharded leaf-wise over the ranks (strong scaling); the only exchange is
 an all-gather of per-leaf log-marginals after fit! and of the aggregation's partial sums (3 n_t doubles per rank) after
 predict (RCCL over xGMI).  Rank 0 prints one JSON line.
@@ -408,7 +409,7 @@ def main():
                                    f"{'[IsoSE, IsoLinear]' if c.get('kvec') else 'IsoSE'} "
                                    f"depth {c['depth']}: {model.L} leaf GPs n={int(nobs.min())}..{int(nobs.max())}, "
                                    f"n_t={Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; "
-                                   f"fit! (Gram+Cholesky+alpha+mll) + update! + predict",
+                                   f"fit! (Gram+Cholesky+forward solve+mll) + update! + predict",
                        "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and of the aggregation's partial sums"
                                       + (f"; {n_sub} concurrent contexts per GPU" if n_sub > 1 else "")},
             "matrix_tflops_fit_predict": matrix_flops_total / ((cats.get("total_fit", 0.0) + cats.get("total_predict", 0.0))

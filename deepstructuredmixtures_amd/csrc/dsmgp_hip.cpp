@@ -724,7 +724,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             u.sym = (i == k) ? 1 : 0;   // diagonal tile: A == B, lower blocks only
                             nsym += (size_t)u.sym;
                             if (fused) {
-                                u.gram = 1 | (i == k ? 2 : 0);
+                                u.gram = 1 | (i == k ? 2 : 0) | 4;   // bit 2: a tile of the factor is first written here, padding rows too
                                 u.kid = lf.kid;
                                 u.gxa = d.Xg + (size_t)i * TB;
                                 u.gxb = d.Xg + (size_t)k * TB;
@@ -823,10 +823,10 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             // diagonal tiles stay full tiles.
             if (nsym * 5 < tiles.size())
                 for (auto& u : tiles) u.sym = 0;
-            {   // padding-row tiles: worth the PAD instantiations of the kernels from a 10 % share on (step 0 has no
-                // update launch: its panel solves decide)
+            {   // short tiles (padding rows below): worth the PAD instantiations of the kernels from a 10 % share on (step 0
+                // has no update launch: its panel solves decide)
                 size_t npad = 0, ntot = tiles.size();
-                for (const auto& u : tiles) npad += (u.mrows != 0 && u.mrows <= 64) ? 1 : 0;
+                for (const auto& u : tiles) npad += (u.mrows != 0 && u.mrows <= 96) ? 1 : 0;
                 if (tiles.empty()) {
                     ntot = trsm.size() - (size_t)S.trsm_off[k];
                     for (size_t q = (size_t)S.trsm_off[k]; q < trsm.size(); ++q) npad += (trsm[q].mrows != 0 && trsm[q].mrows <= 64) ? 1 : 0;
@@ -1415,6 +1415,7 @@ int dsmgp_set_sharing(dsmgp_ctx* c, const int32_t* op, const int32_t* src, const
     }
     HIPCHK(c, hipSetDevice(c->device));
     free_plan(c);
+    free_test(c);     // the task lists of a resident test set point into the plan's arenas: they go with it
     for (int l = 0; l < L; ++l) {
         c->leaves[l].op = sh[l].op;
         c->leaves[l].src = sh[l].src;

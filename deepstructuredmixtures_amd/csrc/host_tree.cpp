@@ -247,7 +247,9 @@ struct TreeBuild {
         const int64_t h = n / 2;
         std::nth_element(b, b + h, e);
         const double hi = b[h];
-        const double m = (n % 2) ? hi : (*std::max_element(b, b + h) + hi) / 2.0;
+        // + 0.0 turns -0.0 into +0.0: which of two signed zeros a selection returns is not defined (NumPy's median and
+        // nth_element differ), and the sign would reach the stored thresholds through 0 * a + m
+        const double m = ((n % 2) ? hi : (*std::max_element(b, b + h) + hi) / 2.0) + 0.0;
         int64_t z1 = 0, z2 = 0;
         int cnt = 0;
         double s_new = m;

@@ -211,8 +211,9 @@ struct TileTask {
     int sym;            // 1: diagonal tile of the factorisation, B == A (C -= A A^T): only the lower 16x16 blocks are
                         //    computed and written (tile_syrk_body); the strictly upper blocks of C are left alone
     int mrows;          // rows of the tile that hold data (rows >= mrows are padding: zero rows of A, whose product is
-                        //    zero); 0 = all 128.  Waves whose rows are all padding issue no MFMAs: a test-row tile of a
-                        //    small leaf (44 routed rows padded to 128) keeps two of its four waves off the matrix pipe
+                        //    zero); 0 = all 128.  Update tasks with mrows <= 96 run in the column-split form (tile_rows_body):
+                        //    a test-row tile of a small leaf (44 routed rows padded to 128) costs 3/8 of a tile; panel solves
+                        //    skip the waves whose 32 rows are all padding
     // Gram matrix fused into the update (gram != 0): the tile is NOT read -- the kernel evaluates k(row, column) where
     // it would have loaded C(row, column), with the operations of gram_half_tile in the same order (bit-identical
     // values), and stores k - product (update = 1) or product - k (update = 0: first piece of a split tile, whose
@@ -221,13 +222,16 @@ struct TileTask {
                         //    but start at different columns (the blocks of L^-T: row tile t starts at column 128 t, all end
                         //    at the step's column) then read the same chunks of it at the same time and share them through
                         //    L2; streamed from their own first columns they never meet
-    int gram;           // bit 0: on; bit 1: tile on the block diagonal of K_nn (noise + eps on the diagonal, identity padding)
+    int gram;           // bit 0: on; bit 1: tile on the block diagonal of K_nn (noise + eps on the diagonal, identity padding);
+                        //    bit 2: short tiles (tile_rows_body) must write the padding rows of C too (tiles of the factor: zeros,
+                        //    ones on the diagonal of a diagonal tile; the rows of K_tn already hold theirs)
     int kid;            // kernel id of the leaf (index into the KParam table)
     const double* gxa;  // coordinates of the tile's rows, column-major [glda x D], offset to the tile's first row
     const double* gxb;  // ... of its columns
     int glda, gldb;
     int gna, gnb;       // valid rows / columns (<= 128)
 };
+static_assert(sizeof(TileTask) == 128, "TileTask is read with scalar loads: keep it two cache lines");
 constexpr int GRAM_FUSE_MAX_D = 32;   // the coordinates of 128 rows and 128 columns go through the ring's LDS
 
 // diagnostic builds (-DDSMGP_DIAG, tools/bench_tile.py) stamp shader cycles; never executed by fit!/predict
@@ -323,26 +327,6 @@ __device__ __forceinline__ void gram_tile_epilogue(const TileTask& tk, const KPa
             }
         }
     }
-}
-
-// Rows 64..127 of a fused-Gram tile whose waves skipped the product (padding rows, gemm_staging_only): the Gram values
-// of padding rows -- zeros, ones on the diagonal of a K_nn diagonal tile.
-__device__ __forceinline__ void gram_pad_rows_store(const TileTask& tk) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wc = w >> 1, l15 = lane & 15, l4 = lane >> 4;
-    const bool diag_tile = (tk.gram & 2) != 0;
-#pragma unroll
-    for (int cm = 0; cm < 4; ++cm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cidx = wc * 64 + 16 * cm + l4 + 4 * r;
-            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)cidx * (size_t)tk.ldc);
-#pragma unroll
-            for (int rn = 0; rn < 4; ++rn) {
-                const int row = 64 + 16 * rn + l15;
-                col[row] = (diag_tile && row == cidx) ? 1.0 : 0.0;
-            }
-        }
 }
 
 // Epilogue shared by the tile kernels: register r of acc[cm][rn] is C(row = wr*64+16rn+l15, col = wc*64+16cm+l4+4r).
@@ -829,66 +813,215 @@ __device__ __forceinline__ void tile_syrk_body(const TileTask& tk, double (*sA)[
     }
 }
 
-// The part of gemm_mainloop_v2 that a wave without data rows still has to do for its workgroup: its share of the global
-// loads and LDS writes of every chunk and all the barriers -- no fragment reads, no MFMAs, no epilogue (C - 0).
-// Used for whole-tile update tasks whose rows 64..127 are padding (TileTask.mrows <= 64) by the two waves that own them:
-// a test-row tile of a small leaf (44 routed rows padded to 128) then loads the matrix pipe of its CU half as much.
-__device__ __forceinline__ void gemm_staging_only(const TileTask& tk, double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP]) {
+// ---------------------------------------------------------------------------------------------
+// Short tiles: update tasks whose rows 16 NR.. are padding (TileTask.mrows <= 16 NR; NR = 2, 4, 6).  The small-leaf regime
+// is made of them: the last row tile of a leaf holds n mod 128 rows, a test-row tile of a depth-4 leaf 44 routed rows on
+// average, and at depth 4 three of four update tiles are one or the other.  In the 2x2 wave grid of gemm_mainloop_v2 such a
+// tile leaves the waves of its lower half without work while the other two still take a full tile's time (and the
+// co-resident workgroup still shares ITS SIMDs with them): the tile is no faster.  Here the four waves split the COLUMNS
+// instead -- wave w owns columns 32w..32w+31 and all NR row blocks, acc[2][NR] -- so every SIMD carries NR/8 of a full
+// tile's matrix work and the task ends in that fraction of the time.  Same ring, prefetch and barrier protocol as
+// gemm_mainloop_v2; rows 64.. of the A panel are neither loaded nor staged for NR <= 4.
+template <int NR>
+__device__ __forceinline__ void gemm_mainloop_rows(const TileTask& tk, d4 (&acc)[2][NR], double (*sA)[KC2 * LDP],
+                                                   double (*sB)[KC2 * LDP]) {
     const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    constexpr bool AHI = NR > 4;                  // rows 64.. of the A panel hold data
+    constexpr int NMEM_G = AHI ? 4 : 3;           // global loads (and LDS writes) per chunk and thread
+    constexpr int NFRAG = (2 + NR + 1) / 2;       // fragment reads per 4-column group, as ds_read2
+    constexpr int NMFMA = 2 * NR;
+#pragma unroll
+    for (int cm = 0; cm < 2; ++cm)
+#pragma unroll
+        for (int rn = 0; rn < NR; ++rn) acc[cm][rn] = (d4){0.0, 0.0, 0.0, 0.0};
     const int scol = t >> 5, srow = 2 * (t & 31);
     const double* gA = tk.A + srow + (size_t)(tk.k0 + scol) * tk.lda;
     const double* gB = tk.B + srow + (size_t)(tk.k0 + scol) * tk.ldb;
     const int sOff = scol * LDP + srow;
-    const int nch = (tk.k1 - tk.k0) / KC2;
     d2 ra0[2], rb0[2], ra1[2], rb1[2];
-#define GLOAD(RA, RB, CH)                                                                        \
+#define RGLOAD(RA, RB, CH)                                                                       \
     do {                                                                                         \
         const size_t oa_ = (size_t)(CH) * KC2 * tk.lda, ob_ = (size_t)(CH) * KC2 * tk.ldb;       \
         RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
-        RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                                    \
+        if (AHI) RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                           \
         RB[0] = *AS_GLOBAL_D2(gB + ob_);                                                         \
         RB[1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                                    \
     } while (0)
-#define SWRITE(RA, RB, BUF)                                                                      \
+#define RSWRITE(RA, RB, BUF)                                                                     \
     do {                                                                                         \
         *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA[0];                                          \
-        *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                                     \
+        if (AHI) *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                            \
         *reinterpret_cast<d2*>(&sB[BUF][sOff]) = RB[0];                                          \
         *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = RB[1];                                     \
     } while (0)
-    if (nch > 0) {   // same protocol as the prologue and the chunks of gemm_mainloop_v2
-        GLOAD(ra0, rb0, 0);
-        GLOAD(ra1, rb1, min(1, nch - 1));
-        SWRITE(ra0, rb0, 0);
-        GLOAD(ra0, rb0, min(2, nch - 1));
-        SWRITE(ra1, rb1, 1);
-        GLOAD(ra1, rb1, min(3, nch - 1));
-        SWRITE(ra0, rb0, 2);
+#define RFRAGS(FA, FB, BUF, G)                                                                   \
+    do {                                                                                         \
+        const double* pa_ = &sB[BUF][((G) * 4 + l4) * LDP + w * 32 + l15];                       \
+        const double* pb_ = &sA[BUF][((G) * 4 + l4) * LDP + l15];                                \
+        FA[0] = pa_[0];                                                                          \
+        FA[1] = pa_[16];                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < NR; ++i_) FB[i_] = pb_[16 * i_];                 \
+    } while (0)
+#define RMFMA(FA, FB)                                                                            \
+    do {                                                                                         \
+        _Pragma("unroll") for (int cm_ = 0; cm_ < 2; ++cm_)                                      \
+            _Pragma("unroll") for (int rn_ = 0; rn_ < NR; ++rn_)                                 \
+                acc[cm_][rn_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[cm_], FB[rn_], acc[cm_][rn_], 0, 0, 0); \
+    } while (0)
+    // one memory instruction in the shadow of each MFMA, as far as the MFMAs go (NR = 2: four of them per group)
+    constexpr int NI_A = NMEM_G < NMFMA ? NMEM_G : NMFMA;
+    constexpr int NI_B = (NMFMA - NI_A) < NFRAG ? (NMFMA - NI_A) : NFRAG;
+    constexpr int NI_REST = NMFMA - NI_A - NI_B;
+#define RINTERLEAVE(MASK_A)                                                                      \
+    do {                                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI_A; ++i_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(MASK_A, 1, 0);                                  \
+        }                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI_B; ++i_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+        }                                                                                        \
+        if constexpr (NI_REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, NI_REST, 0);      \
+    } while (0)
+    const int nch = (tk.k1 - tk.k0) / KC2;
+    if (nch > 0) {
+        RGLOAD(ra0, rb0, 0);
+        RGLOAD(ra1, rb1, min(1, nch - 1));
+        RSWRITE(ra0, rb0, 0);
+        RGLOAD(ra0, rb0, min(2, nch - 1));
+        RSWRITE(ra1, rb1, 1);
+        RGLOAD(ra1, rb1, min(3, nch - 1));
+        RSWRITE(ra0, rb0, 2);
     }
     __syncthreads();
+    double fa0[2], fb0[NR], fa1[2], fb1[NR];
+    if (nch > 0) RFRAGS(fa0, fb0, 0, 0);
+#define RCHUNK(C, LRA, LRB, WRA, WRB)                                                            \
+    do {                                                                                         \
+        const int c_ = (C);                                                                      \
+        const int buf_ = c_ & (NRING - 1);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        RGLOAD(LRA, LRB, min(c_ + 4, nch - 1));                                                  \
+        RFRAGS(fa1, fb1, buf_, 1);                                                               \
+        RMFMA(fa0, fb0);                                                                         \
+        RINTERLEAVE(0x020);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        RSWRITE(WRA, WRB, (c_ + 3) & (NRING - 1));                                               \
+        RFRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                                             \
+        RMFMA(fa1, fb1);                                                                         \
+        RINTERLEAVE(0x200);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __syncthreads();                                                                         \
+    } while (0)
     int c = 0;
     for (; c + 1 < nch; c += 2) {
-        GLOAD(ra0, rb0, min(c + 4, nch - 1));
-        SWRITE(ra1, rb1, (c + 3) & (NRING - 1));
-        __syncthreads();
-        GLOAD(ra1, rb1, min(c + 5, nch - 1));
-        SWRITE(ra0, rb0, (c + 4) & (NRING - 1));
-        __syncthreads();
+        RCHUNK(c, ra0, rb0, ra1, rb1);
+        RCHUNK(c + 1, ra1, rb1, ra0, rb0);
     }
-    if (c < nch) {
-        GLOAD(ra0, rb0, min(c + 4, nch - 1));
-        SWRITE(ra1, rb1, (c + 3) & (NRING - 1));
-        __syncthreads();
+    if (c < nch) RCHUNK(c, ra0, rb0, ra1, rb1);
+#undef RCHUNK
+#undef RINTERLEAVE
+#undef RMFMA
+#undef RFRAGS
+#undef RSWRITE
+#undef RGLOAD
+}
+
+// Epilogue of a short tile: register r of acc[cm][rn] is C(row = 16 rn + l15, col = 32 w + 16 cm + l4 + 4 r).
+//   update = 1 without Gram: C(rows < 16 NR) -= product; the rows below are not touched (padding: they hold what they held)
+//   update = 1 with the Gram fused: C(rows < 16 NR) = k(row, col) - product with gram_finish's padding rules, and -- the
+//   tile has never been written -- the rows 16 NR.. get their padding values when the task says so (TileTask.gram bit 2: tiles
+//   of the factor, whose padding is zero, one on the diagonal; the rows of K_tn are zeroed once by dsmgp_set_test)
+template <int NR, int KIND>
+__device__ __forceinline__ void rows_gram_epilogue(const TileTask& tk, const KParam& p, int D, d4 (&acc)[2][NR], const double* sa,
+                                                   const double* sb) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const size_t ldc = (size_t)tk.ldc;
+    const bool diag_tile = (tk.gram & 2) != 0;
+    const double* pa = sa + l15;
+#pragma unroll
+    for (int cm = 0; cm < 2; ++cm) {
+        const double* pb = sb + w * 32 + 16 * cm + l4;
+        double z[NR][4];
+#pragma unroll
+        for (int rn = 0; rn < NR; ++rn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[rn][r] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double a[NR], b[4];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) a[i] = pa[d * TB + 16 * i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = pb[d * TB + 4 * i];
+            gram_accumulate<KIND, NR, 4>(z, a, b, (KIND == 1) ? p.nh[d] : 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cidx = w * 32 + 16 * cm + l4 + 4 * r;
+            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)cidx * ldc);
+#pragma unroll
+            for (int rn = 0; rn < NR; ++rn) {
+                const double kv = gram_finish<KIND, true>(z[rn][r], p, 16 * rn + l15, cidx, tk.gna, tk.gnb, diag_tile);
+                col[16 * rn + l15] = kv - acc[cm][rn][r];
+            }
+            if (tk.gram & 4) {
+#pragma unroll
+                for (int rn = NR; rn < 8; ++rn) {
+                    const int row = 16 * rn + l15;
+                    col[row] = (diag_tile && row == cidx) ? 1.0 : 0.0;
+                }
+            }
+        }
     }
-#undef SWRITE
-#undef GLOAD
+}
+
+template <int NR>
+__device__ __forceinline__ void tile_rows_body(const TileTask& tk, double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
+                                               const KParam* __restrict__ kp, int D) {
+    d4 acc[2][NR];
+    gemm_mainloop_rows<NR>(tk, acc, sA, sB);      // ends on a barrier: the ring is free
+    if (tk.gram != 0 && kp != nullptr) {
+        const KParam p = kp[tk.kid];
+        gram_stage_coords(tk, D, &sA[0][0], &sB[0][0], true);
+        if (p.kind == 0) rows_gram_epilogue<NR, 0>(tk, p, D, acc, &sA[0][0], &sB[0][0]);
+        else if (p.kind == 1) rows_gram_epilogue<NR, 1>(tk, p, D, acc, &sA[0][0], &sB[0][0]);
+        else rows_gram_epilogue<NR, 2>(tk, p, D, acc, &sA[0][0], &sB[0][0]);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const size_t ldc = (size_t)tk.ldc;
+#pragma unroll
+    for (int cm = 0; cm < 2; ++cm) {       // C -= product, the loads of a column group in flight before its stores
+        double cv[NR][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(w * 32 + 16 * cm + l4 + 4 * r) * ldc);
+#pragma unroll
+            for (int rn = 0; rn < NR; ++rn) cv[rn][r] = col[16 * rn + l15];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(w * 32 + 16 * cm + l4 + 4 * r) * ldc);
+#pragma unroll
+            for (int rn = 0; rn < NR; ++rn) col[16 * rn + l15] = cv[rn][r] - acc[cm][rn][r];
+        }
+    }
 }
 
 // ROLE only names the instantiation (same code): 0 = update launches (whole tiles and split-K pieces), 1 = panel
 // solves (K = 128), so that profilers report the two populations as two kernels
 // (tile_gemm_kernel_v2<false, 0> is the dominant kernel of bench.py's roofline).
-// PAD: the launch carries enough tiles with padding rows (TileTask.mrows) for the staging-only path to pay; without it the
-// check is compiled out (it costs the other launches ~0.3 % through the register allocation of the main path).
+// PAD: the launch carries enough short tiles (TileTask.mrows <= 96: padding rows below) for the column-split form
+// (tile_rows_body) to pay; without it the check is compiled out (it costs the other launches ~0.3 % through the register
+// allocation of the main path).
 template <bool STAMP, int ROLE = 0, bool PAD = false>
 __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
                                                               unsigned long long* __restrict__ stamps,
@@ -903,13 +1036,11 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
         tile_syrk_body(tk, sA, kp, D);
         return;
     }
-    if (PAD && !STAMP && tk.update == 1 && tk.mrows != 0 && tk.wi == nullptr &&
-        ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) * 64 >= tk.mrows)) {
-        gemm_staging_only(tk, sA, sB);   // this wave's rows are padding: C - 0
-        if (tk.gram != 0) {              // ... and with the Gram fused, C's padding rows are this wave's to write, after
-            gram_stage_coords(tk, D, &sA[0][0], &sB[0][0], true);   // its share of the coordinate staging of the other two
-            gram_pad_rows_store(tk);
-        }
+    if (PAD && !STAMP && tk.update == 1 && tk.mrows != 0 && tk.mrows <= 96 && tk.wi == nullptr && tk.rev == 0) {
+        // short tile (rows mrows.. are padding): the waves split the columns, every SIMD does mrows/128 of a tile's work
+        if (tk.mrows <= 32) tile_rows_body<2>(tk, sA, sB, kp, D);
+        else if (tk.mrows <= 64) tile_rows_body<4>(tk, sA, sB, kp, D);
+        else tile_rows_body<6>(tk, sA, sB, kp, D);
         return;
     }
     d4 acc[4][4];
@@ -1638,12 +1769,18 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restri
 //   phase 1: blocked right-looking Cholesky exactly as above (potrf_inv16 on wave 0 with lookahead, panel products,
 //           trailing products) without the inverse products.  L_JJ goes from registers straight to the tile in global
 //           memory; its slot in the image keeps L_JJ^-1 (operand of the panel products and of phase 2)
-//   phase 2: after the off-diagonal blocks of L are written out, L^-1 overwrites L in place, block column by block
-//           column from the right:  Y(J) = L(J,K) X(K,K) (J > K), then X(I,K) = - sum_{J=K+1..I} X(I,J) Y(J), computed
-//           into registers by all waves, written after a barrier (other waves still read the Y blocks)
+//           The forward substitution z = L_kk^-1 w_k rides along: z_J = L_JJ^-1 w_J in P1 (one wave, 16 lanes), then
+//           w_I -= L(I,J) z_J for the rows below in P2 (waves 1..3, one row per thread): no inverse is needed for it
+//   phase 2: L^-1 = X, block column by block column WITHOUT barriers: X(K,K) = L_KK^-1 is in the image, and
+//           X(I,K) = -L_II^-1 sum_{J=K..I-1} L(I,J) X(J,K) depends on the same column's earlier blocks only.  Wave w takes
+//           the columns K = w and 7 - w (37, 31, 27 and 25 block products) and keeps its X blocks in REGISTERS: a 16x16
+//           result in accumulator layout is the second operand of the next product as it stands (register r = rows
+//           4r..4r+3 of the block = the operand's k-slab r), so the image is only read (blocks of L, conflict-free
+//           column reads) and every finished block goes straight to Dinv in global memory.  35 of the kernel's 88 us
+//           were this phase in its barrier-per-column form (two barriers and a round trip through the image per column).
 constexpr int PLD = 144;
 constexpr int PIMG = 64 * PLD;
-constexpr int DIAGP_LDS_BYTES = (PIMG + TB + 64) * (int)sizeof(double);   // image + rhs block + block-offset table
+constexpr int DIAGP_LDS_BYTES = (PIMG + 2 * TB + 64) * (int)sizeof(double);   // image + rhs block + z + block-offset table
 
 struct PackedMap {
     unsigned short off[64];     // [I * 8 + K], doubles; 0xFFFF above the diagonal
@@ -1676,8 +1813,10 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    double* wl = S + PIMG;
-    int* soff = reinterpret_cast<int*>(S + PIMG + TB);
+    double* wl = S + PIMG;                 // right-hand side block w_k, updated in place by the fused forward substitution
+    double* zl = S + PIMG + TB;            // z_k = L_kk^-1 w_k
+    int* soff = reinterpret_cast<int*>(S + PIMG + 2 * TB);
+    const bool fuse = tk.wk != nullptr;
     // block offsets: lane l keeps the offset of block (l >> 3, l & 7) and the l-th lower block; wave-uniform lookups
     // are v_readlane, per-thread lookups (the fused z at the end) go through the copy in LDS
     const int mytab = PACKED.off[lane];
@@ -1793,6 +1932,14 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
                 const double* linv = S + off(J, J);
                 run_pair(BlkOp{linv, 1, PLD, d0, PLD, d0}, BlkOp{linv, 1, PLD, d1, PLD, d1}, two, false);
             }
+            // z_J = L_JJ^-1 w_J (w_J had its last update in P2 of step J - 1; the slot's upper part is zero)
+            if (fuse && w == 3 && lane < 16) {
+                const double* linv = S + off(J, J) + lane;
+                double sum = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sum = fma(linv[c * PLD], wl[16 * J + c], sum);
+                zl[16 * J + lane] = sum;
+            }
         }
         __syncthreads();
         const int m = 7 - J;
@@ -1813,10 +1960,20 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
                 const BlkOp o0 = op_p2(task);
                 run_pair(o0, two ? op_p2(task + 3) : o0, two, true);
             }
+            // w_I -= L(I,J) z_J for the rows below block J, one row per thread of the waves 1..3
+            const int row = 16 * (J + 1) + (t - 64);
+            if (fuse && row < TB) {
+                const double* lrow = S + soff[(row >> 4) * 8 + J] + (row & 15);
+                double sum = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sum = fma(lrow[c * PLD], zl[16 * J + c], sum);
+                wl[row] -= sum;
+            }
         }
         __syncthreads();
     }
     bad = __shfl(bad, 0);
+    if (fuse && t < TB) tk.zk[t] = zl[t];
     // ---- off-diagonal blocks of L -> tile, zeros above the diagonal (diagonal blocks were written by diag_block);
     //      the same sweep zeroes the upper blocks of Dinv.  16 of the 64 blocks per wave.
     {
@@ -1840,85 +1997,45 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
             }
         }
     }
-    __syncthreads();   // every wave has read its L blocks: the image may be overwritten
-    // ---- phase 2: L^-1 in place, block columns from the right
-    for (int K = 6; K >= 0; --K) {
+    // ---- phase 2: L^-1, two block columns per wave, blocks in registers, no barrier (the image is only read)
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int K = half ? 7 - w : w;
         const int m = 7 - K;
-        if (w < m) {   // (a) Y(J) = L(J,K) X(K,K), J = K+1+w and K+1+w+4
-            double* d0 = S + off(K + 1 + w, K);
-            const bool two = w + 4 < m;
-            double* d1 = two ? S + off(K + 1 + w + 4, K) : d0;
-            const double* xkk = S + off(K, K);
-            run_pair(BlkOp{xkk, PLD, 1, d0, PLD, d0}, BlkOp{xkk, PLD, 1, d1, PLD, d1}, two, false);
+        d4 xr[8];
+        {   // X(K,K) = L_KK^-1 into accumulator layout: a product with the identity (reading it lane-per-column
+            // from the image would be a 8-way bank conflict)
+            const double* lk = S + off(K, K);
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lk[(4 * q + l4) * PLD + l15], (l15 == 4 * q + l4) ? 1.0 : 0.0, acc, 0, 0, 0);
+            xr[0] = acc;
         }
-        __syncthreads();
-        // (b) X(I,K) = - sum_{J=K+1..I} X(I,J) Y(J): outputs i = 0..m-1 (I = K+1+i, i+1 products); wave w takes the
-        //     short chain i = w and the long chain i = m-1-w, interleaved
-        const bool have = w < (m + 1) / 2;
-        const int i1 = w, i2 = m - 1 - w;
-        const bool two = have && i2 > i1;
-        d4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-        if (have) {
-            const int I1 = K + 1 + i1, I2 = K + 1 + i2;
-            for (int s = 0; s <= i2; ++s) {
-                const int J = K + 1 + s;
-                const double* y = S + off(J, K);                 // Y(J): Aop(a,k) = Y(k,a)
-                double ya[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ya[q] = y[l15 * PLD + (4 * q + l4)];
-                if (s <= i1) {
-                    const double* x1 = S + off(I1, J);
+        for (int i = 1; i <= 7; ++i) {
+            if (i > m) break;
+            const int I = K + i;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q], x1[l15 + (4 * q + l4) * PLD], acc1, 0, 0, 0);
-                }
-                if (two) {
-                    const double* x2 = S + off(I2, J);
+            for (int s2 = 0; s2 < i; ++s2) {     // sum_J L(I,J) X(J,K): X(J,K) register q is the operand's k-slab q
+                const double* lb = S + off(I, K + s2);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q], x2[l15 + (4 * q + l4) * PLD], acc2, 0, 0, 0);
-                }
+                for (int q = 0; q < 4; ++q)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[(4 * q + l4) * PLD + l15], xr[s2][q], acc, 0, 0, 0);
             }
-        }
-        __syncthreads();
-        if (have) {
-            double* d1 = S + off(K + 1 + i1, K);
+            const double* li = S + off(I, I);
+            d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d1[(l4 + 4 * r) * PLD + l15] = -acc1[r];
-            if (two) {
-                double* d2p = S + off(K + 1 + i2, K);
+            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(li[(4 * q + l4) * PLD + l15], acc[q], x, 0, 0, 0);
+            xr[i] = -x;
+            // register r holds X(row 16 I + l4 + 4 r, column 16 K + l15)
+            const gf64_ptr gD = AS_GLOBAL_F64(tk.Dinv + (size_t)(16 * I + l4) + (size_t)(16 * K + l15) * TB);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d2p[(l4 + 4 * r) * PLD + l15] = -acc2[r];
-            }
-        }
-    }
-    __syncthreads();
-    // ---- off-diagonal blocks of L^-1 -> Dinv (7 of the 28 per wave)
-    {
-        const int bc = lane >> 2, br = 4 * (lane & 3);
-#pragma unroll 3
-        for (int q = 0; q < 9; ++q) {
-            const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
-            const int I = e >> 4, K = e & 15;
-            if (I == K) continue;
-            const double* src = S + off(I, K) + bc * PLD + br;
-            double* gD = tk.Dinv + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * TB;
-            *reinterpret_cast<d2*>(gD) = *reinterpret_cast<const d2*>(src);
-            *reinterpret_cast<d2*>(gD + 2) = *reinterpret_cast<const d2*>(src + 2);
+            for (int r = 0; r < 4; ++r) gD[4 * r] = xr[i][r];
         }
     }
     if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
-    if (tk.wk != nullptr) {
-        // z_k = L_kk^-1 w_k from the inverse still in the image: thread (r = t >> 1, h = t & 1) sums the columns
-        // [64h, 64h+64) of row r
-        const int r = t >> 1, h = t & 1;
-        const int R = r >> 4, ri = r & 15;
-        double sum = 0.0;
-        const int cend = min(r, 64 * h + 63);
-        for (int c = 64 * h; c <= cend; ++c) sum = fma(S[soff[R * 8 + (c >> 4)] + (c & 15) * PLD + ri], wl[c], sum);
-        sum += __shfl_xor(sum, 1);
-        if (h == 0) tk.zk[r] = sum;
-    }
 }
 
 #ifdef DSMGP_DIAG

@@ -13,8 +13,8 @@ import numpy as np
 
 from . import hipabi
 from .kernels import IsoSE, ConstMean, KIND_ISO_SE, KIND_ARD_SE, KIND_ISO_LINEAR
-from .tree import (DSMGPConfig, GPSumNode, build_tree, get_leaves, get_overlap, obs_table, share_schedule, route, route_all,
-                   get_child, ordered_nodes, SHARE_COPY, SHARE_FULL, SHARE_PREFIX)
+from .tree import (DSMGPConfig, GPSumNode, build_tree, get_leaves, get_overlap, obs_table, share_schedule, share_decisions,
+                   share_census, route, route_all, get_child, ordered_nodes, SHARE_COPY, SHARE_FULL, SHARE_PREFIX)
 from . import dist as _dist
 
 EPS = 1e-8  # `const ϵ` of src/DeepStructuredMixtures.jl:27
@@ -154,6 +154,9 @@ class Model:
         self._schedule = None
         self._route_cache = None
         self._tindex = None
+        self.share_op = None          # per leaf: what the last fit did (SHARE_FULL / COPY / PREFIX)
+        self.share_branch = None      # per leaf: the arm of the reference's fit! (tree.BRANCH_*)
+        self.fit_census = None        # tree.share_census(share_branch): counts + the leaves of the arms computed in full here
 
     @property
     def tindex(self):
@@ -192,6 +195,24 @@ class Model:
             hyp = np.concatenate([lf.kernel.loghyp(), [lf.logNoise]])
             self.ctx.set_hyper(lf.kernelid, lf.kernel.kind, hyp)
 
+    def set_option(self, option, value):
+        """`dsmgp_set_option` on the model's context.  An option that rebuilds the plan (OPT_FUSED_GRAM) drops the
+        device-side test set with it: the route cache is told, so the next predict registers its rows again."""
+        self.ctx.set_option(option, value)
+        if self._route_cache is not None:
+            self._route_cache["uploaded"] = False
+
+    def _set_decisions(self, dec):
+        """Record the sharing decisions of this fit (None: fit_naive!, every leaf in full) for the caller: which leaves
+        the reference's default fit! would have sent through its (defective) row-deletion arm is part of the
+        result, not only of the oracle."""
+        if dec is None:
+            dec = (np.zeros(self.L, dtype=np.int32), np.full(self.L, -1, dtype=np.int32), np.zeros(self.L, dtype=np.int64),
+                   np.zeros(self.L, dtype=np.int8))
+        self.share_op, self.share_branch = dec[0], dec[3]
+        self.fit_census = share_census(dec[3])
+        return dec
+
     # ---- leaf table ------------------------------------------------------------------------------
     def _upload(self, tau):
         loc = self.shard.local
@@ -205,7 +226,9 @@ class Model:
             self._schedule = key
             self._route_cache = None
             if self.D is not None and tau is not None:
-                self.share_op = share_schedule(self.leaves, self.D, tau)[0]
+                self._set_decisions(share_decisions(self.leaves, self.D, tau))
+            else:
+                self._set_decisions(None)
             return
         if not self._uploaded:
             self.ctx.set_train(self.x, self.y)
@@ -213,7 +236,7 @@ class Model:
         ptr, idx = obs_table(lv)
         self.ctx.set_leaves(ptr, idx, [lf.kernelid for lf in lv], [lf.mean.m for lf in lv])
         if self.D is not None and tau is not None:
-            op, src, plen = share_schedule(self.leaves, self.D, tau)
+            op, src, plen, _ = self._set_decisions(share_decisions(self.leaves, self.D, tau))
             g2l = {g: i for i, g in enumerate(loc)}
             lop = np.zeros(len(lv), dtype=np.int32)
             lsrc = np.full(len(lv), -1, dtype=np.int32)
@@ -221,9 +244,9 @@ class Model:
             for i, g in enumerate(loc):
                 if op[g] != SHARE_FULL and int(src[g]) in g2l:   # source must live on the same rank
                     lop[i], lsrc[i], lpl[i] = op[g], g2l[int(src[g])], plen[g]
-            self.share_op = op
             self.ctx.set_sharing(lop, lsrc, lpl)
         else:
+            self._set_decisions(None)
             self.ctx.set_sharing(None, None, None)
         self._uploaded = True
         self._schedule = key
@@ -356,10 +379,21 @@ def _fit(model, tau):
     return sec
 
 
+class FitSeconds(float):
+    """What `fit!` returns -- the seconds of the leaf loop (`src/fit.jl:88,121`) -- carrying the census of the sharing
+    decisions: `.census` = dict(full, copy, prefix, lowrank_as_full, leading_as_full, lowrank_leaves, leading_leaves)
+    over the arms of the REFERENCE's fit!.  `lowrank_leaves` are the leaves whose reference result comes from its
+    row-deletion arm (`src/fit.jl:174-201`; numerically defective) and is an exact factorisation here."""
+    census = None
+
+
 def fit(model, tau=0.05):
-    """`fit!(model; τ)`: shared-Cholesky fit (copy + prefix sharing). Returns seconds."""
+    """`fit!(model; τ)`: shared-Cholesky fit (copy + prefix sharing). Returns seconds (`FitSeconds`: the
+    census of the sharing decisions rides on it, and stays on the model as `model.fit_census`)."""
     target = model.model if isinstance(model, GaussianProcess) else model
-    return _fit(target, tau)
+    out = FitSeconds(_fit(target, tau))
+    out.census = target.fit_census
+    return out
 
 
 def fit_naive(model):
@@ -629,6 +663,9 @@ def train(model, optim=None, *, iterations=10_000, lam=None, randinit=True, earl
     try:
         return _train_loop(model, optim, hyp, hist, c, iterations, lam, earlystop, tau, verbose, streaming)
     finally:
+        if streaming:                  # also after an error inside the loop: later passes must not collect gradients
+            model.ctx.want_gradients = 0
+            model.ctx.groups = None
         if has_leaves:
             model.ctx.set_joint(True)
 
@@ -829,10 +866,12 @@ def _finish_partial(model, xt, family, part, n_groups, plain, prior_leaf):
     m = np.zeros(xt.shape[0])
     for g in range(n_groups):
         T = part[2 * g + 1]
-        M = part[2 * g] / T
-        beta = 0.5 * (np.log(s) - np.log(1.0 / T))
-        Cc = Cc + (beta * T) - (beta / s)
-        m = m + M * (beta * T)
+        seen = T != 0.0                      # no leaf of this child saw the row: the group is skipped (agg_finish_kernel)
+        Ts = np.where(seen, T, 1.0)
+        M = part[2 * g] / Ts
+        beta = 0.5 * (np.log(s) - np.log(1.0 / Ts))
+        Cc = Cc + np.where(seen, (beta * Ts) - (beta / s), 0.0)
+        m = m + np.where(seen, M * (beta * Ts), 0.0)
     return m / Cc, 1.0 / Cc
 
 

@@ -127,7 +127,7 @@ def _get_splits(xd, lower, upper, minData, eps, K, rng, depth=1):
     v = u - l
     sel = xd[(xd > l) & (xd <= u)]
     if sel.size > 2 * minData:
-        m = float(np.median(sel))
+        m = float(np.median(sel)) + 0.0     # -0.0 -> +0.0: a column holding both zeros has no unique median bit pattern
         z1 = z2 = 0
         c = 0
         s_new = m
@@ -461,23 +461,32 @@ def _get_overlap_pairwise(root, L):
 SHARE_FULL, SHARE_COPY, SHARE_PREFIX = 0, 1, 2
 
 
-def share_schedule(leaves, Dm, tau=0.05):
+BRANCH_FULL, BRANCH_COPY, BRANCH_PREFIX, BRANCH_LOWRANK, BRANCH_LEADING = 0, 1, 2, 3, 4
+BRANCH_NAMES = ("full", "copy", "prefix", "lowrank_as_full", "leading_as_full")
+
+
+def share_decisions(leaves, Dm, tau=0.05):
     """Per-leaf factorisation decision of the shared-Cholesky `fit!` (`src/fit.jl:71-122`).
 
-    Returns (op, src, plen): op[j] in {FULL, COPY, PREFIX}; for COPY the factor of leaf src[j] is
-    reused as is (`src/fit.jl:132-143`); for PREFIX the leading plen[j] x plen[j] block is leaf
-    src[j]'s factor and the factorisation continues from column plen[j]
-    (`src/fit.jl:208-292` -> `src/AdvancedCholeskey.jl:152-174`).  The row-deletion (low-rank)
-    branches (`src/fit.jl:174-201,256-275` with a non-empty `toupdate`) are numerically defective
-    in the reference and map to FULL.  tau=0 disables sharing except COPY, as in the
-    reference (`src/fit.jl:256`: 0 < 0 is false).
+    Returns (op, src, plen, branch).  op[j] in {FULL, COPY, PREFIX} is what THIS implementation does: for COPY the
+    factor of leaf src[j] is reused as is (`src/fit.jl:132-143`); for PREFIX the leading plen[j] x plen[j] block is
+    leaf src[j]'s factor and the factorisation continues from column plen[j]
+    (`src/fit.jl:208-292` -> `src/AdvancedCholeskey.jl:152-174`).  branch[j] (BRANCH_*) is the arm the REFERENCE takes
+    for the leaf: besides full / copy / prefix,
+      LOWRANK : its row-deletion branch with rows to delete (`src/fit.jl:174-201`: the leaf's list is a subset of its
+                main leaf's and |main.obs[1:e] \ obs| / |obs| < tau).  Numerically defective there; a full
+                factorisation here -- the leaves whose result differs from the reference's own
+      LEADING : the same branch with nothing to delete (the list is a leading part of the main leaf's list; the
+                reference takes the leading block of that factor, which is exact); a full factorisation here
+    tau=0 disables sharing except COPY, as in the reference (`src/fit.jl:173,256`: 0 < 0 is false).
     """
     L = len(leaves)
     op = np.zeros(L, dtype=np.int32)
     src = np.full(L, -1, dtype=np.int32)
     plen = np.zeros(L, dtype=np.int64)
+    branch = np.zeros(L, dtype=np.int8)
     if L == 0:
-        return op, src, plen
+        return op, src, plen, branch
     if isinstance(Dm, LeafOverlap):
         main, d_ij, d_ji = Dm.main_pairs()
     else:
@@ -504,16 +513,38 @@ def share_schedule(leaves, Dm, tau=0.05):
         ione = d_ij[j] == 1.0
         jone = d_ji[j] == 1.0
         if ione and jone:
+            branch[j] = BRANCH_COPY
             if op[i] == SHARE_FULL:
                 op[j], src[j] = SHARE_COPY, i
             elif op[i] == SHARE_COPY:
                 op[j], src[j] = SHARE_COPY, src[i]
         elif ione and not jone and tau > 0.0:
             p = li.nobs
-            if lj.obs[0] == li.obs[0] and lj.nobs > p and np.array_equal(lj.obs[:p], li.obs) \
-                    and op[i] == SHARE_FULL:
-                op[j], src[j], plen[j] = SHARE_PREFIX, i, p
-    return op, src, plen
+            if lj.obs[0] == li.obs[0] and lj.nobs > p and np.array_equal(lj.obs[:p], li.obs):
+                branch[j] = BRANCH_PREFIX
+                if op[i] == SHARE_FULL:
+                    op[j], src[j], plen[j] = SHARE_PREFIX, i, p
+        elif jone and not ione:
+            e = int(np.searchsorted(li.obs, lj.obs[-1])) + 1       # position of max(obs) in the main leaf's list (:168)
+            ndel = e - lj.nobs                                     # |main.obs[1:e] \ obs| (:170): obs is a subset of it
+            if ndel / lj.nobs < tau:                               # :173
+                branch[j] = BRANCH_LOWRANK if ndel > 0 else BRANCH_LEADING
+    return op, src, plen, branch
+
+
+def share_schedule(leaves, Dm, tau=0.05):
+    """(op, src, plen) of `share_decisions`: the schedule `dsmgp_set_sharing` takes."""
+    return share_decisions(leaves, Dm, tau)[:3]
+
+
+def share_census(branch):
+    """Counts of the reference's `fit!` arms over the leaves + the leaf ids of the two arms computed in full here
+    (`share_decisions`): dict(full, copy, prefix, lowrank_as_full, leading_as_full, lowrank_leaves, leading_leaves)."""
+    branch = np.asarray(branch)
+    out = {name: int(np.count_nonzero(branch == code)) for code, name in enumerate(BRANCH_NAMES)}
+    out["lowrank_leaves"] = np.flatnonzero(branch == BRANCH_LOWRANK).tolist()
+    out["leading_leaves"] = np.flatnonzero(branch == BRANCH_LEADING).tolist()
+    return out
 
 
 # ----------------------------------------------------------------------------- routing

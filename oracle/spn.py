@@ -72,13 +72,21 @@ def get_overlap(root, L):
     return D
 
 
-def fit(root, gps, D, tau=0.05, as_written=False):
+def fit(root, gps, D, tau=0.05, as_written=False, census_only=False):
     """fit!(spn, D, gpmap; τ) (src/fit.jl:71-122) with fitcontained! (:124-292).
 
     as_written=False ("lean"): one potrf per leaf, the low-rank row-deletion branches replaced by
     a full factorisation (they are numerically defective).  as_written=True additionally
     reproduces the unconditional extra update_cholesky!(jGP) of :105 for timing.
-    Returns a census dict of the branch taken per leaf."""
+    Returns a census dict of the branch the REFERENCE takes per leaf: counts under "full", "copy", "prefix",
+    "lowrank_as_full" (its row-deletion branch with rows to delete: :174-201, computed in full here) and
+    "leading_as_full" (the same branch with nothing to delete: the leaf's list is a leading part of its main leaf's
+    and the reference takes the leading block of that factor -- exact there, computed in full here), plus
+    "lowrank_leaves" / "leading_leaves", the leaf ids of the last two.
+    census_only=True walks the decisions without any arithmetic (gps may be None; a prefix continuation is assumed
+    to succeed): the census of a model too large to factorise on the host."""
+    if census_only:
+        gps = [_NoGP() for _ in get_leaves(root)]
     leaves = get_leaves(root)
     n = len(leaves)
     processed = np.zeros(n, dtype=bool)
@@ -89,7 +97,8 @@ def fit(root, gps, D, tau=0.05, as_written=False):
         counts[i] += 1
         S[j] = i
     order = sorted(range(n), key=lambda j: counts[j])            # sort! :86 (stable)
-    census = {"full": 0, "copy": 0, "prefix": 0, "lowrank_as_full": 0}
+    census = {"full": 0, "copy": 0, "prefix": 0, "lowrank_as_full": 0, "leading_as_full": 0,
+              "lowrank_leaves": [], "leading_leaves": []}
     for j in order:
         if processed[j]:
             continue
@@ -115,19 +124,43 @@ def fit(root, gps, D, tau=0.05, as_written=False):
         ione = D[i, j] == 1.0
         jone = D[j, i] == 1.0
         if ione and jone:
-            jGP.factors = mainGP.factors.copy()                  # :141-142
-            jGP.alpha = mainGP.alpha.copy()
-            jGP.info = mainGP.info
+            if not census_only:
+                jGP.factors = mainGP.factors.copy()              # :141-142
+                jGP.alpha = mainGP.alpha.copy()
+                jGP.info = mainGP.info
             census["copy"] += 1
         elif ione and not jone:
             _fit_superset(jGP, lj, mainGP, li, tau, census)      # :208-292
         elif jone and not ione:
-            jGP.update_cholesky()                                # :145-206 -> full (F4)
-            census["lowrank_as_full"] += 1
+            # :145-206.  e = position of max(j.obs) in the main leaf's list; toupdate = main.obs[1:e] \ j.obs (:170);
+            # j.obs is a subset of main.obs[1:e], so |toupdate| = e - |j.obs|
+            e = int(np.searchsorted(li.obs, lj.obs[-1])) + 1
+            ndel = e - lj.nobs
+            jGP.update_cholesky()                                # every arm of the branch -> full here
+            if ndel / lj.nobs < tau:                             # :173
+                if ndel > 0:                                     # row deletions (:179-187): defective (F4)
+                    census["lowrank_as_full"] += 1
+                    census["lowrank_leaves"].append(int(j))
+                else:                                            # nothing to delete: leading block of the main factor
+                    census["leading_as_full"] += 1
+                    census["leading_leaves"].append(int(j))
+            else:
+                census["full"] += 1                              # :203-205
         else:
             jGP.update_cholesky()                                # :124-130
             census["full"] += 1
+    census["lowrank_leaves"].sort()
+    census["leading_leaves"].sort()
     return census
+
+
+class _NoGP:
+    """Stand-in leaf for fit(census_only=True): every numerical step is a no-op."""
+    factors = alpha = None
+    info = 0
+
+    def update_cholesky(self):
+        return self
 
 
 def _fit_superset(jGP, lj, mainGP, li, tau, census):
@@ -143,9 +176,13 @@ def _fit_superset(jGP, lj, mainGP, li, tau, census):
         census["full"] += 1
         return
     if (len(toupdate) / lj.nobs) < tau:                          # :256
-        if len(toupdate) > 0:
+        if len(toupdate) > 0:                                    # (cannot happen: D[main, j] = 1 puts main.obs inside s1)
             jGP.update_cholesky()                                # low-rank deletes -> full (F4)
             census["lowrank_as_full"] += 1
+            census["lowrank_leaves"].append(int(lj.leaf))
+            return
+        if isinstance(jGP, _NoGP):
+            census["prefix"] += 1
             return
         F = jGP.noisy_kernel()                                   # :218-230
         p = len(s1)

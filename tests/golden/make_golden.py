@@ -152,7 +152,7 @@ def config1():
     idx = np.concatenate([lf.obs for lf in model.leaves])
     np.savez_compressed(os.path.join(OUT, "config1.npz"), x=x, y=y, xt=xt, obs_ptr=ptr, obs_idx=idx,
                         leaf_mll=leaf_mll, root_mll=z, mu=mu, var=var,
-                        census=np.array([census[k] for k in ("full", "copy", "prefix", "lowrank_as_full")]))
+                        census=np.array([census[k] for k in ("full", "copy", "prefix", "lowrank_as_full", "leading_as_full")]))
     print("config1: L =", model.L, "census", census, "root mll", z)
 
 

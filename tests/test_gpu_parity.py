@@ -199,6 +199,13 @@ def test_config1_readme_example(golden_dir):
     m = dsm.buildDSMGP(X, y, 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(float(np.mean(X))), seed=11)
     assert np.count_nonzero(m.share_op == ptree.SHARE_COPY) == z["census"][1] > 0
     assert np.count_nonzero(m.share_op == ptree.SHARE_PREFIX) == z["census"][2] > 0
+    # the census of the reference's fit! arms rides on fit's return value and stays on the model: equal to the fixture
+    # (generated by the oracle's fit) and to the oracle's census walk
+    assert [m.fit_census[k] for k in ptree.BRANCH_NAMES] == z["census"].tolist()
+    assert m.fit_census == ospn.fit(m.root, None, ospn.get_overlap(m.root, m.L), 0.05, census_only=True)
+    assert m.fit_census["lowrank_leaves"] == [] and len(m.fit_census["leading_leaves"]) == z["census"][4] > 0
+    assert dsm.fit(m, tau=0.5).census["lowrank_as_full"] > 0          # with a generous tau the row-deletion arm would fire
+    dsm.fit(m)
     assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=RTOL, atol=1e-9)
     zroot = dsm.update(m)
     assert abs(zroot - float(z["root_mll"])) <= RTOL * abs(float(z["root_mll"]))
@@ -514,7 +521,13 @@ def test_config4_headline_size_sampled_against_oracle_and_properties():
     import bench
     model, X, y, Xt, ptr, idx = bench.build_model("dsmgp_n100k_d8", 0, 1, 0)
     assert model.L == 144
-    dsm.fit(model)
+    sec = dsm.fit(model)
+    # census of the reference's fit! arms, surfaced by fit (index work: exact): the oracle's walk over the same decisions
+    # gives the same counts and the same leaves for the arms this implementation computes in full
+    cen = ospn.fit(model.root, None, model.D, 0.05, census_only=True)
+    assert sec.census == model.fit_census == cen and sum(cen[k] for k in ptree.BRANCH_NAMES) == 144
+    assert np.count_nonzero(model.share_op == ptree.SHARE_COPY) == cen["copy"]
+    assert np.count_nonzero(model.share_op == ptree.SHARE_PREFIX) <= cen["prefix"]     # a PREFIX source must be factorised in full
     z = dsm.update(model)
     mu, var = dsm.predict(model, Xt)
     nobs = np.array([lf.nobs for lf in model.leaves])

@@ -91,9 +91,33 @@ def test_overlap_schedule_and_routing_match_the_oracle(golden_dir):
     mr = dsm.buildDSMGP(Xr, yr, 3, 4, M=25, kernel=dsm.IsoSE(0.0, 0.0), fit_now=False, seed=2)
     assert np.array_equal(mr.D, ospn.get_overlap(mr.root, mr.L))
     op, src, plen = ptree.share_schedule(m.leaves, m.D, 0.05)
-    full, copy, prefix, lowrank = z["census"]
+    full, copy, prefix, lowrank, leading = z["census"]
     assert np.count_nonzero(op == ptree.SHARE_COPY) == copy
     assert np.count_nonzero(op == ptree.SHARE_PREFIX) == prefix
+    # the census of the REFERENCE's fit! arms (index work: exact) -- product (share_decisions) == oracle (census walk and
+    # the real fit) == committed fixture, at the default tau, with sharing off and at a tau where row deletions fire
+    for tau in (0.05, 0.0, 0.5):
+        dec = ptree.share_decisions(m.leaves, m.D, tau)
+        assert all(np.array_equal(a, b) for a, b in zip(dec[:3], ptree.share_schedule(m.leaves, m.D, tau)))
+        cen = ptree.share_census(dec[3])
+        assert cen == ospn.fit(m.root, None, D_or, tau, census_only=True)
+        assert sum(cen[k] for k in ptree.BRANCH_NAMES) == m.L
+        if tau == 0.05:
+            assert [cen[k] for k in ptree.BRANCH_NAMES] == [full, copy, prefix, lowrank, leading]
+            gps = ospn.make_leaf_gps(m.root, x.reshape(-1, 1), y, exact_dist=True)
+            assert cen == ospn.fit(m.root, gps, D_or, tau)
+        if tau == 0.5:
+            assert cen["lowrank_as_full"] > 0 and len(cen["lowrank_leaves"]) == cen["lowrank_as_full"]
+            for j in cen["lowrank_leaves"]:      # a strict subset of its main leaf's list, rows to delete before its last row
+                assert op[j] == ptree.SHARE_FULL
+    # the model carries the census of its last fit; fit_naive! has nothing to share
+    mo = dsm.buildDSMGP(x.reshape(-1, 1), y, 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(float(np.mean(x))),
+                        seed=11, fit_now=False, ctx=OracleContext())
+    sec = dsm.fit(mo)
+    assert isinstance(sec, float) and sec.census == mo.fit_census == ptree.share_census(ptree.share_decisions(m.leaves, m.D, 0.05)[3])
+    assert np.array_equal(mo.share_branch == ptree.BRANCH_LEADING, np.isin(np.arange(mo.L), sec.census["leading_leaves"]))
+    dsm.fit_naive(mo)
+    assert mo.fit_census["full"] == mo.L and mo.fit_census["lowrank_leaves"] == []
     for j in np.flatnonzero(op == ptree.SHARE_COPY):
         assert np.array_equal(m.leaves[j].obs, m.leaves[src[j]].obs) and op[src[j]] == ptree.SHARE_FULL
     for j in np.flatnonzero(op == ptree.SHARE_PREFIX):
@@ -437,6 +461,8 @@ def _same_tree(a, b):
     if a.kind == "split":
         if a.split != b.split or not np.array_equal(a.lowerBound, b.lowerBound) or not np.array_equal(a.upperBound, b.upperBound):
             return False
+        if any(np.signbit(sa) != np.signbit(sb) for (_, sa), (_, sb) in zip(a.split, b.split)):   # 0.0 == -0.0: compare the bit too
+            return False
     elif not np.array_equal(a.logweights, b.logweights) or a.of_gps != b.of_gps:
         return False
     return all(_same_tree(x, y) for x, y in zip(a.children, b.children))
@@ -462,6 +488,14 @@ def test_native_tree_builder_equals_the_interpreted_builder_bit_for_bit():
         b = ptree.build_tree(X, y, cfg(), seed=11 + i, native=False)
         assert len(ptree.get_leaves(a)) == len(ptree.get_leaves(b)) > 1
         assert _same_tree(a, b), i
+    # columns holding both signed zeros (rounded small negatives) with median cuts (bnoise = 0): which zero a selection
+    # returns is not defined, so both builders canonicalise the median to +0.0 -- thresholds agree in the sign bit too
+    for seed in range(12):
+        X = np.round(uniform(300 + seed, 0, 1200 * 2).reshape((1200, 2), order="F") - 0.5, 1)
+        assert np.any(np.signbit(X) & (X == 0)) and np.any(~np.signbit(X) & (X == 0))
+        y = normal(400 + seed, 0, 1200)
+        cfg = lambda: ptree.DSMGPConfig(None, dsm.IsoSE(0, 0), 1.0, 25, 4, 1, 2, 0.0, False)  # noqa: E731
+        assert _same_tree(ptree.build_tree(X, y, cfg(), seed=seed, native=True), ptree.build_tree(X, y, cfg(), seed=seed, native=False))
     # the committed leaf table of config 1 pins both builders
     z = np.load(os.path.join(ROOT, "tests", "golden", "config1.npz"))
     m = dsm.buildDSMGP(z["x"].reshape(-1, 1), z["y"], 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5), seed=11,

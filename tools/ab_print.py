@@ -3,7 +3,11 @@ import glob
 import json
 
 for f in sorted(glob.glob("gpurun_out/ab_*.json")):
-    d = json.load(open(f))
+    try:
+        d = json.load(open(f))
+    except Exception as e:
+        print(f, "unreadable:", e)
+        continue
     c = d["device_seconds_per_step"]
     keys = ("gram", "chol_update", "chol_reduce", "chol_diag", "chol_trsm", "total_fit")
     print(f, round(d["value"], 4), "frac", round(d["roofline"]["frac"], 4),
