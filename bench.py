@@ -27,7 +27,22 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r02_update_kernel_traffic.json"
+TRAFFIC_FILE = "r03_update_kernel_traffic.json"
+
+
+def source_stamp():
+    """sha256 over the sources that decide what the timed kernels do (bench.py, the HIP sources and the header): the PMC
+    traffic figure under profiles/ carries the stamp of the tree it was measured on, and is only quoted while it matches
+    the tree that runs (there is no .git on the GPU box to ask for a commit)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "include", "dsmgp_hip.h")]
+    csrc = os.path.join(ROOT, "deepstructuredmixtures_amd", "csrc")
+    files += sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".cpp", ".sh")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 F64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X public spec, fp64 matrix = fp64 vector; the in-container guide lists no fp64 figure
 
 CONFIGS = {
@@ -73,66 +88,80 @@ def default_sub(world):
 def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
     """Oracle ("port" of the reference's per-leaf arithmetic, LAPACK via SciPy) on a bounded sample of
     the same workload: whole leaves, lean form (one potrf per leaf, diag-only variance), timed on the
-    host cores and scaled to the full leaf table by the cost model n^3/3 + n^2 (n_t + 2)."""
+    host cores and scaled to the full leaf table by the cost model n^3/3 + n^2 (n_t + 2).  The sample always holds
+    the largest and the smallest leaf; one mid-size leaf is held out of the scaling and predicted by it (the model's
+    extrapolation error is part of the result); "as written" is timed on eight leaves."""
     from oracle import gp as ogp
     nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)
     nt = np.diff(ptr).astype(np.float64)
     cost = nobs ** 3 / 3 + nobs ** 2 * (nt + 2)
     order = np.argsort(nobs)
-    # sample spread over the size range: every q-th leaf by size, grown until the time budget is used
-    sample, spent, done_cost = [], 0.0, 0.0
+
+    def make(j):
+        lf = model.leaves[j]
+        return ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(lf.kernel.kind, lf.kernel.loghyp()),
+                                   lf.logNoise, exact_dist=False)
+
+    def lean(j):
+        t0 = time.perf_counter()
+        g = make(j).update_cholesky()
+        g.mll()
+        rows = idx[ptr[j]:ptr[j + 1]]
+        if rows.size:
+            g.prediction(Xt[rows])
+        return time.perf_counter() - t0
+
+    lean(int(order[0]))                                     # untimed: BLAS thread pool start-up, page faults
+    held = int(order[len(order) // 2])                      # held out: predicted by the scaling, then measured
+    times = {}
+    spent = 0.0
+    picks = [int(order[-1]), int(order[0])]                 # the largest leaf (3 % of the flops at the headline config) first
     for q in (16, 8, 4, 2):
-        for j in order[q // 2::q]:
-            if j in sample:
-                continue
-            lf = model.leaves[j]
-            t0 = time.perf_counter()
-            g = ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(lf.kernel.kind, lf.kernel.loghyp()),
-                                    lf.logNoise, exact_dist=False).update_cholesky()
-            g.mll()
-            rows = idx[ptr[j]:ptr[j + 1]]
-            if rows.size:
-                g.prediction(Xt[rows])
-            spent += time.perf_counter() - t0
-            done_cost += cost[j]
-            sample.append(int(j))
-            if spent > budget_s:
-                break
+        picks += [int(j) for j in order[q // 2::q]]
+    for j in picks:
+        if j in times or j == held:
+            continue
+        times[j] = lean(j)
+        spent += times[j]
         if spent > budget_s:
             break
+    sample = list(times)
+    done_cost = float(sum(cost[j] for j in sample))
     est = spent * cost.sum() / done_cost
+    t_held = lean(held)
+    pred_held = spent * cost[held] / done_cost
     try:
         import threadpoolctl
         threads = max([p["num_threads"] for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
         threads = os.cpu_count() or 1
     # "as written" (SURVEY 8(d)): the reference factorises every leaf twice per fit! (F3), forms the full K_tt and
-    # V^T V in prediction and predicts in two passes (F10).  Timed on three sampled leaves against the lean form of
-    # the same leaves; the ratio scales the lean estimate.  Informative only -- the lean figure is the baseline.
-    lean3 = written3 = 0.0
-    for j in sample[:3]:
-        lf = model.leaves[j]
+    # V^T V in prediction and predicts in two passes (F10).  Timed on the eight cheapest sampled leaves against the lean
+    # form of the same leaves; the ratio scales the lean estimate.  Informative only -- the lean figure is the baseline.
+    lean8 = written8 = 0.0
+    eight = sorted(sample, key=lambda j: cost[j])[:8]
+    for j in eight:
         rows = idx[ptr[j]:ptr[j + 1]]
-        mk = lambda: ogp.GaussianProcess(X[lf.obs], y[lf.obs], lf.mean.m, ogp.make_kernel(lf.kernel.kind, lf.kernel.loghyp()),  # noqa: E731
-                                         lf.logNoise, exact_dist=False)
+        lean8 += times[j]
         t0 = time.perf_counter()
-        g = mk().update_cholesky()
-        g.mll()
-        g.prediction(Xt[rows])
-        lean3 += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        g = mk().update_cholesky().update_cholesky()
+        g = make(j).update_cholesky().update_cholesky()
         g.mll()
         g.prediction(Xt[rows], full_cov=True)
         g.prediction(Xt[rows], full_cov=True)
-        written3 += time.perf_counter() - t0
+        written8 += time.perf_counter() - t0
+    by_size = sorted(sample, key=lambda j: nobs[j])
     return {"value": est, "unit": "s", "cores": int(threads), "kind": "port",
-            "sample": f"{len(sample)} of {model.L} leaves (n={int(nobs[sample].min())}..{int(nobs[sample].max())}) "
-                      f"timed {spent:.1f} s with the NumPy/LAPACK oracle, one potrf per leaf + alpha + diag-only predict; "
+            "sample": f"{len(sample)} of {model.L} leaves (n={int(nobs[sample].min())}..{int(nobs[sample].max())}, the largest leaf "
+                      f"included) timed {spent:.1f} s with the NumPy/LAPACK oracle, one potrf per leaf + alpha + diag-only predict; "
                       f"scaled by (n^3/3 + n^2(n_t+2)) to all leaves",
-            "as_written_value": est * written3 / lean3,
+            "per_leaf_gflops": [{"n": int(nobs[j]), "seconds": round(times[j], 4), "gflops": round(cost[j] / times[j] / 1e9, 1)}
+                                for j in by_size],
+            "held_out_leaf": {"n": int(nobs[held]), "measured_s": t_held, "predicted_s": pred_held,
+                              "relative_error": (pred_held - t_held) / t_held},
+            "as_written_value": est * written8 / lean8,
             "as_written_note": f"two factorisations per leaf, full predictive covariance, two predict passes: "
-                               f"{written3 / lean3:.2f}x the lean form on 3 sampled leaves ({lean3:.1f} s vs {written3:.1f} s)"}
+                               f"{written8 / lean8:.2f}x the lean form on the {len(eight)} cheapest sampled leaves "
+                               f"({lean8:.1f} s vs {written8:.1f} s)"}
 
 
 def bench_train(args, model, X, y, rank, world, td, torch):
@@ -299,7 +328,15 @@ def main():
     else:
         n_sub = args.sub if args.sub is not None else default_sub(world)
         model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
-    ctx = model.ctx
+    try:
+        ctx = model.ctx
+    except Exception as e:      # a sub-context failed to come up (several HIP contexts per GPU next to the process group):
+        if n_sub <= 1:          # fall back to one context per GPU and say so
+            raise
+        print(f"# rank {rank}: {n_sub} contexts per GPU failed ({e}); falling back to one", file=sys.stderr)
+        n_sub = 1
+        model._n_sub, model._ctx = 1, None
+        ctx = model.ctx
     if args.unfused_gram:
         ctx.set_option(dsm.hipabi.OPT_FUSED_GRAM, 0)
     if args.mode == "train":
@@ -363,9 +400,16 @@ def main():
         tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath) and world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard:
             # PMC counters cannot be collected inside this run: the figure is the one of the committed rocprofv3 --pmc
-            # passes of this same command (tools/profile_round.sh), NOT a measurement of this run
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            traffic_source = f"profiles/{TRAFFIC_FILE} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
+            # passes of this same command (tools/profile_round.sh), NOT a measurement of this run -- and it is quoted only
+            # while the sources it was taken on are the sources that run now
+            tj = json.load(open(tpath))
+            if tj.get("source_stamp") == source_stamp():
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = (f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command on this source tree, stamp "
+                                  f"{tj['source_stamp']}, commit {tj.get('commit', '?')}; not measured in this run)")
+            else:
+                traffic_source = (f"profiles/{TRAFFIC_FILE} is stale: taken on source stamp {tj.get('source_stamp')}, "
+                                  f"this tree is {source_stamp()}")
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along, each task "
@@ -411,7 +455,8 @@ def main():
                                    f"n_t={Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; "
                                    f"fit! (Gram+Cholesky+forward solve+mll) + update! + predict",
                        "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and of the aggregation's partial sums"
-                                      + (f"; {n_sub} concurrent contexts per GPU" if n_sub > 1 else "")},
+                                      + (f"; {n_sub} concurrent contexts per GPU" if n_sub > 1 else "")
+                                      + (f"; exchange: {model.shard.exchange}" if world > 1 else "")},
             "matrix_tflops_fit_predict": matrix_flops_total / ((cats.get("total_fit", 0.0) + cats.get("total_predict", 0.0))
                                                                / args.steps) / 1e12 if world == 1 else None,
             "device_seconds_per_step": {k: v / args.steps for k, v in cats.items() if v > 0},

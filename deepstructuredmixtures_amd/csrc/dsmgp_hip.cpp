@@ -6,6 +6,7 @@
 #include "../../include/dsmgp_hip_diag.h"
 #endif
 #include "kernels.hpp"
+#include "kernels_fused.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -72,6 +73,10 @@ struct StepLists {
     DevBuf<TileTask> upd, trsm;
     DevBuf<ReduceTask> red;
     DevBuf<DiagTask> diag;
+    // steps with more diagonal blocks than CUs run fused (kernels_fused.hpp): diag_fused_kernel, then tile_fused_kernel
+    std::vector<int> fdiag_off, ftile_off;                   // size nsteps+1; a fused step has no classic tasks and vice versa
+    DevBuf<DiagFusedTask> fdiag;
+    DevBuf<FusedTask> ftile;
     int nsteps = 0;
 };
 
@@ -322,6 +327,8 @@ struct dsmgp_ctx {
 
     DevBuf<GramTask> gram;          // Gram launch of fit!: every lower tile, or (fused) the tiles no update task writes
     bool fuse_gram = true;          // update tasks of fit! evaluate the Gram values of their tile themselves (TileTask.gram)
+    bool fuse_steps = true;         // block steps with more diagonal blocks than CUs run as two fused launches (kernels_fused.hpp)
+    std::vector<char> fused_step[2];   // per phase and block step: the step runs fused (decided by build_plan)
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
     // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
@@ -505,6 +512,8 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.trsm.p);
         dev_free(ph.red.p);
         dev_free(ph.diag.p);
+        dev_free(ph.fdiag.p);
+        dev_free(ph.ftile.p);
     }
     arena_put(c, c->slabF);
     dev_free(c->fwd.p);
@@ -549,6 +558,8 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.trsm.p);
         dev_free(ph.red.p);
         dev_free(ph.diag.p);
+        dev_free(ph.fdiag.p);
+        dev_free(ph.ftile.p);
     }
     arena_put(c, c->slabJ);
     c->joint_ready = false;
@@ -688,10 +699,14 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.nsteps = nsteps;
         std::vector<TileTask> trsm;
         std::vector<DiagTask> diag;
+        std::vector<FusedTask> ftile;
+        std::vector<DiagFusedTask> fdiag;
         S.upd_off.assign(nsteps + 1, 0);
         S.red_off.assign(nsteps + 1, 0);
         S.trsm_off.assign(nsteps + 1, 0);
         S.diag_off.assign(nsteps + 1, 0);
+        S.fdiag_off.assign(nsteps + 1, 0);
+        S.ftile_off.assign(nsteps + 1, 0);
         S.step_tiles.assign(nsteps, 0);
         S.pad.assign(nsteps, 0);
         for (int k = 0; k < nsteps; ++k) {
@@ -699,6 +714,9 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             S.red_off[k] = (int)U.red.size();
             S.trsm_off[k] = (int)trsm.size();
             S.diag_off[k] = (int)diag.size();
+            S.fdiag_off[k] = (int)fdiag.size();
+            S.ftile_off[k] = (int)ftile.size();
+            const bool fstep = k < (int)c->fused_step[ph].size() && c->fused_step[ph][k] != 0;
             std::vector<TileTask> tiles;
             size_t nsym = 0;
             for (int l = 0; l < L; ++l) {
@@ -711,6 +729,30 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                     const int i_first = (k < lf.kb) ? lf.kb : k;
                     const bool own_diag = (k >= lf.kb);
                     for (int i = i_first; i < lf.nb; ++i) {
+                        if (fstep) {      // fused step: the diagonal tile belongs to the diagonal-block task, the tiles below
+                            if (i == k) continue;                                  // are updated and solved in one task each
+                            FusedTask f{};
+                            f.A = d.F + (size_t)i * TB;
+                            f.B = d.F + (size_t)k * TB;
+                            f.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
+                            f.Dinv = d.Dinv + (size_t)k * TB * TB;
+                            f.lda = f.ldb = f.ldc = ld;
+                            f.k1 = k * TB;
+                            f.gxa = d.Xg + (size_t)i * TB;
+                            f.gxb = d.Xg + (size_t)k * TB;
+                            f.glda = f.gldb = ld;
+                            f.gna = std::max(0, std::min(TB, lf.n - i * TB));
+                            f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                            f.kid = lf.kid;
+                            f.mrows = tile_mrows(lf.n - i * TB);
+                            f.zpad = 1;
+                            if (ph == 0) {
+                                f.zk = d.z + (size_t)k * TB;
+                                f.wi = d.w + (size_t)i * TB;
+                            }
+                            ftile.push_back(f);
+                            continue;
+                        }
                         if (k > 0) {
                             TileTask u{};
                             u.A = d.F + (size_t)i * TB;
@@ -765,12 +807,49 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         g.ld = ld;
                         g.nvalid = std::max(0, std::min(TB, lf.n - k * TB));
                         g.row0 = k * TB;
-                        diag.push_back(g);
+                        if (fstep) {
+                            DiagFusedTask fg{};
+                            fg.d = g;
+                            fg.A = d.F + (size_t)k * TB;
+                            fg.gx = d.Xg + (size_t)k * TB;
+                            fg.k1 = k * TB;
+                            fg.glda = ld;
+                            fg.kid = lf.kid;
+                            fdiag.push_back(fg);
+                        } else {
+                            diag.push_back(g);
+                        }
                     }
                 }
                 if (with_test && lf.nt > 0) {
                     for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
                         double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
+                        if (fstep) {
+                            FusedTask f{};
+                            f.A = d.Vt + (size_t)ti * TB;
+                            f.B = d.F + (size_t)k * TB;
+                            f.C = tile;
+                            f.Dinv = d.Dinv + (size_t)k * TB * TB;
+                            f.lda = lf.ntpad;
+                            f.ldb = ld;
+                            f.ldc = lf.ntpad;
+                            f.k1 = k * TB;
+                            f.gxa = d.Xtg + (size_t)ti * TB;
+                            f.gxb = d.Xg + (size_t)k * TB;
+                            f.glda = lf.ntpad;
+                            f.gldb = ld;
+                            f.gna = std::max(0, std::min(TB, lf.nt - ti * TB));
+                            f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                            f.kid = lf.kid;
+                            f.mrows = tile_mrows(lf.nt - ti * TB);
+                            if (d.zfused) {
+                                f.zk = d.z + (size_t)k * TB;
+                                f.wi = d.macc + (size_t)ti * TB;
+                                f.sq = d.sacc + (size_t)ti * TB;
+                            }
+                            ftile.push_back(f);
+                            continue;
+                        }
                         if (k > 0) {
                             TileTask u{};
                             u.A = d.Vt + (size_t)ti * TB;
@@ -840,14 +919,20 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 // model's panel-solve launches fetched 2.6x their tile bytes)
                 std::vector<int> unused(trsm.size());
                 xcd_permute(trsm, unused, (size_t)S.trsm_off[k], trsm.size(), c->xcd_order);
+                std::vector<int> unused2(ftile.size());      // fused tiles of a leaf share its B panel and Dinv_k
+                xcd_permute(ftile, unused2, (size_t)S.ftile_off[k], ftile.size(), c->xcd_order);
             }
         }
         S.upd_off[nsteps] = (int)U.upd.size();
         S.red_off[nsteps] = (int)U.red.size();
         S.trsm_off[nsteps] = (int)trsm.size();
         S.diag_off[nsteps] = (int)diag.size();
+        S.fdiag_off[nsteps] = (int)fdiag.size();
+        S.ftile_off[nsteps] = (int)ftile.size();
         if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
+        if (int rc = dev_upload(c, S.fdiag, fdiag)) return rc;
+        if (int rc = dev_upload(c, S.ftile, ftile)) return rc;
     }
     {
         const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
@@ -960,13 +1045,35 @@ int build_plan(dsmgp_ctx* c) {
         HIPCHK(c, hipGetLastError());
     }
 
+    // Which block steps run fused (kernels_fused.hpp): those whose diagonal blocks alone fill the chip -- the same rule
+    // as the choice of the packed diagonal-block kernel, so a step factorises its blocks with the same code either way
+    for (int ph = 0; ph < 2; ++ph) {
+        int ns = 0;
+        for (const LeafHost& lf : c->leaves)
+            if ((lf.op == DSMGP_SHARE_PREFIX) == (ph == 1)) ns = std::max(ns, lf.nb);
+        c->fused_step[ph].assign(ns, 0);
+        if (!c->fuse_steps || !gram_fused(c)) continue;
+        for (int k = 0; k < ns; ++k) {
+            int nd = 0;
+            for (int l = 0; l < L; ++l) {
+                const LeafHost& lf = c->leaves[l];
+                if ((lf.op == DSMGP_SHARE_PREFIX) == (ph == 1) && lf.owner == l && lf.nb > k && k >= lf.kb) ++nd;
+            }
+            c->fused_step[ph][k] = nd > c->ncu ? 1 : 0;
+        }
+    }
     // Gram tasks: lower tiles of every owner; with the Gram fused into the update tasks only the tiles that have none --
-    // block column 0 (a PREFIX leaf: below the blocks it copies from its source; the copied blocks need no Gram at all)
+    // block column 0 (a PREFIX leaf: below the blocks it copies from its source; the copied blocks need no Gram at all),
+    // and none at all where step 0 runs fused (its tasks start from the kernel function)
     std::vector<GramTask> gram;
     const bool fused = gram_fused(c);
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
         if (lf.owner != l) continue;
+        {
+            const std::vector<char>& fs = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
+            if (fused && !fs.empty() && fs[0]) continue;
+        }
         const LeafDev& d = c->h_leaves[l];
         for (int j = 0; j < (fused ? 1 : lf.nb); ++j)
             for (int i = (fused ? std::max(j, lf.kb) : j); i < lf.nb; ++i) {
@@ -1162,6 +1269,23 @@ struct PhaseTimer {
 // One factorisation phase: for every block step, update (-> split-K reduce) -> diagonal -> panel solve.
 int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
     for (int k = 0; k < S.nsteps; ++k) {
+        const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
+        if (nfd > 0 || nft > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
+            if (nfd > 0) {
+                pt.begin(2);
+                diag_fused_kernel<<<nfd, 256, DIAGP_LDS_BYTES, c->stream>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
+                pt.note(k, nfd, 0);
+                pt.end();
+            }
+            if (nft > 0) {
+                pt.begin(1);
+                tile_fused_kernel<<<nft, 256, 0, c->stream>>>(S.ftile.p + S.ftile_off[k], c->d_kp, c->D);
+                pt.note(k, nft, nft);
+                pt.end();
+                if (count_launches) c->n_update_launches++;
+            }
+            continue;
+        }
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
         if (nu > 0) {
             pt.begin(1);
@@ -1242,6 +1366,8 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(diag_fused_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1313,6 +1439,15 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
             free_test(c);
         }
         c->fuse_gram = value != 0;
+        return 0;
+    }
+    if (option == DSMGP_OPT_FUSED_STEPS) {
+        if ((value != 0) != c->fuse_steps) {
+            HIPCHK(c, hipSetDevice(c->device));
+            free_plan(c);
+            free_test(c);
+        }
+        c->fuse_steps = value != 0;
         return 0;
     }
     return fail(c, DSMGP_E_ARG, "set_option: unknown option");
@@ -1739,9 +1874,13 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
             if (lf.nt == 0) continue;
+            // where step 0 runs fused, the tasks of block column 0 evaluate their K_tn tile themselves.  A COPY leaf rides
+            // with its source's phase (phase 0: a source is factorised in full)
+            const std::vector<char>& fs = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
+            const bool step0_fused = gram_fused(c) && !fs.empty() && fs[0];
             for (int ti = 0; ti < lf.ntpad / TB; ++ti)
                 for (int j = 0; j < lf.nb; ++j, ++q)
-                    if (j == 0) pg0.push_back(pg[q]);
+                    if (j == 0 && !step0_fused) pg0.push_back(pg[q]);
         }
         if (int rc = dev_upload(c, c->pgram0, pg0)) return rc;
     }
@@ -2795,6 +2934,86 @@ int dsmgp_allgather(dsmgp_ctx* c, const double* send, int64_t count, double* rec
     const int rc = g_rccl.AllGather(c->d_xchg, c->d_xchg + n, n, NCCL_FLOAT64, c->comm, c->stream);
     if (rc != 0) return fail(c, DSMGP_E_HIP, "ncclAllGather: " + g_rccl.what(rc));
     HIPCHK(c, hipMemcpyAsync(recv, c->d_xchg + n, n * (size_t)c->comm_world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+namespace {
+// all-gather of `n` doubles per rank, device to device on the context's stream: d_xchg = [send n | recv world * n]
+int xchg_reserve(dsmgp_ctx* c, size_t n) {
+    const size_t need = n * (size_t)(c->comm_world + 1);
+    if (need > c->xchg_cap) {
+        dev_free(c->d_xchg);
+        HIPCHK(c, hipMalloc(&c->d_xchg, need * sizeof(double)));
+        c->xchg_cap = need;
+    }
+    return 0;
+}
+int xchg_gather(dsmgp_ctx* c, size_t n) {
+    const int rc = g_rccl.AllGather(c->d_xchg, c->d_xchg + n, n, NCCL_FLOAT64, c->comm, c->stream);
+    if (rc != 0) return fail(c, DSMGP_E_HIP, "ncclAllGather: " + g_rccl.what(rc));
+    return 0;
+}
+}  // namespace
+
+int dsmgp_fit_exchange(dsmgp_ctx* c, int64_t count, double* out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->comm) return fail(c, DSMGP_E_STATE, "fit_exchange before comm_init");
+    if (!out || count <= 0 || count < c->L) return fail(c, DSMGP_E_ARG, "fit_exchange: count must cover this rank's leaves");
+    if (c->L > 0 && !c->fitted) return fail(c, DSMGP_E_STATE, "fit_exchange before fit");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = 2 * (size_t)count;
+    if (int rc = xchg_reserve(c, n)) return rc;
+    if (c->L > 0) {
+        // info lives per factor owner: the owner table goes up once per call (L ints)
+        std::vector<int> owner(c->L);
+        for (int l = 0; l < c->L; ++l) owner[l] = c->leaves[l].owner;
+        int* d_owner = nullptr;
+        HIPCHK(c, hipMalloc(&d_owner, (size_t)c->L * sizeof(int)));
+        HIPCHK(c, hipMemcpyAsync(d_owner, owner.data(), (size_t)c->L * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        pack_mll_info_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(c->d_mll, c->d_info, d_owner, c->L, count, c->d_xchg);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // owner is stack storage
+        (void)hipFree(d_owner);
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->d_xchg, 0, n * sizeof(double), c->stream));
+    }
+    if (int rc = xchg_gather(c, n)) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_xchg + n, n * (size_t)c->comm_world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dsmgp_aggregate_exchange(dsmgp_ctx* c, double* total_out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->comm) return fail(c, DSMGP_E_STATE, "aggregate_exchange before comm_init");
+    if (!c->agg_partial_ready) return fail(c, DSMGP_E_STATE, "aggregate_exchange before aggregate_partial");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->agg_W * (size_t)c->n_t;
+    if (int rc = xchg_reserve(c, n)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_xchg, c->d_agg_part, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (int rc = xchg_gather(c, n)) return rc;
+    sum_ranks_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->d_xchg + n, c->comm_world, (int64_t)n, c->d_agg_part);
+    HIPCHK(c, hipGetLastError());
+    if (total_out) HIPCHK(c, hipMemcpyAsync(total_out, c->d_agg_part, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dsmgp_aggregate_exchange_empty(dsmgp_ctx* c, int32_t W, int64_t n_t, double* total_out) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->comm) return fail(c, DSMGP_E_STATE, "aggregate_exchange before comm_init");
+    if (W <= 0 || n_t <= 0) return fail(c, DSMGP_E_ARG, "aggregate_exchange_empty: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)W * (size_t)n_t;
+    if (int rc = xchg_reserve(c, n)) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_xchg, 0, n * sizeof(double), c->stream));
+    if (int rc = xchg_gather(c, n)) return rc;
+    if (total_out) {
+        sum_ranks_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->d_xchg + n, c->comm_world, (int64_t)n, c->d_xchg);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(total_out, c->d_xchg, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -1807,9 +1807,9 @@ struct PackedMap {
 };
 __constant__ const PackedMap PACKED{};
 
-__global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* __restrict__ tasks) {
-    extern __shared__ __attribute__((aligned(16))) double S[];   // image [64 cols][PLD rows] + rhs[128] + int off[64]
-    const DiagTask tk = tasks[blockIdx.x];
+// have_image: the caller has already put the lower blocks of the tile into the image (diag_fused_kernel: straight from
+// the accumulators of the tile's update); the barrier below makes them visible
+__device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double* S, bool have_image) {
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
     if (t < 64) soff[t] = mytab;
     auto off = [&](int I, int K) { return __builtin_amdgcn_readlane(mytab, I * 8 + K); };
 
-    {   // lower blocks of the tile -> image: 9 blocks per wave, a lane moves four rows of one column of a block
+    if (!have_image) {   // lower blocks of the tile -> image: 9 blocks per wave, a lane moves four rows of one column of a block
         const int bc = lane >> 2, br = 4 * (lane & 3);
         d2 v[9][2];
 #pragma unroll
@@ -2036,6 +2036,12 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
         }
     }
     if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
+}
+
+__global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* __restrict__ tasks) {
+    extern __shared__ __attribute__((aligned(16))) double S[];   // image [64 cols][PLD rows] + rhs[128] + z[128] + int off[64]
+    const DiagTask tk = tasks[blockIdx.x];
+    chol_diag_packed_body(tk, S, false);
 }
 
 #ifdef DSMGP_DIAG
@@ -2501,6 +2507,24 @@ __global__ __launch_bounds__(256) void agg_scores_kernel(const double* __restric
         out[3 * (size_t)blockIdx.x + 1] = red[1][0];
         out[3 * (size_t)blockIdx.x + 2] = red[2][0];
     }
+}
+
+// Multi-GPU exchange helpers (dsmgp_fit_exchange / dsmgp_aggregate_exchange): pack (mll, info) of the local leaves, and add
+// the gathered partial sums in rank order -- a fixed order, so every rank ends with the same bits
+__global__ void pack_mll_info_kernel(const double* __restrict__ mll, const int* __restrict__ info, const int* __restrict__ owner,
+                                     int L, int64_t count, double* __restrict__ out) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= count) return;
+    out[2 * l] = l < L ? mll[l] : 0.0;
+    out[2 * l + 1] = l < L ? (double)info[owner[l]] : 0.0;
+}
+
+__global__ void sum_ranks_kernel(const double* __restrict__ gathered, int world, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = gathered[i];
+    for (int r = 1; r < world; ++r) s += gathered[(size_t)r * n + i];
+    out[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,468 @@
+// Fused block step of the batched Cholesky for launches with MANY leaves (the small-leaf regime: depth >= 3 trees, PoE
+// models), gfx950 only.  The classic step of kernels.hpp is three launches that pass every tile of the block column
+// through memory twice more than necessary:
+//     update  F[i,k] = K(i,k) - F[i,0:K] F[k,0:K]^T     (write the tile)
+//     diag    L_kk, Dinv_k                               (read the diagonal tile, write it and its inverse)
+//     solve   F[i,k] = F[i,k] Dinv_k^T                   (read the tile, write it again)
+// which is what a launch of a few hundred tiles needs -- every tile of the step in ONE launch, the diagonal block on the
+// chain of dependent launches kept as short as possible.  With thousands of leaves the diagonal tiles of a step fill the
+// chip by themselves, so the step is reordered (src/AdvancedCholeskey.jl:161-171 does the same per leaf: the diagonal
+// block first, then the panel below it):
+//     diag_fused_kernel   per leaf: S = K(k,k) - F[k,0:K] F[k,0:K]^T (lower blocks, straight into the LDS image),
+//                         L_kk = chol(S), z_k, Dinv_k               -- the tile never exists unfactorised in memory
+//     tile_fused_kernel   per tile below: C = K(i,k) - F[i,0:K] F[k,0:K]^T stays in the accumulators, which ARE the
+//                         second operand of the solve (register r of a 16x16 result = k-slab r of the operand);
+//                         X = C Dinv_k^T with Dinv_k's 36 lower blocks staged once in LDS; the tile is written once
+// Two launches per step, no Gram launch for block column 0 (K = 0: the tasks start at the kernel function), and at depth 4
+// about 60 GB of the 210 GB a fit moves are not moved.  The arithmetic is that of the classic step -- the products sum over
+// K chunk by chunk, the Gram values come from gram_accumulate / gram_finish, the solve sums over j in groups of four
+// ascending, the riders reduce inside a wave as in tile_trsm_kernel -- with one difference in ORDER: a tile below the
+// diagonal starts from -K(i,k) and accumulates the product on it (the kernel function is evaluated first, while the
+// accumulators are not yet live and the first operand loads are in flight) where the classic update subtracts the
+// finished product from K(i,k).  Diagonal blocks are bit-identical to the classic step's, tiles below agree to rounding
+// (test_fused_steps_agree_with_the_classic_steps).
+#pragma once
+#include <type_traits>
+#include "kernels.hpp"
+
+namespace dsmgp {
+
+struct FusedTask {
+    const double* A;      // row panel F[i, 0:K] (or the rows of K_tn L^-T so far), ld lda
+    const double* B;      // column panel F[k, 0:K], ld ldb
+    double* C;            // the tile, written once: (K(i,k) - A B^T) Dinv_k^T
+    const double* Dinv;   // inverse of the step's diagonal block (ld 128), from diag_fused_kernel of the same step
+    const double* zk;     // riders, as in TileTask: z_k (128) ...
+    double* wi;           // ... train rows: w_i -= X z_k; test rows (sq set): mu += X z_k.  NULL = none
+    double* sq;           // test rows: sum of squares of the solved row
+    const double* gxa;    // coordinates of the tile's rows, column-major [glda x D], offset to the first row
+    const double* gxb;    // ... of its columns
+    int lda, ldb, ldc, k1;        // K range [0, k1)
+    int glda, gldb, gna, gnb;     // valid rows / columns (<= 128)
+    int kid;
+    int mrows;            // rows that hold data, rounded up to 16; 0 = all 128.  <= 64: a wave takes 16 rows instead of 32
+    int zpad;             // tile of the factor: its padding rows are written here too (zeros)
+    int pad[3];
+};
+static_assert(sizeof(FusedTask) == 128, "FusedTask is read with scalar loads: keep it two cache lines");
+
+struct DiagFusedTask {
+    DiagTask d;           // the diagonal block: T (the tile of F), Dinv, wk / zk, info, ld, nvalid, row0
+    const double* A;      // F[k, 0:K]: the block row left of the tile, ld = d.ld
+    const double* gx;     // coordinates of the block's points, ld glda
+    int k1, glda, kid, pad;
+};
+
+// Row-split tile product: wave w owns the rows RW w .. RW w + RW - 1 (RW = 16 NRW: 32 for a whole tile, 16 for a tile of
+// at most 64 data rows) and ALL 128 columns, acc[8][NRW] -- whole rows of the tile in one wave are what the solve that
+// follows needs.  Ring, prefetch and barrier protocol of gemm_mainloop_v2; rows 64.. of the A panel are not staged for
+// NRW = 1.
+template <int NRW>
+__device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda, const double* B, int ldb, int K,
+                                                       d4 (&acc)[8][NRW], double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP]) {
+    // acc comes in initialised by the caller (-K(i,k): rowsplit_gram_init) and goes out as acc + A B^T
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    constexpr bool AHI = NRW > 1;
+    constexpr int NMEM_G = AHI ? 4 : 3;
+    constexpr int NFRAG = (8 + NRW + 1) / 2;
+    constexpr int NMFMA = 8 * NRW;
+    constexpr int NI_A = NMEM_G;
+    constexpr int NI_B = (NMFMA - NI_A) < NFRAG ? (NMFMA - NI_A) : NFRAG;
+    constexpr int NI_REST = NMFMA - NI_A - NI_B;
+    const int scol = t >> 5, srow = 2 * (t & 31);
+    const double* gA = A + srow + (size_t)scol * lda;
+    const double* gB = B + srow + (size_t)scol * ldb;
+    const int sOff = scol * LDP + srow;
+    const int rowoff = 16 * NRW * w + l15;
+    d2 ra0[2], rb0[2], ra1[2], rb1[2];
+#define FGLOAD(RA, RB, CH)                                                                       \
+    do {                                                                                         \
+        const size_t oa_ = (size_t)(CH) * KC2 * lda, ob_ = (size_t)(CH) * KC2 * ldb;             \
+        RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
+        if (AHI) RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                           \
+        RB[0] = *AS_GLOBAL_D2(gB + ob_);                                                         \
+        RB[1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                                    \
+    } while (0)
+#define FSWRITE(RA, RB, BUF)                                                                     \
+    do {                                                                                         \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA[0];                                          \
+        if (AHI) *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                            \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff]) = RB[0];                                          \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = RB[1];                                     \
+    } while (0)
+#define FFRAGS(FA, FB, BUF, G)                                                                   \
+    do {                                                                                         \
+        const double* pa_ = &sB[BUF][((G) * 4 + l4) * LDP + l15];                                \
+        const double* pb_ = &sA[BUF][((G) * 4 + l4) * LDP + rowoff];                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) FA[i_] = pa_[16 * i_];                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NRW; ++i_) FB[i_] = pb_[16 * i_];                \
+    } while (0)
+#define FMFMA(FA, FB)                                                                            \
+    do {                                                                                         \
+        _Pragma("unroll") for (int cb_ = 0; cb_ < 8; ++cb_)                                      \
+            _Pragma("unroll") for (int rn_ = 0; rn_ < NRW; ++rn_)                                \
+                acc[cb_][rn_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[cb_], FB[rn_], acc[cb_][rn_], 0, 0, 0); \
+    } while (0)
+#define FINTERLEAVE(MASK_A)                                                                      \
+    do {                                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI_A; ++i_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(MASK_A, 1, 0);                                  \
+        }                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < NI_B; ++i_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+        }                                                                                        \
+        if constexpr (NI_REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, NI_REST, 0);      \
+    } while (0)
+    const int nch = K / KC2;
+    if (nch > 0) {
+        FGLOAD(ra0, rb0, 0);
+        FGLOAD(ra1, rb1, min(1, nch - 1));
+        FSWRITE(ra0, rb0, 0);
+        FGLOAD(ra0, rb0, min(2, nch - 1));
+        FSWRITE(ra1, rb1, 1);
+        FGLOAD(ra1, rb1, min(3, nch - 1));
+        FSWRITE(ra0, rb0, 2);
+    }
+    __syncthreads();
+    double fa0[8], fb0[NRW], fa1[8], fb1[NRW];
+    if (nch > 0) FFRAGS(fa0, fb0, 0, 0);
+#define FCHUNK(C, LRA, LRB, WRA, WRB)                                                            \
+    do {                                                                                         \
+        const int c_ = (C);                                                                      \
+        const int buf_ = c_ & (NRING - 1);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        FGLOAD(LRA, LRB, min(c_ + 4, nch - 1));                                                  \
+        FFRAGS(fa1, fb1, buf_, 1);                                                               \
+        FMFMA(fa0, fb0);                                                                         \
+        FINTERLEAVE(0x020);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        FSWRITE(WRA, WRB, (c_ + 3) & (NRING - 1));                                               \
+        FFRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                                             \
+        FMFMA(fa1, fb1);                                                                         \
+        FINTERLEAVE(0x200);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __syncthreads();                                                                         \
+    } while (0)
+    int c = 0;
+    for (; c + 1 < nch; c += 2) {
+        FCHUNK(c, ra0, rb0, ra1, rb1);
+        FCHUNK(c + 1, ra1, rb1, ra0, rb0);
+    }
+    if (c < nch) FCHUNK(c, ra0, rb0, ra1, rb1);
+#undef FCHUNK
+#undef FINTERLEAVE
+#undef FMFMA
+#undef FFRAGS
+#undef FSWRITE
+#undef FGLOAD
+}
+
+// The 36 lower 16x16 blocks of Dinv_k in LDS, compact, block rows from the LAST one up -- block (cb, jb), jb <= cb, at
+// 256 (lower_block_base(cb) + jb) -- each column-major with leading dimension 16: the MFMA operand read (16 rows per k
+// column, four k columns per lane group) touches 64 consecutive doubles, conflict-free.  36 x 256 doubles = the ring's
+// 73,728 bytes exactly.  The solve runs from the last block column to the first, so the first half of this order (18
+// blocks: block rows 7, 6 and three blocks of row 5) is all it needs to start.
+__host__ __device__ constexpr int lower_block_base(int cb) { return (7 - cb) * (10 + cb) / 2; }   // sum_{c > cb} (c + 1)
+struct LowerBlocks {
+    unsigned char cb[36], jb[36];
+    constexpr LowerBlocks() : cb{}, jb{} {
+        int n = 0;
+        for (int c = 7; c >= 0; --c)
+            for (int j = 0; j <= c; ++j) {
+                cb[n] = (unsigned char)c;
+                jb[n] = (unsigned char)j;
+                ++n;
+            }
+    }
+};
+__constant__ const LowerBlocks LOWER_BLOCKS{};
+static_assert(lower_block_base(7) == 0 && lower_block_base(6) == 8 && lower_block_base(5) == 15 && lower_block_base(0) == 35, "block order");
+
+// acc <- -k(row, col) in the accumulator layout of gemm_mainloop_rowsplit (register q of acc[cb][rn] is the entry
+// (row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q)); the operations of gram_half_tile in its order (gram_accumulate /
+// gram_finish): the values the Gram launch would have written, negated.  The product is then accumulated ON it, so the
+// task starts with the kernel function -- under the memory latency of its first operand loads, with the accumulators not
+// yet live -- and the accumulators end as -(K - A B^T) = -C.
+template <int KIND, int NRW>
+__device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KParam& p, int D, d4 (&acc)[8][NRW], const double* sa,
+                                                      const double* sb) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int rowbase = 16 * NRW * w + l15;
+    const double* pa = sa + rowbase;
+    constexpr int CG = (NRW == 1) ? 2 : 1;      // column blocks per pass: 8 entries per lane and pass either way
+    constexpr int NJ = 4 * CG;
+#pragma unroll
+    for (int cp = 0; cp < 8 / CG; ++cp) {
+        const double* pb = sb + 16 * CG * cp + l4;
+        double z[NRW][NJ];
+#pragma unroll
+        for (int rn = 0; rn < NRW; ++rn)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) z[rn][j] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double a[NRW], b[NJ];
+#pragma unroll
+            for (int i = 0; i < NRW; ++i) a[i] = pa[d * TB + 16 * i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = pb[d * TB + 16 * (j >> 2) + 4 * (j & 3)];
+            gram_accumulate<KIND, NRW, NJ>(z, a, b, (KIND == 1) ? p.nh[d] : 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cidx = 16 * CG * cp + 16 * (j >> 2) + l4 + 4 * (j & 3);
+#pragma unroll
+            for (int rn = 0; rn < NRW; ++rn) {
+                acc[CG * cp + (j >> 2)][rn][j & 3] = -gram_finish<KIND, true>(z[rn][j], p, rowbase + 16 * rn, cidx, tk.gna, tk.gnb, false);
+            }
+        }
+    }
+}
+
+template <int NRW>
+__device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
+                                                const KParam* __restrict__ kp, int D) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // Dinv_k's 36 lower blocks go global (L2: the diagonal-block launch of this step wrote them) -> registers -> LDS in two
+    // halves of 9 loads per thread.  The first half is issued NOW and lands under the kernel-function arithmetic and the
+    // product; the second is issued when the first goes to LDS and lands under the first two block columns of the solve.
+    // Thread t moves the doubles 2 (t & 127), + 1 of block 2 e + (t >> 7).
+    const int dj = (t & 127) >> 3, di = 2 * (t & 7), dhalf = __builtin_amdgcn_readfirstlane(t >> 7);
+    auto dinv_load = [&](int e) {
+        const int b = 2 * e + dhalf;
+        const int cb = LOWER_BLOCKS.cb[b], jb = LOWER_BLOCKS.jb[b];
+        return *AS_GLOBAL_D2(tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB);
+    };
+    d2 dv[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) dv[e] = dinv_load(e);
+    d4 acc[8][NRW];
+    {   // acc = -k(row, col): coordinates through the (still unused) ring
+        const KParam p = kp[tk.kid];
+        double* sa = &sA[0][0];
+        double* sb = &sB[0][0];
+        for (int e = t; e < D * TB; e += 256) {
+            const int d = e >> 7, r = e & (TB - 1);
+            sa[e] = (r < tk.gna) ? tk.gxa[r + (size_t)d * tk.glda] : 0.0;
+            sb[e] = (r < tk.gnb) ? tk.gxb[r + (size_t)d * tk.gldb] : 0.0;
+        }
+        __syncthreads();
+        if (p.kind == 0) rowsplit_gram_init<0, NRW>(tk, p, D, acc, sa, sb);
+        else if (p.kind == 1) rowsplit_gram_init<1, NRW>(tk, p, D, acc, sa, sb);
+        else rowsplit_gram_init<2, NRW>(tk, p, D, acc, sa, sb);
+        __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
+    }
+    gemm_mainloop_rowsplit<NRW>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB);   // acc = -C; ends on a barrier: the ring is free
+    double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256
+    d2 dw[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) dw[e] = dinv_load(9 + e);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) *reinterpret_cast<d2*>(sD + (size_t)(2 * e + dhalf) * 256 + 2 * (t & 127)) = dv[e];
+    __syncthreads();
+    // -X = (-C) Dinv_k^T, column blocks from the right: X(:, cb) = sum_{jb <= cb} C(:, jb) Dinv(cb, jb)^T reads the blocks of
+    // C up to cb and is the last to read C(:, cb), whose registers it takes over.  The accumulators are the second operand
+    // as they stand: register q of C(:, jb) holds the columns 16 jb + l4 + 4 q = the k-slab q of the product.
+    auto solve_block_column = [&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        d4 x[NRW];
+#pragma unroll
+        for (int rn = 0; rn < NRW; ++rn) x[rn] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jb = 0; jb <= cb; ++jb) {
+            const double* blk = sD + (lower_block_base(cb) + jb) * 256 + l15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a = blk[(4 * q + l4) * 16];
+#pragma unroll
+                for (int rn = 0; rn < NRW; ++rn) x[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x[rn], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = -x[rn];     // X itself from here on
+        __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later column blocks from piling up in registers
+    };
+    solve_block_column(std::integral_constant<int, 7>{});
+    solve_block_column(std::integral_constant<int, 6>{});
+#pragma unroll
+    for (int e = 0; e < 9; ++e) *reinterpret_cast<d2*>(sD + (size_t)(2 * (9 + e) + dhalf) * 256 + 2 * (t & 127)) = dw[e];
+    __syncthreads();
+    solve_block_column(std::integral_constant<int, 5>{});
+    solve_block_column(std::integral_constant<int, 4>{});
+    solve_block_column(std::integral_constant<int, 3>{});
+    solve_block_column(std::integral_constant<int, 2>{});
+    solve_block_column(std::integral_constant<int, 1>{});
+    solve_block_column(std::integral_constant<int, 0>{});
+    // store: register q of acc[cb][rn] is X(row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q)
+    const unsigned lofs = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
+    const size_t ldc = (size_t)tk.ldc;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * q) * ldc);
+#pragma unroll
+            for (int rn = 0; rn < NRW; ++rn) col[lofs + 16 * rn] = acc[cb][rn][q];
+            if (NRW == 1 && tk.zpad) col[lofs + 64] = 0.0;      // rows 64.. of a short tile of the factor: padding
+        }
+    if (tk.wi != nullptr) {     // riders, reduced inside the wave as in tile_trsm_kernel (same order: same bits)
+        double p[NRW], q2[NRW];
+#pragma unroll
+        for (int rn = 0; rn < NRW; ++rn) p[rn] = q2[rn] = 0.0;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double z = tk.zk[16 * cb + l4 + 4 * q];
+#pragma unroll
+                for (int rn = 0; rn < NRW; ++rn) {
+                    p[rn] = fma(acc[cb][rn][q], z, p[rn]);
+                    q2[rn] = fma(acc[cb][rn][q], acc[cb][rn][q], q2[rn]);
+                }
+            }
+#pragma unroll
+        for (int rn = 0; rn < NRW; ++rn) {
+            p[rn] += __shfl_xor(p[rn], 16);
+            p[rn] += __shfl_xor(p[rn], 32);
+            q2[rn] += __shfl_xor(q2[rn], 16);
+            q2[rn] += __shfl_xor(q2[rn], 32);
+        }
+        if (l4 == 0) {
+#pragma unroll
+            for (int rn = 0; rn < NRW; ++rn) {
+                const int row = 16 * NRW * w + 16 * rn + l15;
+                if (tk.sq == nullptr) tk.wi[row] -= p[rn];
+                else {
+                    tk.wi[row] += p[rn];
+                    tk.sq[row] += q2[rn];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tile_fused_kernel(const FusedTask* __restrict__ tasks, const KParam* __restrict__ kp,
+                                                            int D) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP];
+    static_assert(2 * NRING * KC2 * LDP == 36 * 256, "the ring holds the 36 lower blocks of Dinv_k exactly");
+    static_assert(GRAM_FUSE_MAX_D * TB <= NRING * KC2 * LDP, "coordinate image of a tile must fit half the ring");
+    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
+    double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem + NRING * KC2 * LDP);
+    const FusedTask tk = tasks[blockIdx.x];
+    if (tk.mrows != 0 && tk.mrows <= 64) tile_fused_body<1>(tk, sA, sB, kp, D);
+    else tile_fused_body<2>(tk, sA, sB, kp, D);
+}
+
+// Gram values of a wave's 9 lower blocks of the diagonal tile, S = k - product in place (syrk_gram_epilogue without the
+// store), then the blocks go into the packed image of chol_diag_packed_body
+template <int SHAPE, int KIND>
+__device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KParam& p, int D, d4 (&acc)[9], const int (&blk)[6],
+                                                  const double* sa) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {
+        int rb[3], cb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (SHAPE == 0) {
+                rb[j] = blk[g3];
+                cb[j] = blk[3 + j];
+            } else {
+                rb[j] = blk[2 * g3 + (j > 0 ? 1 : 0)];
+                cb[j] = blk[2 * g3 + (j > 1 ? 1 : 0)];
+            }
+        }
+        double z[3][1][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[j][0][r] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double nhd = (KIND == 1) ? p.nh[d] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double a[1], b[4];
+                a[0] = sa[d * TB + 16 * rb[j] + l15];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = sa[d * TB + 16 * cb[j] + l4 + 4 * r];
+                gram_accumulate<KIND, 1, 4>(z[j], a, b, nhd);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rb[j] + l15, col = 16 * cb[j] + l4 + 4 * r;
+                const double kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
+                acc[3 * g3 + j][r] = kv - acc[3 * g3 + j][r];
+            }
+    }
+}
+
+template <int SHAPE>
+__device__ __forceinline__ void diag_fused_front(const TileTask& tt, const KParam* __restrict__ kp, int D, double* S, const int (&blk)[6]) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
+    d4 acc[9];
+    syrk_mainloop<SHAPE>(tt, acc, sA, blk);                 // ends on a barrier: the ring is free
+    const KParam p = kp[tt.kid];
+    gram_stage_coords(tt, D, S, nullptr, false);            // coordinates over the ring (barrier inside)
+    if (p.kind == 0) syrk_gram_inplace<SHAPE, 0>(tt, p, D, acc, blk, S);
+    else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1>(tt, p, D, acc, blk, S);
+    else syrk_gram_inplace<SHAPE, 2>(tt, p, D, acc, blk, S);
+    __syncthreads();                                        // the coordinates are no longer read: the image takes their place
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int rb, cb;
+            if (SHAPE == 0) {
+                rb = blk[g3];
+                cb = blk[3 + j];
+            } else {
+                rb = blk[2 * g3 + (j > 0 ? 1 : 0)];
+                cb = blk[2 * g3 + (j > 1 ? 1 : 0)];
+            }
+            double* dst = S + PACKED.off[rb * 8 + cb] + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * PLD] = acc[3 * g3 + j][r];
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask* __restrict__ tasks, const KParam* __restrict__ kp, int D) {
+    extern __shared__ __attribute__((aligned(16))) double S[];   // DIAGP_LDS_BYTES: ring / coordinates / image share the front
+    static_assert(NRING * KC2 * LDP <= PIMG && GRAM_FUSE_MAX_D * TB <= PIMG, "ring and coordinates must fit under the image");
+    const DiagFusedTask ft = tasks[blockIdx.x];
+    TileTask tt{};
+    tt.A = ft.A;
+    tt.lda = ft.d.ld;
+    tt.k0 = 0;
+    tt.k1 = ft.k1;
+    tt.kid = ft.kid;
+    tt.gxa = ft.gx;
+    tt.glda = ft.glda;
+    tt.gna = tt.gnb = ft.d.nvalid;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w == 3) {
+        const int blk[6] = {0, 1, 3, 4, 6, 7};
+        diag_fused_front<1>(tt, kp, D, S, blk);
+    } else {
+        const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
+        const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
+        diag_fused_front<0>(tt, kp, D, S, blk);
+    }
+    chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
+}
+
+}  // namespace dsmgp

@@ -2,9 +2,10 @@
 
 Leaves are independent units (`src/fit.jl:88-119` touches one leaf and at most its "main" leaf), so
 each rank factorises and predicts its own leaves; what is exchanged is small: per-leaf log-marginals
-after fit and per-(leaf, routed test row) predictive moments after predict, by an all-gather
-(RCCL over xGMI when the process group is `nccl`, gloo on CPU in the tests).  The sum/product
-aggregation then runs redundantly on every rank.
+after fit and the partial sums of the predict aggregation, by an all-gather.  With the `nccl` process group the
+collective runs on the context's own stream through the library (`dsmgp_fit_exchange` / `dsmgp_aggregate_exchange`:
+RCCL over xGMI, the payload never leaves HBM before it: `Shard.device_comm`); with gloo (CPU rehearsal in the
+tests) or when that path cannot be set up, through `torch.distributed` from host buffers.
 """
 import numpy as np
 
@@ -25,6 +26,53 @@ class Shard:
         self.rank = int(rank)
         self.world = int(world)
         self.local = np.flatnonzero(self.owner == self.rank)
+        self.comm_ctx = None          # hipabi.Context whose RCCL communicator carries the exchanges (device_comm)
+        self.exchange = "none" if self.world == 1 else "torch"
+
+    # ---- exchange through the library (RCCL on the context's stream) ----------------------------
+    def device_comm(self, ctx, force=False):
+        """Set up the library's own RCCL communicator on `ctx` (one per rank) when the process group is `nccl`: rank 0
+        draws the 128-byte id, torch.distributed carries it to the others, every rank calls dsmgp_comm_init and proves
+        the communicator with one tiny all-gather.  All ranks take the device path or none does (a MIN all-reduce of
+        the per-rank verdicts); on any failure the exchanges stay on torch.distributed.  Returns the path in use."""
+        td = _pg()
+        if self.world == 1 and force:          # one-rank communicator: the GPU box's test of this path
+            uid = ctx.comm_unique_id()
+            ctx.comm_init(0, 1, uid)
+            self.comm_ctx, self.exchange = ctx, "rccl-device"
+            return self.exchange
+        if self.world == 1 or td is None or td.get_backend() != "nccl" or self.comm_ctx is not None:
+            return self.exchange
+        import torch
+        ok = 1
+        try:
+            box = [ctx.comm_unique_id() if self.rank == 0 else None]
+            td.broadcast_object_list(box, src=0)
+            ctx.comm_init(self.rank, self.world, box[0])
+            got = ctx.allgather(np.array([float(self.rank)]))
+            ok = int(np.array_equal(got.ravel(), np.arange(self.world, dtype=np.float64)))
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        td.all_reduce(flag, op=td.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            self.comm_ctx, self.exchange = ctx, "rccl-device"
+        else:
+            try:
+                ctx.comm_destroy()
+            except Exception:
+                pass
+        return self.exchange
+
+    def fit_exchange(self, ctx):
+        """(mll, info) of every leaf after this rank's fit: one device-to-device all-gather (dsmgp_fit_exchange)."""
+        counts = np.bincount(self.owner, minlength=self.world)
+        both = ctx.fit_exchange(int(max(1, counts.max())))
+        out = np.empty((self.owner.size, 2))
+        for r in range(self.world):
+            idx = np.flatnonzero(self.owner == r)
+            out[idx] = both[r, : idx.size]
+        return out
 
     @staticmethod
     def single(L):

@@ -14,6 +14,7 @@ N_TIMINGS = 18
 AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
 OPT_ARD_LENGTHSCALE_GRADIENT = 1
 OPT_FUSED_GRAM = 2
+OPT_FUSED_STEPS = 3
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
 
@@ -63,6 +64,9 @@ SIGNATURES = {
     "dsmgp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "dsmgp_comm_init": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_char_p]),
     "dsmgp_allgather": (C.c_int, [_ctx, _dp, C.c_int64, _dp]),
+    "dsmgp_fit_exchange": (C.c_int, [_ctx, C.c_int64, _dp]),
+    "dsmgp_aggregate_exchange": (C.c_int, [_ctx, _dp]),
+    "dsmgp_aggregate_exchange_empty": (C.c_int, [_ctx, C.c_int32, C.c_int64, _dp]),
     "dsmgp_comm_destroy": (C.c_int, [_ctx]),
     "dsmgp_tree_build": (C.c_int, [_dp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                    C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -244,7 +248,7 @@ class Context:
         return self.predict_fetch()
 
     def set_option(self, option, value):
-        """include/dsmgp_hip.h DSMGP_OPT_*: OPT_ARD_LENGTHSCALE_GRADIENT = 1, OPT_FUSED_GRAM = 2."""
+        """include/dsmgp_hip.h DSMGP_OPT_*: OPT_ARD_LENGTHSCALE_GRADIENT = 1, OPT_FUSED_GRAM = 2, OPT_FUSED_STEPS = 3."""
         self._chk(self.lib.dsmgp_set_option(self.h, int(option), int(value)))
 
     def gradients(self, stride):
@@ -273,11 +277,13 @@ class Context:
                                            var.ctypes.data_as(_dp) if fetch else None))
         return mu, var
 
-    def aggregate_partial(self, family, leaf_coef=None, leaf_group=None, n_groups=0):
-        """This context's partial sums, shape (W, n_t): what ranks / contexts exchange and add."""
+    def aggregate_partial(self, family, leaf_coef=None, leaf_group=None, n_groups=0, fetch=True):
+        """This context's partial sums, shape (W, n_t): what ranks / contexts exchange and add (fetch=False: they stay on
+        the device, for aggregate_exchange)."""
         coef, pc, grp, pg = self._agg_args(family, leaf_coef, leaf_group)
-        part = np.empty((agg_width(family, n_groups), self.n_t))
-        self._chk(self.lib.dsmgp_aggregate_partial(self.h, int(family), pc, pg, int(n_groups), part.ctypes.data_as(_dp)))
+        part = np.empty((agg_width(family, n_groups), self.n_t)) if fetch else None
+        self._chk(self.lib.dsmgp_aggregate_partial(self.h, int(family), pc, pg, int(n_groups),
+                                                   part.ctypes.data_as(_dp) if fetch else None))
         return part
 
     def aggregate_finish(self, partial=None, plain=False, prior_kernel_id=0, fetch=True):
@@ -319,6 +325,24 @@ class Context:
         out = np.empty((self.world, local.size))
         self._chk(self.lib.dsmgp_allgather(self.h, p, local.size, out.ctypes.data_as(_dp)))
         return out
+
+    def fit_exchange(self, count):
+        """(world, count, 2) array of (mll, info) per rank and leaf slot of the last fit, gathered device to device."""
+        out = np.empty((self.world, int(count), 2))
+        self._chk(self.lib.dsmgp_fit_exchange(self.h, int(count), out.ctypes.data_as(_dp)))
+        return out
+
+    def aggregate_exchange(self, W, fetch=False):
+        """Sum over ranks of the partial sums of the last aggregate_partial, left on the device for aggregate_finish."""
+        tot = np.empty((int(W), self.n_t)) if fetch else None
+        self._chk(self.lib.dsmgp_aggregate_exchange(self.h, tot.ctypes.data_as(_dp) if fetch else None))
+        return tot
+
+    def aggregate_exchange_empty(self, W, n_t):
+        """The same collective from a rank without leaves: contributes zeros, returns the total (W, n_t)."""
+        tot = np.empty((int(W), int(n_t)))
+        self._chk(self.lib.dsmgp_aggregate_exchange_empty(self.h, int(W), int(n_t), tot.ctypes.data_as(_dp)))
+        return tot
 
     def comm_destroy(self):
         self._chk(self.lib.dsmgp_comm_destroy(self.h))

@@ -177,6 +177,8 @@ class Model:
                 self._ctx = hipabi.MultiContext(self._device, self._n_sub)
             else:
                 self._ctx = hipabi.Context(self._device)
+                if self.shard.world > 1:      # nccl process group: the exchanges run through the library's communicator
+                    self.shard.device_comm(self._ctx)
         return self._ctx
 
     # ---- kernel ids -> shared hyper-parameters --------------------------------------------------
@@ -363,12 +365,17 @@ def prediction(gp, xtest):
 
 def _fit(model, tau):
     model._upload(tau)
+    if model.shard.world > 1 and _ctx_type(model) is hipabi.Context:
+        _ = model.ctx          # every rank, also one without leaves, joins the set-up of the device exchange (collective)
     if len(model.shard.local) == 0:
         mll_loc, info_loc, sec = np.zeros(0), np.zeros(0, dtype=np.int32), 0.0
     else:
         model._push_hyper()
         mll_loc, info_loc, sec = model.ctx.fit()
-    both = model.shard.gather_leaf_columns(np.stack([mll_loc, info_loc.astype(np.float64)], axis=1))   # one collective
+    if model.shard.comm_ctx is not None:
+        both = model.shard.fit_exchange(model.ctx)     # device to device over RCCL, then one copy to the host
+    else:
+        both = model.shard.gather_leaf_columns(np.stack([mll_loc, info_loc.astype(np.float64)], axis=1))   # one collective
     model.leaf_mll = np.ascontiguousarray(both[:, 0])
     model.leaf_info = both[:, 1].astype(np.int32)
     model.last_fit_seconds = sec
@@ -884,11 +891,24 @@ def _predict_device(model, xt, rc):
             model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
             rc["uploaded"] = True
         model.last_predict_seconds = model.ctx.predict_run()
-    single = model.shard.world == 1 and isinstance(model.ctx, hipabi.Context)
+    single = model.shard.world == 1 and isinstance(model.ctx, hipabi.Context) and model.shard.comm_ctx is None
     if single:      # one context holds every leaf: partial sums, finish and (later) scores never leave the device
         mu, var = model.ctx.aggregate(family, coef, group, G, plain=plain, prior_kernel_id=prior.kernelid if prior else 0)
         model._scores_on_device = True
         return mu, var
+    if model.shard.comm_ctx is not None:
+        # the exchange step of predict inside the library: partial sums stay in HBM, are all-gathered over RCCL on the
+        # context's stream and added in rank order on the device; the finish runs on the total
+        W = hipabi.agg_width(family, G)
+        if have:
+            model.ctx.aggregate_partial(family, None if coef is None else coef[loc], None if group is None else group[loc], G,
+                                        fetch=False)
+            model.ctx.aggregate_exchange(W)
+            mu, var = model.ctx.aggregate_finish(None, plain=plain, prior_kernel_id=prior.kernelid if prior else 0)
+            model._scores_on_device = True
+            return mu, var
+        part = model.ctx.aggregate_exchange_empty(W, xt.shape[0])
+        return _finish_partial(model, xt, family, part, G, plain, prior)
     if have:
         part = model.ctx.aggregate_partial(family, None if coef is None else coef[loc], None if group is None else group[loc], G)
     else:

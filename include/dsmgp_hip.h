@@ -147,6 +147,13 @@ int dsmgp_gradients(dsmgp_ctx* ctx, double* grad_out, int32_t stride);
  * covers block column 0 only (D <= 32; above that the option has no effect); 0 = every lower tile of K_y goes through
  * memory first.  Changing it discards the leaf plan and a registered test set: set it before dsmgp_set_test. */
 #define DSMGP_OPT_FUSED_GRAM 2
+/* DSMGP_OPT_FUSED_STEPS: 1 (default) = a block step of the factorisation whose diagonal blocks alone fill the chip (more
+ * leaves in the step than CUs: depth >= 3 trees, large PoE models) runs as two launches -- the diagonal block's task also
+ * updates its tile, the tasks of the tiles below update AND solve them, each tile written once (the per-step order of
+ * src/AdvancedCholeskey.jl:161-171, batched over leaves); 0 = every step as update / diagonal block / panel solve
+ * launches.  Same arithmetic in the same order: bit-identical results.  Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing
+ * it discards the leaf plan and a registered test set. */
+#define DSMGP_OPT_FUSED_STEPS 3
 int dsmgp_set_option(dsmgp_ctx* ctx, int32_t option, int32_t value);
 
 /* ---- inspection ------------------------------------------------------------------------------- */
@@ -205,6 +212,17 @@ int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx
 int dsmgp_comm_unique_id(char* id_out /* 128 bytes */);
 int dsmgp_comm_init(dsmgp_ctx* ctx, int32_t rank, int32_t world, const char* id /* 128 bytes */);
 int dsmgp_allgather(dsmgp_ctx* ctx, const double* send, int64_t count, double* recv /* world x count */);
+/*      The two exchanges of the path with the payload staying in HBM until after the collective:
+ *      dsmgp_fit_exchange: per-leaf (log-marginal, info) of the last dsmgp_fit, straight from the device results, padded to
+ *        `count` leaves per rank (count >= this rank's leaf count; a rank without leaves passes its context with no leaf
+ *        table and contributes zeros): out[(r * count + l) * 2 + {0, 1}] = mll / info of rank r's leaf l.
+ *      dsmgp_aggregate_exchange: after dsmgp_aggregate_partial on every rank, all-gathers the W x n_t partial sums and
+ *        adds them in rank order on the device (the same bits on every rank); dsmgp_aggregate_finish(ctx, NULL, ...)
+ *        then finishes from the total.  A rank without leaves calls dsmgp_aggregate_exchange_empty(ctx, W, n_t) instead
+ *        (it contributes zeros and receives the total in `total_out`, W x n_t doubles, may be NULL). */
+int dsmgp_fit_exchange(dsmgp_ctx* ctx, int64_t count, double* out /* world x count x 2 */);
+int dsmgp_aggregate_exchange(dsmgp_ctx* ctx, double* total_out /* W x n_t, may be NULL */);
+int dsmgp_aggregate_exchange_empty(dsmgp_ctx* ctx, int32_t W, int64_t n_t, double* total_out /* may be NULL */);
 int dsmgp_comm_destroy(dsmgp_ctx* ctx);
 
 /* Host-only (no device): the random partition tree of buildTree (src/treeStructure.jl:4-307: getSplits, _buildSplit,

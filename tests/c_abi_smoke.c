@@ -1,0 +1,131 @@
+/*
+ * c_abi_smoke.c -- a host that is NOT Python calling the C ABI of include/dsmgp_hip.h (plain C99, the header only):
+ * what a Julia `ccall` (julia/DSMGPHip.jl) or any other FFI does.  One exact GP:
+ *     dsmgp_create -> set_train -> set_leaves -> set_hyper -> fit -> predict_leaves -> download_factor -> destroy
+ * i.e. update_cholesky! / mll / prediction of src/gaussianprocess.jl:82-137,163 on the device, compared with the expected
+ * numbers the caller passes in (tests/test_gpu_parity.py writes them from the mpmath-pinned fixture
+ * tests/golden/gp_edge.npz; n = 160 crosses a 128-tile edge).
+ *
+ * Input file (native endianness): int64 n, D, nt, kind, nhyp; then doubles X[n*D] (column-major), y[n], Xt[nt*D]
+ * (column-major), loghyp[nhyp] (= [logl..., logs, logNoise]), mean, mll, mu[nt], var[nt], alpha[n].
+ * Exit code 0 = all within tolerance (1e-8 relative on mll / mu / var: the north-star bar; 1e-7 on alpha).
+ *
+ * Built by __graft_entry__.build():  gcc -std=c99 -pedantic -Wall -Werror tests/c_abi_smoke.c -Iinclude
+ *     -Ldeepstructuredmixtures_amd -ldsmgp_hip -lm -Wl,-rpath,'$ORIGIN/../deepstructuredmixtures_amd' -o tests/c_abi_smoke
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "dsmgp_hip.h"
+
+static int fail(dsmgp_ctx* ctx, const char* what, int rc) {
+    fprintf(stderr, "c_abi_smoke: %s failed (%d): %s\n", what, rc, dsmgp_last_error(ctx));
+    return 2;
+}
+
+static double* read_doubles(FILE* f, size_t count) {
+    double* p = (double*)malloc((count ? count : 1) * sizeof(double));
+    if (!p || fread(p, sizeof(double), count, f) != count) {
+        fprintf(stderr, "c_abi_smoke: short input file\n");
+        exit(3);
+    }
+    return p;
+}
+
+static int close_enough(const char* name, const double* got, const double* want, int64_t n, double rtol, double atol) {
+    double worst = 0.0;
+    int64_t i, at = -1;
+    for (i = 0; i < n; ++i) {
+        const double err = fabs(got[i] - want[i]) - (atol + rtol * fabs(want[i]));
+        if (!(err <= 0.0) && (at < 0 || err > worst)) {
+            worst = err;
+            at = i;
+        }
+    }
+    if (at >= 0) {
+        fprintf(stderr, "c_abi_smoke: %s[%lld] = %.17g, expected %.17g\n", name, (long long)at, got[at], want[at]);
+        return 1;
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    int64_t hdr[5];
+    int64_t n, D, nt, kind, nhyp, i;
+    double *X, *y, *Xt, *loghyp, *scal, *mu_want, *var_want, *alpha_want;
+    double *mu, *var, *alpha, *F;
+    double mll = 0.0, seconds = 0.0, maxabs = 0.0;
+    int32_t info = -1, kid = 0;
+    int64_t obs_ptr[2], route_ptr[2];
+    int64_t *obs_idx, *route_idx;
+    dsmgp_ctx* ctx = NULL;
+    char name[256];
+    int rc, bad = 0;
+    FILE* f;
+
+    if (argc != 2) {
+        fprintf(stderr, "usage: c_abi_smoke <input file>\n");
+        return 3;
+    }
+    f = fopen(argv[1], "rb");
+    if (!f || fread(hdr, sizeof(int64_t), 5, f) != 5) {
+        fprintf(stderr, "c_abi_smoke: cannot read %s\n", argv[1]);
+        return 3;
+    }
+    n = hdr[0]; D = hdr[1]; nt = hdr[2]; kind = hdr[3]; nhyp = hdr[4];
+    X = read_doubles(f, (size_t)(n * D));
+    y = read_doubles(f, (size_t)n);
+    Xt = read_doubles(f, (size_t)(nt * D));
+    loghyp = read_doubles(f, (size_t)nhyp);
+    scal = read_doubles(f, 2);                 /* mean, mll */
+    mu_want = read_doubles(f, (size_t)nt);
+    var_want = read_doubles(f, (size_t)nt);
+    alpha_want = read_doubles(f, (size_t)n);
+    fclose(f);
+
+    obs_idx = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+    route_idx = (int64_t*)malloc((size_t)nt * sizeof(int64_t));
+    mu = (double*)malloc((size_t)nt * sizeof(double));
+    var = (double*)malloc((size_t)nt * sizeof(double));
+    alpha = (double*)malloc((size_t)n * sizeof(double));
+    F = (double*)malloc((size_t)(n * n) * sizeof(double));
+    if (!obs_idx || !route_idx || !mu || !var || !alpha || !F) return 3;
+    for (i = 0; i < n; ++i) obs_idx[i] = i;
+    for (i = 0; i < nt; ++i) route_idx[i] = i;
+    obs_ptr[0] = 0; obs_ptr[1] = n;
+    route_ptr[0] = 0; route_ptr[1] = nt;
+
+    if ((rc = dsmgp_create(0, &ctx)) != 0) return fail(NULL, "dsmgp_create", rc);
+    if ((rc = dsmgp_device_name(ctx, name, (int32_t)sizeof(name))) != 0) return fail(ctx, "dsmgp_device_name", rc);
+    if ((rc = dsmgp_set_train(ctx, X, y, n, (int32_t)D)) != 0) return fail(ctx, "dsmgp_set_train", rc);
+    if ((rc = dsmgp_set_leaves(ctx, 1, obs_ptr, obs_idx, &kid, &scal[0])) != 0) return fail(ctx, "dsmgp_set_leaves", rc);
+    if ((rc = dsmgp_set_hyper(ctx, 0, (int32_t)kind, loghyp, (int32_t)nhyp)) != 0) return fail(ctx, "dsmgp_set_hyper", rc);
+    if ((rc = dsmgp_fit(ctx, &mll, &info, &seconds)) != 0) return fail(ctx, "dsmgp_fit", rc);
+    if (info != 0) {
+        fprintf(stderr, "c_abi_smoke: info = %d\n", (int)info);
+        return 1;
+    }
+    if ((rc = dsmgp_predict_leaves(ctx, Xt, nt, route_ptr, route_idx, mu, var)) != 0) return fail(ctx, "dsmgp_predict_leaves", rc);
+    if ((rc = dsmgp_download_factor(ctx, 0, F, alpha)) != 0) return fail(ctx, "dsmgp_download_factor", rc);
+    /* an error must come back as a code + message, never as a crash: a second leaf table entry out of range */
+    if (dsmgp_download_factor(ctx, 7, F, alpha) != DSMGP_E_ARG) {
+        fprintf(stderr, "c_abi_smoke: leaf out of range was not rejected\n");
+        bad = 1;
+    }
+    if ((rc = dsmgp_destroy(ctx)) != 0) return fail(NULL, "dsmgp_destroy", rc);
+
+    bad |= close_enough("mll", &mll, &scal[1], 1, 1e-8, 0.0);
+    bad |= close_enough("mu", mu, mu_want, nt, 1e-8, 1e-11);
+    bad |= close_enough("var", var, var_want, nt, 1e-8, 1e-11);
+    for (i = 0; i < n; ++i) maxabs = fmax(maxabs, fabs(alpha_want[i]));
+    bad |= close_enough("alpha", alpha, alpha_want, n, 0.0, 1e-7 * maxabs);
+    for (i = 0; i < n; ++i)
+        if (!(F[i + i * n] > 0.0)) bad = 1;     /* the factor came back: a positive diagonal, zeros above it */
+    if (n > 1 && F[0 + 1 * n] != 0.0) bad = 1;
+    if (bad) return 1;
+    printf("c_abi_smoke ok: %s  n=%lld D=%lld kind=%lld  mll=%.12g  fit %.3g s\n", name, (long long)n, (long long)D,
+           (long long)kind, mll, seconds);
+    return 0;
+}

@@ -103,6 +103,41 @@ def gp_cases():
     return list(cases)
 
 
+def gp_edge_cases():
+    """n = 160 (one whole 128-block plus a partial one: the factorisation crosses a tile edge) for all three kernel kinds,
+    with test points where the predictive variance cancels: three rows AT training inputs (rows on both sides of the
+    tile edge), three 1e-7 away from them, three elsewhere.  Noise standard deviation 0.03: at a training point
+    sigma^2 = k** + noise - |V|^2 loses three to four digits.  50-digit mpmath values; the oracle must match them first."""
+    cases = {}
+    specs = [
+        ("isose_n160_d2", 0, 160, 2, [np.log(0.35), np.log(1.1)], np.log(0.03)),
+        ("ardse_n160_d3", 1, 160, 3, [np.log(0.3), np.log(0.5), np.log(0.9), -0.1], np.log(0.03)),
+        ("isolinear_n160_d3", 2, 160, 3, [np.log(0.9), 0.0], np.log(0.03)),
+    ]
+    for si, (name, kind, n, D, loghyp, logNoise) in enumerate(specs):
+        X = uniform(500 + si, 0, n * D).reshape((n, D), order="F")
+        y = np.sin(3.0 * X[:, 0]) * np.cos(2.0 * X[:, 1]) + 0.03 * normal(600 + si, 0, n)
+        at = X[[5, 127, 128]]
+        near = X[[40, 126, 159]] + 1e-7
+        Xt = np.concatenate([at, near, uniform(700 + si, 0, 3 * D).reshape((3, D), order="F")])
+        mean = float(np.mean(y))
+        g = ogp.GaussianProcess(X, y, mean, ogp.make_kernel(kind, loghyp), logNoise, exact_dist=True).update_cholesky()
+        mu, var = g.prediction(Xt)
+        alpha_mp, mll_mp, mu_mp, var_mp = mp_gp(kind, loghyp, logNoise, X, y, mean, Xt)
+        assert np.allclose(g.alpha, alpha_mp, rtol=1e-7, atol=1e-9), name          # conditioning ~ n s2 / noise ~ 2e5
+        assert abs(g.mll() - mll_mp) < 1e-10 * max(1.0, abs(mll_mp)), name
+        assert np.allclose(mu, mu_mp, rtol=1e-9, atol=1e-11), name
+        assert np.allclose(var, var_mp, rtol=1e-8, atol=1e-12), name
+        cases[name] = dict(kind=kind, X=X, y=y, Xt=Xt, mean=mean, loghyp=np.array(loghyp), logNoise=logNoise,
+                           alpha=np.array(alpha_mp), mll=mll_mp, mu=np.array(mu_mp), var=np.array(var_mp))
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[f"{name}/{k}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "gp_edge.npz"), **flat)
+    return {n: (float(np.min(c["var"])), float(c["mll"])) for n, c in cases.items()}
+
+
 def analytic():
     """n=1 and n=2 closed forms (IsoSE), written out by hand."""
     out = {}
@@ -177,6 +212,7 @@ def tree_small():
 
 if __name__ == "__main__":
     print("gp cases:", gp_cases())
+    print("tile-edge cases (min var, mll):", gp_edge_cases())
     analytic()
     config1()
     tree_small()

@@ -167,6 +167,34 @@ def test_not_positive_definite_is_reported(ctx):
     assert linfo > 0 and 1 < info[0] <= n
 
 
+def test_first_bad_minor_is_reported_exactly(ctx):
+    """Deterministic non-positive-definite cases with a KNOWN first bad leading minor: IsoLinear kernel
+    (K = X X^T / l^2, l = 1) on rows 2^27 e_i, so K = 2^54 x (0/1 matrix) and noise + eps (< 1) is absorbed by rounding
+    (ulp(2^54) = 4): every operation of the factorisation is exact in binary floating point -- sqrt(2^54) = 2^27,
+    1 / 2^54 -- and a repeated row makes its pivot exactly 0.  `info` must EQUAL LAPACK's: the index of that row
+    (1-based), inside the first 128-block and, with D = 131 orthogonal directions, at row 131 of the second block (the
+    blocked path: panel solve, update of the next diagonal tile, global row offset of the block)."""
+    import scipy.linalg as sla
+    for D, n, rep in ((3, 140, 3), (131, 140, 130)):
+        X = np.zeros((n, D))
+        for i in range(min(n, D)):
+            X[i, i] = 2.0 ** 27
+        X[rep, :] = 0.0
+        X[rep, 0] = 2.0 ** 27                                        # row `rep` repeats row 0: the first dependent row
+        for i in range(rep + 1, n):
+            X[i, :] = 0.0
+            X[i, (i * 7) % D] = 2.0 ** 27                            # what follows the bad pivot does not matter
+        ctx.set_train(X, np.zeros(n))
+        ctx.set_leaves([0, n], np.arange(n), [0], [0.0])
+        ctx.set_sharing(None, None, None)
+        ctx.set_hyper(0, 2, [0.0, 0.0, -30.0])
+        _, info, _ = ctx.fit()
+        K = X @ X.T + (np.exp(-60.0) + 1e-8) * np.eye(n)
+        assert K[rep, rep] == 2.0 ** 54                              # the shift is absorbed
+        _, linfo = sla.lapack.dpotrf(K, lower=1)
+        assert linfo == rep + 1 and info[0] == linfo, (D, int(info[0]), linfo)
+
+
 def test_error_paths(ctx):
     with pytest.raises(hipabi.DsmgpError):
         ctx.set_leaves([0, 3], [2, 1, 0], [0], [0.0])               # not ascending
@@ -1236,3 +1264,202 @@ def test_single_gp_prediction_registers_its_rows_once():
     assert np.allclose(mu2, mo2, rtol=RTOL, atol=1e-9) and np.allclose(v2, vo2, rtol=RTOL, atol=1e-10)
     mu3, v3 = dsm.predict(gp, Xt[:50])                  # predict(gp, x) clamps the variance like the tree models
     assert np.array_equal(mu3, mu2) and np.all(v3 > 0)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
+    """Small-leaf regime: a table of 700 leaves of 130..700 rows -- last row tiles of every class (<= 32,
+    <= 64, <= 96, whole), 10..150 routed test rows per leaf (short and whole test tiles, two tiles for some), a COPY and
+    a PREFIX leaf -- has more diagonal blocks per step than the chip has CUs, so its block steps run fused
+    (diag_fused_kernel + tile_fused_kernel: each tile written once, short tiles in the 16-rows-per-wave form); with
+    DSMGP_OPT_FUSED_STEPS = 0 the same table runs as update (short tiles in the column-split form) / packed diagonal
+    block / panel solve launches.  Same arithmetic up to the order of one addition per entry: log-marginals 1e-12, the
+    factor of sampled leaves 1e-11, moments 1e-9 (conditioning-limited); three leaves against the oracle at the
+    north-star tolerance.  All three kernel kinds (the Gram values are evaluated inside the tasks)."""
+    N, D, L = 60_000, 3, 700
+    X, y, Xt = regression_data(N, D, n_test=160, seed=5150 + kind)
+    rng = np.random.default_rng(11 + kind)
+    sizes = rng.integers(130, 701, size=L)
+    sizes[:8] = [130, 160, 192, 224, 256, 300, 352, 384]                  # every row class at least once
+    obs = [np.sort(rng.choice(N, size=int(n), replace=False)) for n in sizes]
+    obs[10] = obs[3].copy()                                               # COPY of leaf 3
+    # a PREFIX claim needs the source's list as the leading part of an ascending list: rows above the source's last row
+    tail = np.arange(obs[5][-1] + 1, min(N, obs[5][-1] + 1 + 230))
+    obs[11] = np.concatenate([obs[5], tail])
+    op = np.zeros(L, dtype=np.int32)
+    src = np.full(L, -1, dtype=np.int32)
+    plen = np.zeros(L, dtype=np.int64)
+    op[10], src[10] = 1, 3
+    if tail.size:
+        op[11], src[11], plen[11] = 2, 5, obs[5].size
+    ntest = rng.integers(10, 151, size=L)
+    rptr = np.concatenate([[0], np.cumsum(ntest)])
+    ridx = np.concatenate([np.sort(rng.choice(Xt.shape[0], size=int(k), replace=False)) for k in ntest])
+    hyp = {0: [np.log(0.3), 0.0, np.log(0.1)], 1: [np.log(0.3), np.log(0.4), np.log(0.5), 0.0, np.log(0.1)],
+           2: [np.log(1.5), 0.0, np.log(0.3)]}[kind]
+    means = [float(np.mean(y[o])) for o in obs]
+    means[10] = means[3]
+
+    def run(fused):
+        ctx.set_option(hipabi.OPT_FUSED_STEPS, 1 if fused else 0)
+        ctx.set_train(X, y)
+        ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, dtype=np.int32), means)
+        ctx.set_sharing(op, src, plen)
+        ctx.set_hyper(0, kind, hyp)
+        ctx.set_test(Xt, rptr, ridx)                 # resident: the test rows ride through the factorisation launches
+        ctx.set_profile(2)
+        mll, info, _ = ctx.fit()
+        t = ctx.timings()
+        assert np.all(info == 0)
+        ctx.predict_run()
+        mu, var = ctx.predict_fetch()
+        fa = [ctx.download_factor(j, obs[j].size) for j in (0, 5, 11, 300, 699)]
+        return mll, mu, var, fa, t
+
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        ctx.set_option(hipabi.OPT_FUSED_STEPS, 1)
+        ctx.set_profile(0)
+    # the fused steps have no panel-solve launches: what is left are the last block steps of the few largest leaves
+    assert a[4]["chol_trsm"] < 0.25 * b[4]["chol_trsm"] and a[4]["gram"] < 0.25 * b[4]["gram"]
+    assert np.allclose(a[0], b[0], rtol=1e-12, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
+    # the moments carry the conditioning of K_y (1e5..1e6 here, more for the additive ArdSE kernel): two summation orders
+    # of the same arithmetic agree to ~ cond x 1e-16, an order of magnitude inside the north-star tolerance
+    emu = float(np.max(np.abs(a[1] - b[1])) / max(1.0, float(np.max(np.abs(b[1])))))
+    evar = float(np.max(np.abs(a[2] - b[2]) / np.abs(b[2])))
+    assert emu <= 1e-9 and evar <= 1e-9, (emu, evar)
+    for (Fa, aa), (Fb, ab) in zip(a[3], b[3]):
+        assert np.max(np.abs(Fa - Fb)) <= 1e-11 * np.max(np.abs(Fb)), float(np.max(np.abs(Fa - Fb)) / np.max(np.abs(Fb)))
+        assert np.max(np.abs(aa - ab)) <= 1e-8 * np.max(np.abs(ab)), float(np.max(np.abs(aa - ab)) / np.max(np.abs(ab)))
+    mk = {0: lambda: ogp.IsoSE(hyp[0], hyp[1]), 1: lambda: ogp.ArdSE(np.array(hyp[:3]), hyp[3]), 2: lambda: ogp.IsoLinear(hyp[0])}[kind]
+    for j in (0, 11, 699):
+        g = ogp.GaussianProcess(X[obs[j]], y[obs[j]], means[j], mk(), hyp[-1], True).update_cholesky()
+        assert abs(a[0][j] - g.mll()) <= RTOL * abs(g.mll())
+        mo, vo = g.prediction(Xt[ridx[rptr[j]:rptr[j + 1]]])
+        assert np.allclose(a[1][rptr[j]:rptr[j + 1]], mo, rtol=RTOL, atol=1e-9)
+        assert np.allclose(a[2][rptr[j]:rptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
+
+
+def test_set_sharing_after_set_test_drops_the_test_set(ctx):
+    """dsmgp_set_sharing rebuilds the leaf plan, so a test set registered before it (whose task lists point
+    into the old plan's arenas) must go with it -- the C ABI sequence set_leaves -> set_test -> set_sharing -> fit used to
+    replay the joint launches against freed memory.  Now the test set is dropped (predict says so), and registered again
+    it gives the result of the unshared table."""
+    N, D = 900, 2
+    X, y, Xt = regression_data(N, D, n_test=50, seed=808)
+    o = np.arange(0, 600)
+    obs_ptr, obs_idx = [0, 600, 1200, 1500], np.concatenate([o, o, np.arange(600, 900)])
+    means = [float(np.mean(y[o]))] * 2 + [float(np.mean(y[600:]))]
+    rptr, ridx = np.arange(4) * 50, np.tile(np.arange(50), 3)
+
+    def table():
+        ctx.set_train(X, y)
+        ctx.set_leaves(obs_ptr, obs_idx, [0, 0, 0], means)
+        ctx.set_hyper(0, 0, [np.log(0.4), 0.0, np.log(0.2)])
+
+    table()
+    ctx.set_sharing(None, None, None)
+    ctx.fit()
+    ref = ctx.predict_leaves(Xt, rptr, ridx)
+    table()
+    ctx.set_test(Xt, rptr, ridx)
+    ctx.set_sharing([0, 1, 0], [-1, 0, -1], [0, 0, 0])          # leaf 1 = COPY of leaf 0: new plan, new addresses
+    mll, info, _ = ctx.fit()
+    assert np.all(info == 0) and mll[0] == mll[1]
+    with pytest.raises(hipabi.DsmgpError) as e:
+        ctx.predict_run()
+    assert "set_test" in str(e.value)
+    ctx.set_test(Xt, rptr, ridx)
+    ctx.fit()                                                   # joint: the rows ride through the new plan's launches
+    ctx.predict_run()
+    mu, var = ctx.predict_fetch()
+    assert np.allclose(mu, ref[0], rtol=1e-11, atol=1e-12) and np.allclose(var, ref[1], rtol=1e-10, atol=1e-13)
+
+
+def _edge_cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "gp_edge.npz"))
+    cases = {}
+    for key in z.files:
+        name, field = key.split("/")
+        cases.setdefault(name, {})[field] = z[key]
+    return cases
+
+
+def test_mpmath_golden_across_a_tile_edge(ctx, golden_dir):
+    """n = 160 crosses the 128-tile edge of the blocked factorisation (one whole block, a 32-row last tile, a panel solve
+    and an update between them); test rows AT training inputs on both sides of the edge, 1e-7 away from them and elsewhere,
+    noise standard deviation 0.03: sigma^2 = k** + noise - |V|^2 cancels three to four digits there.  50-digit mpmath
+    values for all three kernel kinds (tests/golden/gp_edge.npz); the north-star tolerance with the fixture's small
+    absolute term."""
+    for name, c in _edge_cases(golden_dir).items():
+        n = c["X"].shape[0]
+        mll, info, _ = _single(ctx, c["X"], c["y"], float(c["mean"]), int(c["kind"]), c["loghyp"], float(c["logNoise"]))
+        assert info[0] == 0
+        assert abs(mll[0] - float(c["mll"])) <= RTOL * abs(float(c["mll"])), name
+        _, alpha = ctx.download_factor(0, n)
+        assert np.max(np.abs(alpha - c["alpha"])) <= 1e-7 * np.max(np.abs(c["alpha"])), name
+        nt = c["Xt"].shape[0]
+        mu, var = ctx.predict_leaves(c["Xt"], [0, nt], np.arange(nt))
+        assert np.allclose(mu, c["mu"], rtol=RTOL, atol=1e-11), (name, float(np.max(np.abs(mu - c["mu"]))))
+        assert np.allclose(var, c["var"], rtol=RTOL, atol=1e-11), (name, float(np.max(np.abs(var - c["var"]) / c["var"])))
+        ctx.fit()                                                    # resident rows: the joint path gives the same numbers
+        ctx.predict_run()
+        mu2, var2 = ctx.predict_fetch()
+        assert np.allclose(mu2, c["mu"], rtol=RTOL, atol=1e-11) and np.allclose(var2, c["var"], rtol=RTOL, atol=1e-11), name
+
+
+def test_c_host_calls_the_abi(golden_dir, tmp_path):
+    """tests/c_abi_smoke.c -- plain C99 against include/dsmgp_hip.h, no Python in the process -- runs create / set_train /
+    set_leaves / set_hyper / fit / predict_leaves / download_factor / destroy on the mpmath-pinned n = 160 cases and
+    compares with their numbers itself (exit code 0).  Built by __graft_entry__.build(); a child process, so its HIP
+    context is its own."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "c_abi_smoke")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    for name, c in _edge_cases(golden_dir).items():
+        n, D = c["X"].shape
+        nt = c["Xt"].shape[0]
+        hyp = np.concatenate([c["loghyp"], [float(c["logNoise"])]])
+        path = os.path.join(tmp_path, name + ".bin")
+        with open(path, "wb") as f:
+            f.write(struct.pack("5q", n, D, nt, int(c["kind"]), hyp.size))
+            for a in (np.asfortranarray(c["X"]).ravel(order="F"), c["y"], np.asfortranarray(c["Xt"]).ravel(order="F"), hyp,
+                      np.array([float(c["mean"]), float(c["mll"])]), c["mu"], c["var"], c["alpha"]):
+                f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stdout, r.stderr)
+        assert "c_abi_smoke ok" in r.stdout and "gfx950" in r.stdout
+
+
+def test_shard_exchange_through_the_library_communicator():
+    """with the `nccl` process group the two exchanges of the path run inside the library -- per-leaf
+    (mll, info) and the aggregation's partial sums are all-gathered device to device over RCCL on the context's stream
+    (dsmgp_fit_exchange / dsmgp_aggregate_exchange) and only the results come to the host.  One GPU here, so a one-rank
+    communicator (RCCL refuses two ranks on one device; the two-rank layout is rehearsed over gloo in the CPU suite):
+    `Shard.device_comm(ctx, force=True)` drives fit!, update! and predict of a DSMGP and of an rBCM through that path;
+    results must equal the plain single-context path bit for bit (a sum over one rank is the value itself)."""
+    X, y, Xt = regression_data(4000, 3, n_test=300, seed=321)
+    for build in (lambda: dsm.buildDSMGP(X, y, 3, 4, M=60, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=5, fit_now=False),
+                  lambda: dsm.buildBCM(X, y, 4, M=300, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=5, fit_now=False)):
+        ref = build()
+        dsm.fit(ref)
+        zr = dsm.update(ref) if ref.family == "dsmgp" else 0.0
+        mr, vr = dsm.predict(ref, Xt)
+        m = build()
+        assert m.shard.device_comm(m.ctx, force=True) == "rccl-device" and m.shard.comm_ctx is m.ctx
+        dsm.fit(m)
+        z = dsm.update(m) if m.family == "dsmgp" else 0.0
+        mu, var = dsm.predict(m, Xt)
+        assert np.array_equal(m.leaf_mll, ref.leaf_mll) and np.array_equal(m.leaf_info, ref.leaf_info) and z == zr
+        assert np.array_equal(mu, mr) and np.array_equal(var, vr)
+        assert dsm.scores(m, np.zeros(Xt.shape[0])) == dsm.scores(ref, np.zeros(Xt.shape[0]))      # finish ran on the device
+        # the rank-without-leaves form of the predict exchange: zeros in, the total out
+        tot = m.ctx.aggregate_exchange_empty(3, Xt.shape[0])
+        assert tot.shape == (3, Xt.shape[0]) and np.all(tot == 0.0)
+        m.ctx.comm_destroy()

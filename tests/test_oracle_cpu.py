@@ -51,6 +51,30 @@ def test_oracle_matches_mpmath_golden(golden_dir):
         assert np.allclose(np.tril(g.factors) @ np.tril(g.factors).T, g.noisy_kernel(), rtol=1e-12, atol=1e-13)
 
 
+def test_oracle_matches_mpmath_across_a_tile_edge(golden_dir):
+    """n = 160 (the blocked factorisation of the HIP path crosses its 128-tile edge there) for the three kernel kinds, test
+    rows AT training inputs, 1e-7 away from them and elsewhere: where sigma^2 = k** + noise - |V|^2 cancels three to four
+    digits.  50-digit mpmath values (tests/golden/make_golden.py: gp_edge_cases)."""
+    z = np.load(os.path.join(golden_dir, "gp_edge.npz"))
+    cases = {}
+    for key in z.files:
+        name, field = key.split("/")
+        cases.setdefault(name, {})[field] = z[key]
+    assert sorted(int(c["kind"]) for c in cases.values()) == [0, 1, 2]
+    for name, c in cases.items():
+        assert c["X"].shape[0] == 160 and np.array_equal(c["Xt"][:3], c["X"][[5, 127, 128]])
+        g = ogp.GaussianProcess(c["X"], c["y"], float(c["mean"]), ogp.make_kernel(int(c["kind"]), c["loghyp"]), float(c["logNoise"]),
+                                True).update_cholesky()
+        assert g.info == 0
+        assert abs(g.mll() - float(c["mll"])) <= 1e-10 * abs(float(c["mll"])), name
+        assert np.max(np.abs(g.alpha - c["alpha"])) <= 1e-7 * np.max(np.abs(c["alpha"])), name
+        mu, var = g.prediction(c["Xt"])
+        assert np.allclose(mu, c["mu"], rtol=1e-9, atol=1e-11), name
+        assert np.allclose(var, c["var"], rtol=1e-8, atol=1e-12), name
+        kss = np.diag(ogp.kernelmatrix(g.kernel, c["Xt"][:6], c["Xt"][:6], exact=True))
+        assert np.all(c["var"][:6] < 0.05 * kss)          # the rows at / next to training inputs really cancel: var << k**
+
+
 def test_kernel_forms():
     X = uniform(1, 0, 12).reshape((4, 3), order="F")
     Y = uniform(2, 0, 15).reshape((5, 3), order="F")

@@ -53,7 +53,18 @@ def update_launches(d, counter, per_step=103):
 fu, wu = update_launches("pmc2", "FETCH_SIZE"), update_launches("pmc3", "WRITE_SIZE")
 fetch = sum(float(r["Counter_Value"]) for r in fu) * 1024 * 2     # KB -> B; gfx950 counts 128-B requests of wide reads as 64 B
 write = sum(float(r["Counter_Value"]) for r in wu) * 1024
-res = {"kernel": "tile_gemm_kernel_v2<false, 0, false>: update launches of the last fit (test rows riding along)", "launches": len(fu),
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import subprocess
+import bench  # noqa: E402  (source_stamp: the tree the profile was taken on = the tree this summary is made from)
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "status", "--porcelain", "--", "bench.py", "include", "deepstructuredmixtures_amd/csrc"],
+                           capture_output=True, text=True).stdout.strip()
+    commit = commit + ("+uncommitted" if dirty else "")
+except Exception:
+    commit = "?"
+res = {"source_stamp": bench.source_stamp(), "commit": commit,
+       "kernel": "tile_gemm_kernel_v2<false, 0, false>: update launches of the last fit (test rows riding along)", "launches": len(fu),
        "fetch_bytes_total": fetch, "write_bytes_total": write, "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)),
        "note": "FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024 over the update launches of one fit; separate --pmc passes of "
                "`python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline` (tools/profile_round.sh)"}
