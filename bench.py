@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
     ap.add_argument("--unfused-gram", action="store_true",
                     help="diagnostic: every Gram tile through memory first (DSMGP_OPT_FUSED_GRAM = 0), for A/B runs")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="diagnostic: DSMGP_OPT_LOOKAHEAD = 1 (bulk update on the main stream, finish on a second one), for A/B runs")
+    ap.add_argument("--no-fused-steps", action="store_true", help="diagnostic: DSMGP_OPT_FUSED_STEPS = 0, for A/B runs")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
@@ -339,6 +342,10 @@ def main():
         ctx = model.ctx
     if args.unfused_gram:
         ctx.set_option(dsm.hipabi.OPT_FUSED_GRAM, 0)
+    if args.lookahead:
+        ctx.set_option(dsm.hipabi.OPT_LOOKAHEAD, 1)
+    if args.no_fused_steps:
+        ctx.set_option(dsm.hipabi.OPT_FUSED_STEPS, 0)
     if args.mode == "train":
         return bench_train(args, model, X, y, rank, world, td, torch)
     ctx.set_profile(0 if args.no_profile else 1)   # timed region: events around the update launches only

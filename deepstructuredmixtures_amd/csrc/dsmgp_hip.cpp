@@ -65,6 +65,9 @@ struct HostLog {
     }
 };
 
+enum { STEP_CLASSIC = 0, STEP_FUSED = 1, STEP_LOOKAHEAD = 2 };
+constexpr int FUSED_SHALLOW_STEPS = 4;   // block steps 0..4 (K <= 512) always run fused
+
 struct StepLists {
     // one phase (wave) of factorisation: per block step k the tasks for update / split-K reduce / diag / trsm
     std::vector<int> upd_off, red_off, diag_off, trsm_off;   // size nsteps+1
@@ -75,6 +78,7 @@ struct StepLists {
     DevBuf<DiagTask> diag;
     // steps with more diagonal blocks than CUs run fused (kernels_fused.hpp): diag_fused_kernel, then tile_fused_kernel
     std::vector<int> fdiag_off, ftile_off;                   // size nsteps+1; a fused step has no classic tasks and vice versa
+    std::vector<char> mode;                                  // STEP_* per step (lookahead: upd/red hold the bulk, fdiag/ftile the finish)
     DevBuf<DiagFusedTask> fdiag;
     DevBuf<FusedTask> ftile;
     int nsteps = 0;
@@ -198,6 +202,9 @@ struct UpdateSplitter {
             r.nsplit = S;
             // piece 0 stores product - Gram value, or the tile is defined as -product: nothing to read from it
             r.fresh = (tiles[i].gram != 0 || tiles[i].update == 2) ? 1 : 0;
+            // a whole-tile task with the Gram fused and update = 0 stores product - K (bulk tiles of the lookahead
+            // schedule, which the finish task takes as its accumulator start): split, the reduce must leave +sum of slabs
+            r.neg = (tiles[i].gram != 0 && tiles[i].update == 0) ? 1 : 0;
             red.push_back(r);
             red_slab.push_back((int64_t)(first + (i - from) * S));
         }
@@ -328,7 +335,18 @@ struct dsmgp_ctx {
     DevBuf<GramTask> gram;          // Gram launch of fit!: every lower tile, or (fused) the tiles no update task writes
     bool fuse_gram = true;          // update tasks of fit! evaluate the Gram values of their tile themselves (TileTask.gram)
     bool fuse_steps = true;         // block steps with more diagonal blocks than CUs run as two fused launches (kernels_fused.hpp)
-    std::vector<char> fused_step[2];   // per phase and block step: the step runs fused (decided by build_plan)
+    bool lookahead = false;         // opt-in (DSMGP_OPT_LOOKAHEAD): the other steps run on the lookahead schedule (STEP_LOOKAHEAD)
+    // per phase and block step (decided by build_plan):
+    //   STEP_CLASSIC    update (all tiles, split-K) / reduce / diagonal block / panel solve launches, one after the other
+    //   STEP_FUSED      many leaves: diag_fused_kernel, then tile_fused_kernel, from the kernel function (kernels_fused.hpp)
+    //   STEP_LOOKAHEAD  few leaves: the update of step k is cut at its last block column -- the BULK (columns before
+    //                   k - 1) runs on the main stream as soon as step k - 2 is final, the FINISH (diag_fused_kernel and
+    //                   tile_fused_kernel starting from the bulk's tile: rank-128 update + factorisation / solve) on a side
+    //                   stream after the bulk, beside the bulk of step k + 1: the chain diagonal block -> panel solve no
+    //                   longer sits between two update launches (src/AdvancedCholeskey.jl:161-171 per step, pipelined)
+    std::vector<char> fused_step[2];
+    hipStream_t side = nullptr;     // the finish launches of lookahead steps
+    std::vector<hipEvent_t> ev_bulk, ev_fin;   // per block step (grown on demand, no timing)
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
     // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
@@ -647,7 +665,8 @@ int check_hyper(dsmgp_ctx* c) {
 // 2*K flops (K = 128k) per lower-triangle element of that block column.
 // A PREFIX leaf keeps the leading kb x kb blocks of its source: in block columns k < kb only the rows >= 128 kb are
 // updated (they are the launches of build_factor_steps), the copied part costs nothing.
-double update_flops(int n, int kb = 0) {
+template <class Depth>
+double update_flops(int n, int kb, Depth depth /* block step -> blocks of K the timed launch covers */) {
     double f = 0.0;
     for (int k = 1; k * TB < n; ++k) {
         const int c0 = k * TB, c1 = std::min(n, c0 + TB);
@@ -655,15 +674,16 @@ double update_flops(int n, int kb = 0) {
         if (k < kb) elems = (double)(c1 - c0) * (double)std::max(0, n - kb * TB);
         else
             for (int c = c0; c < c1; ++c) elems += (double)(n - c);
-        f += 2.0 * (double)c0 * elems;
+        f += 2.0 * (double)(depth(k) * TB) * elems;
     }
     return f;
 }
 
 // Per-leaf algorithmic flops of the test rows riding through the sweep: 2*K per (test row, column) element.
-double predict_update_flops(int n, int nt) {
+template <class Depth>
+double predict_update_flops(int n, int nt, Depth depth) {
     double f = 0.0;
-    for (int k = 1; k * TB < n; ++k) f += 2.0 * (double)(k * TB) * (double)nt * (double)std::min(TB, n - k * TB);
+    for (int k = 1; k * TB < n; ++k) f += 2.0 * (double)(depth(k) * TB) * (double)nt * (double)std::min(TB, n - k * TB);
     return f;
 }
 
@@ -709,6 +729,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.ftile_off.assign(nsteps + 1, 0);
         S.step_tiles.assign(nsteps, 0);
         S.pad.assign(nsteps, 0);
+        S.mode.assign(nsteps, STEP_CLASSIC);
         for (int k = 0; k < nsteps; ++k) {
             S.upd_off[k] = (int)U.upd.size();
             S.red_off[k] = (int)U.red.size();
@@ -716,7 +737,13 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             S.diag_off[k] = (int)diag.size();
             S.fdiag_off[k] = (int)fdiag.size();
             S.ftile_off[k] = (int)ftile.size();
-            const bool fstep = k < (int)c->fused_step[ph].size() && c->fused_step[ph][k] != 0;
+            const int mode = k < (int)c->fused_step[ph].size() ? c->fused_step[ph][k] : STEP_CLASSIC;
+            S.mode[k] = (char)mode;
+            const bool fstep = mode != STEP_CLASSIC;               // diagonal blocks and tiles below go through the fused kernels
+            const bool look = mode == STEP_LOOKAHEAD && k >= 2;    // ... which start from the tile a bulk update launch wrote
+            const int kfin0 = look ? (k - 1) * TB : 0;             // first column of the finish tasks' K range
+            const int kfin = look ? TB : k * TB;                   // ... and its length
+            const int kbulk = (k - 1) * TB;                        // the bulk's K range is [0, kbulk)
             std::vector<TileTask> tiles;
             size_t nsym = 0;
             for (int l = 0; l < L; ++l) {
@@ -730,14 +757,37 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                     const bool own_diag = (k >= lf.kb);
                     for (int i = i_first; i < lf.nb; ++i) {
                         if (fstep) {      // fused step: the diagonal tile belongs to the diagonal-block task, the tiles below
-                            if (i == k) continue;                                  // are updated and solved in one task each
+                            if (look) {                                            // are updated and solved in one task each
+                                // lookahead: the bulk of the update (columns before k - 1) is a task of the main stream's
+                                // launch; the diagonal tile keeps K - product, the tiles below product - K: the start
+                                // value of their finish task's accumulators
+                                TileTask u{};
+                                u.A = d.F + (size_t)i * TB;
+                                u.B = d.F + (size_t)k * TB;
+                                u.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
+                                u.lda = u.ldb = u.ldc = ld;
+                                u.k0 = 0;
+                                u.k1 = kbulk;
+                                u.update = (i == k) ? 1 : 0;
+                                u.mrows = tile_mrows(lf.n - i * TB);
+                                u.gram = 1 | (i == k ? 2 : 0) | 4;
+                                u.kid = lf.kid;
+                                u.gxa = d.Xg + (size_t)i * TB;
+                                u.gxb = d.Xg + (size_t)k * TB;
+                                u.glda = u.gldb = ld;
+                                u.gna = std::max(0, std::min(TB, lf.n - i * TB));
+                                u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                                tiles.push_back(u);
+                            }
+                            if (i == k) continue;
                             FusedTask f{};
-                            f.A = d.F + (size_t)i * TB;
-                            f.B = d.F + (size_t)k * TB;
+                            f.A = d.F + (size_t)i * TB + (size_t)kfin0 * ld;
+                            f.B = d.F + (size_t)k * TB + (size_t)kfin0 * ld;
                             f.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
                             f.Dinv = d.Dinv + (size_t)k * TB * TB;
                             f.lda = f.ldb = f.ldc = ld;
-                            f.k1 = k * TB;
+                            f.k1 = kfin;
+                            f.mem = look ? 1 : 0;
                             f.gxa = d.Xg + (size_t)i * TB;
                             f.gxb = d.Xg + (size_t)k * TB;
                             f.glda = f.gldb = ld;
@@ -810,9 +860,10 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         if (fstep) {
                             DiagFusedTask fg{};
                             fg.d = g;
-                            fg.A = d.F + (size_t)k * TB;
+                            fg.A = d.F + (size_t)k * TB + (size_t)kfin0 * ld;
                             fg.gx = d.Xg + (size_t)k * TB;
-                            fg.k1 = k * TB;
+                            fg.k1 = kfin;
+                            fg.mem = look ? 1 : 0;
                             fg.glda = ld;
                             fg.kid = lf.kid;
                             fdiag.push_back(fg);
@@ -825,15 +876,38 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                     for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
                         double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
                         if (fstep) {
+                            if (look) {          // bulk task of the test-row tile: product - K_tn over the columns before k - 1
+                                TileTask u{};
+                                u.A = d.Vt + (size_t)ti * TB;
+                                u.B = d.F + (size_t)k * TB;
+                                u.C = tile;
+                                u.lda = lf.ntpad;
+                                u.ldb = ld;
+                                u.ldc = lf.ntpad;
+                                u.k0 = 0;
+                                u.k1 = kbulk;
+                                u.update = 0;
+                                u.mrows = tile_mrows(lf.nt - ti * TB);
+                                u.gram = 1;
+                                u.kid = lf.kid;
+                                u.gxa = d.Xtg + (size_t)ti * TB;
+                                u.gxb = d.Xg + (size_t)k * TB;
+                                u.glda = lf.ntpad;
+                                u.gldb = ld;
+                                u.gna = std::max(0, std::min(TB, lf.nt - ti * TB));
+                                u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                                tiles.push_back(u);
+                            }
                             FusedTask f{};
-                            f.A = d.Vt + (size_t)ti * TB;
-                            f.B = d.F + (size_t)k * TB;
+                            f.A = d.Vt + (size_t)ti * TB + (size_t)kfin0 * lf.ntpad;
+                            f.B = d.F + (size_t)k * TB + (size_t)kfin0 * ld;
                             f.C = tile;
                             f.Dinv = d.Dinv + (size_t)k * TB * TB;
                             f.lda = lf.ntpad;
                             f.ldb = ld;
                             f.ldc = lf.ntpad;
-                            f.k1 = k * TB;
+                            f.k1 = kfin;
+                            f.mem = look ? 1 : 0;
                             f.gxa = d.Xtg + (size_t)ti * TB;
                             f.gxb = d.Xg + (size_t)k * TB;
                             f.glda = lf.ntpad;
@@ -912,7 +986,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 }
                 S.pad[k] = (npad * 10 >= ntot && ntot >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
             }
-            U.add_step(tiles, k * TB);
+            U.add_step(tiles, look ? kbulk : k * TB);
             S.step_tiles[k] = (int)tiles.size();
             {   // panel solves of a leaf read the same Dinv_k: keep them on one XCD (small leaves have 3-4 of them per
                 // step; dealt round-robin every one of them fetched the 128 KB block from HBM on its own: the depth-4
@@ -947,10 +1021,15 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             if (int rc = dev_upload(c, phase[ph].red, split[ph].red)) return rc;
         }
     }
+    // algorithmic flops of the launches timed as "update" (slot 1): 2 K per element of block column k, with K = 128 k --
+    // or 128 (k - 1) where the step runs on the lookahead schedule (its bulk launch stops one block column short; the
+    // last rank-128 update belongs to the finish tasks)
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
-        if (lf.owner == l) alg_flops += update_flops(lf.n, lf.kb);
-        if (with_test && lf.nt > 0) alg_flops += predict_update_flops(lf.n, lf.nt);
+        const std::vector<char>& md = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
+        auto depth = [&](int k) { return (k < (int)md.size() && md[k] == STEP_LOOKAHEAD) ? std::max(0, k - 1) : k; };
+        if (lf.owner == l) alg_flops += update_flops(lf.n, lf.kb, depth);
+        if (with_test && lf.nt > 0) alg_flops += predict_update_flops(lf.n, lf.nt, depth);
     }
     return 0;
 }
@@ -1045,21 +1124,25 @@ int build_plan(dsmgp_ctx* c) {
         HIPCHK(c, hipGetLastError());
     }
 
-    // Which block steps run fused (kernels_fused.hpp): those whose diagonal blocks alone fill the chip -- the same rule
-    // as the choice of the packed diagonal-block kernel, so a step factorises its blocks with the same code either way
+    // How every block step runs (STEP_*).  Fused: the steps whose diagonal blocks alone fill the chip -- the same rule as the
+    // choice of the packed diagonal-block kernel.  Lookahead: the others, when the Gram values are evaluated in the tasks.
     for (int ph = 0; ph < 2; ++ph) {
         int ns = 0;
         for (const LeafHost& lf : c->leaves)
             if ((lf.op == DSMGP_SHARE_PREFIX) == (ph == 1)) ns = std::max(ns, lf.nb);
-        c->fused_step[ph].assign(ns, 0);
-        if (!c->fuse_steps || !gram_fused(c)) continue;
+        c->fused_step[ph].assign(ns, STEP_CLASSIC);
+        if (!gram_fused(c)) continue;
         for (int k = 0; k < ns; ++k) {
             int nd = 0;
             for (int l = 0; l < L; ++l) {
                 const LeafHost& lf = c->leaves[l];
                 if ((lf.op == DSMGP_SHARE_PREFIX) == (ph == 1) && lf.owner == l && lf.nb > k && k >= lf.kb) ++nd;
             }
-            c->fused_step[ph][k] = nd > c->ncu ? 1 : 0;
+            // fused: the diagonal blocks alone fill the chip -- or the step is shallow (K <= 512: the one workgroup that
+            // updates a diagonal tile before factorising it is done in a few microseconds; deeper, that update belongs in
+            // the many-workgroup update launch, split along K)
+            if (c->fuse_steps && (nd > c->ncu || k <= FUSED_SHALLOW_STEPS)) c->fused_step[ph][k] = STEP_FUSED;
+            else if (c->lookahead) c->fused_step[ph][k] = STEP_LOOKAHEAD;
         }
     }
     // Gram tasks: lower tiles of every owner; with the Gram fused into the update tasks only the tiles that have none --
@@ -1072,7 +1155,7 @@ int build_plan(dsmgp_ctx* c) {
         if (lf.owner != l) continue;
         {
             const std::vector<char>& fs = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
-            if (fused && !fs.empty() && fs[0]) continue;
+            if (fused && !fs.empty() && fs[0] != STEP_CLASSIC) continue;
         }
         const LeafDev& d = c->h_leaves[l];
         for (int j = 0; j < (fused ? 1 : lf.nb); ++j)
@@ -1230,7 +1313,7 @@ struct PhaseTimer {
         }
         return (int)used++;
     }
-    void begin(int slot) {
+    void begin(int slot, hipStream_t st = nullptr) {
         on = c->profile >= 2 || (c->profile == 1 && slot == 1);
         if (!on) return;
         const int a = take(), b = take();
@@ -1238,7 +1321,7 @@ struct PhaseTimer {
             on = false;
             return;
         }
-        (void)hipEventRecord(c->event_pool[a], c->stream);
+        (void)hipEventRecord(c->event_pool[a], st ? st : c->stream);
         spans.push_back({slot, a, b, -1, 0, 0});
     }
     void note(int step, int ntasks, int nred) {
@@ -1248,9 +1331,9 @@ struct PhaseTimer {
             spans.back().red = nred;
         }
     }
-    void end() {
+    void end(hipStream_t st = nullptr) {
         if (!on) return;
-        (void)hipEventRecord(c->event_pool[spans.back().e1], c->stream);
+        (void)hipEventRecord(c->event_pool[spans.back().e1], st ? st : c->stream);
     }
     void collect() {
         const bool log = std::getenv("DSMGP_STEPLOG") != nullptr;
@@ -1266,10 +1349,75 @@ struct PhaseTimer {
     }
 };
 
-// One factorisation phase: for every block step, update (-> split-K reduce) -> diagonal -> panel solve.
+// One factorisation phase.  Classic step: update (-> split-K reduce) -> diagonal block -> panel solve, on the context's
+// stream.  Fused step (many leaves): diag_fused_kernel -> tile_fused_kernel, same stream.  Lookahead step k: the bulk update
+// (-> reduce) on the context's stream once step k - 2 is final; the finish -- diag_fused_kernel, tile_fused_kernel -- on the
+// side stream once the bulk and step k - 1 are done.  ev_fin[k] marks step k final on whichever stream finished it.
 int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
+    auto grow = [&](std::vector<hipEvent_t>& v, int n) -> bool {
+        while ((int)v.size() < n) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+            v.push_back(e);
+        }
+        return true;
+    };
+    bool any_look = false;
+    for (int k = 0; k < S.nsteps; ++k) any_look = any_look || S.mode[k] == STEP_LOOKAHEAD;
+    if (any_look && (!c->side || !grow(c->ev_bulk, S.nsteps + 1) || !grow(c->ev_fin, S.nsteps + 1)))
+        return fail(c, DSMGP_E_HIP, "lookahead schedule: cannot create events");
+    std::vector<char> fin_on_side(S.nsteps, 0);     // where step k became final
+    hipEvent_t ev_start = nullptr;
+    if (any_look) {   // everything queued on the context's stream so far (Gram launch, rhs copy, a previous phase) precedes the side stream's work
+        ev_start = c->ev_bulk[S.nsteps];
+        HIPCHK(c, hipEventRecord(ev_start, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side, ev_start, 0));
+    }
+    auto main_waits_step = [&](int k) -> int {      // the context's stream needs step k final
+        if (k >= 0 && fin_on_side[k]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fin[k], 0));
+        return 0;
+    };
     for (int k = 0; k < S.nsteps; ++k) {
         const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
+        const int nu = S.upd_off[k + 1] - S.upd_off[k];
+        if (S.mode[k] == STEP_LOOKAHEAD) {
+            if (nu > 0) {       // bulk: reads the columns before k - 1
+                if (int rc = main_waits_step(k - 2)) return rc;
+                pt.begin(1);
+                launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0);
+                pt.note(k, nu, S.step_tiles[k]);
+                pt.end();
+                const int nr = S.red_off[k + 1] - S.red_off[k];
+                if (nr > 0) {
+                    pt.begin(13);
+                    tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
+                    pt.end();
+                }
+                if (count_launches) c->n_update_launches++;
+                HIPCHK(c, hipEventRecord(c->ev_bulk[k], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_bulk[k], 0));
+            }
+            if (k > 0 && !fin_on_side[k - 1]) {     // the previous step finished on the context's stream
+                HIPCHK(c, hipEventRecord(c->ev_fin[k - 1], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fin[k - 1], 0));
+            }
+            if (nfd > 0) {
+                pt.begin(2, c->side);
+                diag_fused_kernel<<<nfd, 256, DIAGP_LDS_BYTES, c->side>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
+                pt.note(k, nfd, 0);
+                pt.end(c->side);
+            }
+            if (nft > 0) {
+                pt.begin(3, c->side);
+                tile_fused_kernel<<<nft, 256, 0, c->side>>>(S.ftile.p + S.ftile_off[k], c->d_kp, c->D);
+                pt.note(k, nft, 0);
+                pt.end(c->side);
+            }
+            HIPCHK(c, hipEventRecord(c->ev_fin[k], c->side));
+            fin_on_side[k] = 1;
+            continue;
+        }
+        if (int rc = main_waits_step(k - 1)) return rc;
         if (nfd > 0 || nft > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
             if (nfd > 0) {
                 pt.begin(2);
@@ -1286,7 +1434,6 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
             }
             continue;
         }
-        const int nu = S.upd_off[k + 1] - S.upd_off[k];
         if (nu > 0) {
             pt.begin(1);
             launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0);
@@ -1317,6 +1464,9 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
             pt.end();
         }
     }
+    // the context's stream continues (next phase, forward solves, mll) only when the last steps are final
+    for (int k = std::max(0, S.nsteps - 2); k < S.nsteps; ++k)
+        if (int rc = main_waits_step(k)) return rc;
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1362,6 +1512,14 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         delete c;
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
+    {   // side stream of the lookahead schedule: its launches are the dependent chain, so they go first when slots free up
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            c->side = nullptr;
+        }
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
@@ -1401,6 +1559,9 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->d_l2);
     (void)dsmgp_comm_destroy(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_bulk) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_fin) (void)hipEventDestroy(e);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1448,6 +1609,16 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
             free_test(c);
         }
         c->fuse_steps = value != 0;
+        return 0;
+    }
+    if (option == DSMGP_OPT_LOOKAHEAD) {
+        if (value != 0 && !c->side) return fail(c, DSMGP_E_STATE, "lookahead schedule: no second stream on this device");
+        if ((value != 0) != c->lookahead) {
+            HIPCHK(c, hipSetDevice(c->device));
+            free_plan(c);
+            free_test(c);
+        }
+        c->lookahead = value != 0;
         return 0;
     }
     return fail(c, DSMGP_E_ARG, "set_option: unknown option");
@@ -1877,7 +2048,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
             // where step 0 runs fused, the tasks of block column 0 evaluate their K_tn tile themselves.  A COPY leaf rides
             // with its source's phase (phase 0: a source is factorised in full)
             const std::vector<char>& fs = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
-            const bool step0_fused = gram_fused(c) && !fs.empty() && fs[0];
+            const bool step0_fused = gram_fused(c) && !fs.empty() && fs[0] != STEP_CLASSIC;
             for (int ti = 0; ti < lf.ntpad / TB; ++ti)
                 for (int j = 0; j < lf.nb; ++j, ++q)
                     if (j == 0 && !step0_fused) pg0.push_back(pg[q]);

@@ -1407,6 +1407,8 @@ struct ReduceTask {
     int ldc;
     int nsplit;
     int fresh;             // 1: the tile is not read (C = -(slab_0 + ...)): slab 0 already holds product - Gram value
+    int neg;               // 1: the result is stored negated (C = +(slab_0 + ...) for a fresh tile): tiles the lookahead
+                           //    schedule's finish task starts from hold -(K - product)
 };
 
 // REDUCE_WGS workgroups per tile (16 columns each); a thread owns two rows of four columns and keeps the loads of
@@ -1430,7 +1432,7 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(const ReduceTask* __re
 #pragma unroll
     for (int i = 0; i < 4; ++i) cv[i] = tk.fresh ? d2{0.0, 0.0} : *reinterpret_cast<const d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc) = cv[i] - s[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc) = tk.neg ? s[i] - cv[i] : cv[i] - s[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1809,9 +1811,12 @@ __constant__ const PackedMap PACKED{};
 
 // have_image: the caller has already put the lower blocks of the tile into the image (diag_fused_kernel: straight from
 // the accumulators of the tile's update); the barrier below makes them visible
+// Roles rotate with the workgroup index: the wave that runs the pivot chain (role 0: potrf_inv16, a long dependent VALU
+// sequence) is hardware wave (blockIdx & 3)'s neighbour rather than always wave 0, so the two workgroups sharing a CU usually
+// run their chains on different SIMDs instead of interleaving them on SIMD 0.
 __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double* S, bool have_image) {
     const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int w = (__builtin_amdgcn_readfirstlane(t >> 6) + (int)(blockIdx.x & 3)) & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
     double* wl = S + PIMG;                 // right-hand side block w_k, updated in place by the fused forward substitution
     double* zl = S + PIMG + TB;            // z_k = L_kk^-1 w_k
@@ -1961,7 +1966,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
                 run_pair(o0, two ? op_p2(task + 3) : o0, two, true);
             }
             // w_I -= L(I,J) z_J for the rows below block J, one row per thread of the waves 1..3
-            const int row = 16 * (J + 1) + (t - 64);
+            const int row = 16 * (J + 1) + 64 * (w - 1) + lane;      // (w = role 1..3: 192 threads for at most 112 rows)
             if (fuse && row < TB) {
                 const double* lrow = S + soff[(row >> 4) * 8 + J] + (row & 15);
                 double sum = 0.0;

@@ -42,7 +42,10 @@ struct FusedTask {
     int kid;
     int mrows;            // rows that hold data, rounded up to 16; 0 = all 128.  <= 64: a wave takes 16 rows instead of 32
     int zpad;             // tile of the factor: its padding rows are written here too (zeros)
-    int pad[3];
+    int mem;              // 1: the task starts from the tile in memory, which holds -(K(i,k) - A' B'^T) over the columns BEFORE the
+                          //    K range of this task (lookahead schedule: a bulk update launch wrote it), instead of from the
+                          //    kernel function; A, B then point at the last block column and k1 = 128
+    int pad[2];
 };
 static_assert(sizeof(FusedTask) == 128, "FusedTask is read with scalar loads: keep it two cache lines");
 
@@ -50,16 +53,43 @@ struct DiagFusedTask {
     DiagTask d;           // the diagonal block: T (the tile of F), Dinv, wk / zk, info, ld, nvalid, row0
     const double* A;      // F[k, 0:K]: the block row left of the tile, ld = d.ld
     const double* gx;     // coordinates of the block's points, ld glda
-    int k1, glda, kid, pad;
+    int k1, glda, kid;
+    int mem;              // 1: S starts from the tile in memory (= K(k,k) minus the product over the columns before A's: the bulk
+                          //    update of the lookahead schedule wrote it) instead of from the kernel function
 };
 
 // Row-split tile product: wave w owns the rows RW w .. RW w + RW - 1 (RW = 16 NRW: 32 for a whole tile, 16 for a tile of
 // at most 64 data rows) and ALL 128 columns, acc[8][NRW] -- whole rows of the tile in one wave are what the solve that
 // follows needs.  Ring, prefetch and barrier protocol of gemm_mainloop_v2; rows 64.. of the A panel are not staged for
 // NRW = 1.
+// The first two chunks of the operand panels, loaded by rowsplit_prefetch BEFORE the task's kernel-function phase so that
+// their memory latency passes under its arithmetic; gemm_mainloop_rowsplit starts from them.
+struct RowsplitPrefetch {
+    d2 ra0[2], rb0[2], ra1[2], rb1[2];
+};
+template <int NRW>
+__device__ __forceinline__ void rowsplit_prefetch(const double* A, int lda, const double* B, int ldb, int K, RowsplitPrefetch& pf) {
+    const int t = threadIdx.x;
+    const int nch = K / KC2;
+    if (nch <= 0) return;
+    const int scol = t >> 5, srow = 2 * (t & 31);
+    const double* gA = A + srow + (size_t)scol * lda;
+    const double* gB = B + srow + (size_t)scol * ldb;
+    const size_t o1a = (size_t)min(1, nch - 1) * KC2 * lda, o1b = (size_t)min(1, nch - 1) * KC2 * ldb;
+    pf.ra0[0] = *AS_GLOBAL_D2(gA);
+    if (NRW > 1) pf.ra0[1] = *AS_GLOBAL_D2(gA + 64);
+    pf.rb0[0] = *AS_GLOBAL_D2(gB);
+    pf.rb0[1] = *AS_GLOBAL_D2(gB + 64);
+    pf.ra1[0] = *AS_GLOBAL_D2(gA + o1a);
+    if (NRW > 1) pf.ra1[1] = *AS_GLOBAL_D2(gA + o1a + 64);
+    pf.rb1[0] = *AS_GLOBAL_D2(gB + o1b);
+    pf.rb1[1] = *AS_GLOBAL_D2(gB + o1b + 64);
+}
+
 template <int NRW>
 __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda, const double* B, int ldb, int K,
-                                                       d4 (&acc)[8][NRW], double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP]) {
+                                                       d4 (&acc)[8][NRW], double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
+                                                       const RowsplitPrefetch& pf) {
     // acc comes in initialised by the caller (-K(i,k): rowsplit_gram_init) and goes out as acc + A B^T
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -78,6 +108,13 @@ __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda,
     const int sOff = scol * LDP + srow;
     const int rowoff = 16 * NRW * w + l15;
     d2 ra0[2], rb0[2], ra1[2], rb1[2];
+#pragma unroll
+    for (int i_ = 0; i_ < 2; ++i_) {
+        ra0[i_] = pf.ra0[i_];
+        rb0[i_] = pf.rb0[i_];
+        ra1[i_] = pf.ra1[i_];
+        rb1[i_] = pf.rb1[i_];
+    }
 #define FGLOAD(RA, RB, CH)                                                                       \
     do {                                                                                         \
         const size_t oa_ = (size_t)(CH) * KC2 * lda, ob_ = (size_t)(CH) * KC2 * ldb;             \
@@ -119,9 +156,7 @@ __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda,
         if constexpr (NI_REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, NI_REST, 0);      \
     } while (0)
     const int nch = K / KC2;
-    if (nch > 0) {
-        FGLOAD(ra0, rb0, 0);
-        FGLOAD(ra1, rb1, min(1, nch - 1));
+    if (nch > 0) {      // chunks 0 and 1 arrive in `pf`
         FSWRITE(ra0, rb0, 0);
         FGLOAD(ra0, rb0, min(2, nch - 1));
         FSWRITE(ra1, rb1, 1);
@@ -233,8 +268,9 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     // Dinv_k's 36 lower blocks go global (L2: the diagonal-block launch of this step wrote them) -> registers -> LDS in two
-    // halves of 9 loads per thread.  The first half is issued NOW and lands under the kernel-function arithmetic and the
-    // product; the second is issued when the first goes to LDS and lands under the first two block columns of the solve.
+    // halves of 9 loads per thread, both issued when the product is done: the second lands under the first two block
+    // columns of the solve.  (Issuing the first half before the product, held in registers across it, measured the same:
+    // depth 4 0.0584 / 0.0598 / 0.0589 without against 0.0625 / 0.0596 / 0.0586 s with, same box, alternating.)
     // Thread t moves the doubles 2 (t & 127), + 1 of block 2 e + (t >> 7).
     const int dj = (t & 127) >> 3, di = 2 * (t & 7), dhalf = __builtin_amdgcn_readfirstlane(t >> 7);
     auto dinv_load = [&](int e) {
@@ -242,11 +278,20 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
         const int cb = LOWER_BLOCKS.cb[b], jb = LOWER_BLOCKS.jb[b];
         return *AS_GLOBAL_D2(tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB);
     };
-    d2 dv[9];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) dv[e] = dinv_load(e);
+    RowsplitPrefetch pf;
+    rowsplit_prefetch<NRW>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, pf);
     d4 acc[8][NRW];
-    {   // acc = -k(row, col): coordinates through the (still unused) ring
+    if (tk.mem) {   // acc = the tile as the bulk update left it (-C over the earlier columns): 64 NRW loads in flight per lane
+        const unsigned lofs0 = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * q) * (size_t)tk.ldc);
+#pragma unroll
+                for (int rn = 0; rn < NRW; ++rn) acc[cb][rn][q] = col[lofs0 + 16 * rn];
+            }
+    } else {        // acc = -k(row, col): coordinates through the (still unused) ring
         const KParam p = kp[tk.kid];
         double* sa = &sA[0][0];
         double* sb = &sB[0][0];
@@ -261,8 +306,11 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
         else rowsplit_gram_init<2, NRW>(tk, p, D, acc, sa, sb);
         __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
     }
-    gemm_mainloop_rowsplit<NRW>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB);   // acc = -C; ends on a barrier: the ring is free
+    gemm_mainloop_rowsplit<NRW>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB, pf);   // acc = -C; ends on a barrier: the ring is free
     double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256
+    d2 dv[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) dv[e] = dinv_load(e);
     d2 dw[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) dw[e] = dinv_load(9 + e);
@@ -410,18 +458,40 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
 }
 
 template <int SHAPE>
-__device__ __forceinline__ void diag_fused_front(const TileTask& tt, const KParam* __restrict__ kp, int D, double* S, const int (&blk)[6]) {
+__device__ __forceinline__ void diag_fused_front(const TileTask& tt, bool mem, const KParam* __restrict__ kp, int D, double* S,
+                                                 const int (&blk)[6]) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
     d4 acc[9];
     syrk_mainloop<SHAPE>(tt, acc, sA, blk);                 // ends on a barrier: the ring is free
-    const KParam p = kp[tt.kid];
-    gram_stage_coords(tt, D, S, nullptr, false);            // coordinates over the ring (barrier inside)
-    if (p.kind == 0) syrk_gram_inplace<SHAPE, 0>(tt, p, D, acc, blk, S);
-    else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1>(tt, p, D, acc, blk, S);
-    else syrk_gram_inplace<SHAPE, 2>(tt, p, D, acc, blk, S);
-    __syncthreads();                                        // the coordinates are no longer read: the image takes their place
+    if (mem) {
+        // lookahead schedule: the tile holds K(k,k) minus the product over the earlier columns (the bulk update wrote it):
+        // S = tile - product over this task's columns, block by block in the accumulator layout (36 loads in flight)
+        const size_t ldc = (size_t)tt.ldc;
+        double cv[9][4];
+#pragma unroll
+        for (int g3 = 0; g3 < 3; ++g3)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int rb = (SHAPE == 0) ? blk[g3] : blk[2 * g3 + (j > 0 ? 1 : 0)];
+                const int cb = (SHAPE == 0) ? blk[3 + j] : blk[2 * g3 + (j > 1 ? 1 : 0)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cv[3 * g3 + j][r] = AS_GLOBAL_F64(tt.C)[(size_t)(16 * rb + l15) + (size_t)(16 * cb + l4 + 4 * r) * ldc];
+            }
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] = cv[i][r] - acc[i][r];
+    } else {
+        const KParam p = kp[tt.kid];
+        gram_stage_coords(tt, D, S, nullptr, false);        // coordinates over the ring (barrier inside)
+        if (p.kind == 0) syrk_gram_inplace<SHAPE, 0>(tt, p, D, acc, blk, S);
+        else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1>(tt, p, D, acc, blk, S);
+        else syrk_gram_inplace<SHAPE, 2>(tt, p, D, acc, blk, S);
+        __syncthreads();                                    // the coordinates are no longer read: the image takes their place
+    }
 #pragma unroll
     for (int g3 = 0; g3 < 3; ++g3)
 #pragma unroll
@@ -453,14 +523,17 @@ __global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask*
     tt.gxa = ft.gx;
     tt.glda = ft.glda;
     tt.gna = tt.gnb = ft.d.nvalid;
+    tt.C = ft.d.T;
+    tt.ldc = ft.d.ld;
+    const bool mem = ft.mem != 0;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w == 3) {
         const int blk[6] = {0, 1, 3, 4, 6, 7};
-        diag_fused_front<1>(tt, kp, D, S, blk);
+        diag_fused_front<1>(tt, mem, kp, D, S, blk);
     } else {
         const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
         const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
-        diag_fused_front<0>(tt, kp, D, S, blk);
+        diag_fused_front<0>(tt, mem, kp, D, S, blk);
     }
     chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
 }
