@@ -88,7 +88,8 @@ def default_sub(world):
 def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
     """Oracle ("port" of the reference's per-leaf arithmetic, LAPACK via SciPy) on a bounded sample of
     the same workload: whole leaves, lean form (one potrf per leaf, diag-only variance), timed on the
-    host cores and scaled to the full leaf table by the cost model n^3/3 + n^2 (n_t + 2).  The sample always holds
+    host cores; every other leaf is priced with the cost model n^3/3 + n^2 (n_t + 2) at the measured rate interpolated
+    over the leaf size.  The sample always holds
     the largest and the smallest leaf; one mid-size leaf is held out of the scaling and predicted by it (the model's
     extrapolation error is part of the result); "as written" is timed on eight leaves."""
     from oracle import gp as ogp
@@ -126,10 +127,13 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
         if spent > budget_s:
             break
     sample = list(times)
-    done_cost = float(sum(cost[j] for j in sample))
-    est = spent * cost.sum() / done_cost
+    # extrapolation: the measured rate (model flops per second) interpolated over the leaf size -- LAPACK runs the small
+    # leaves at a tenth of the rate of the large ones, so one pooled rate would be wrong for both
+    by_n = sorted(sample, key=lambda j: nobs[j])
+    rate = lambda n: np.interp(n, [nobs[j] for j in by_n], [cost[j] / times[j] for j in by_n])  # noqa: E731
+    est = float(np.sum(cost / rate(nobs)))
     t_held = lean(held)
-    pred_held = spent * cost[held] / done_cost
+    pred_held = float(cost[held] / rate(nobs[held]))
     try:
         import threadpoolctl
         threads = max([p["num_threads"] for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] or [1])
@@ -153,7 +157,7 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
     return {"value": est, "unit": "s", "cores": int(threads), "kind": "port",
             "sample": f"{len(sample)} of {model.L} leaves (n={int(nobs[sample].min())}..{int(nobs[sample].max())}, the largest leaf "
                       f"included) timed {spent:.1f} s with the NumPy/LAPACK oracle, one potrf per leaf + alpha + diag-only predict; "
-                      f"scaled by (n^3/3 + n^2(n_t+2)) to all leaves",
+                      f"every other leaf priced at n^3/3 + n^2(n_t+2) flops over the measured rate interpolated at its size",
             "per_leaf_gflops": [{"n": int(nobs[j]), "seconds": round(times[j], 4), "gflops": round(cost[j] / times[j] / 1e9, 1)}
                                 for j in by_size],
             "held_out_leaf": {"n": int(nobs[held]), "measured_s": t_held, "predicted_s": pred_held,
@@ -370,7 +374,7 @@ def main():
         step()
     sync_all()
     t0 = time.perf_counter()
-    upd_s, upd_launches, fit_s, pred_s = 0.0, 0, 0.0, 0.0
+    upd_s, upd_launches, fused_launches, fit_s, pred_s = 0.0, 0, 0, 0.0, 0.0
     cats = {}
     for _ in range(args.steps):
         mu, var = step()
@@ -379,6 +383,7 @@ def main():
             cats[k] = cats.get(k, 0.0) + v
         fl, nl = ctx.work()
         upd_launches += nl
+        fused_launches += ctx.work_fused()[1]
     sync_all()
     elapsed = time.perf_counter() - t0
     if not args.no_profile:   # one more, untimed, step with every category timed: the breakdown printed below
@@ -386,7 +391,7 @@ def main():
         ctx.set_profile(2)
         step()
         cats = {k: v * args.steps for k, v in ctx.timings().items()}
-        for k in ("chol_update", "total_fit", "total_predict"):   # these come from the timed region itself
+        for k in ("chol_update", "chol_fused", "total_fit", "total_predict"):   # these come from the timed region itself
             cats[k] = timed.get(k, 0.0)
         ctx.set_profile(1)
     if td is not None:
@@ -396,16 +401,29 @@ def main():
     per_step = elapsed / args.steps
     assert args.simulate_shard or (np.all(np.isfinite(mu)) and np.all(var > 0))
 
-    # roofline of the dominant kernel (f64-MFMA Cholesky update) on this rank
+    # roofline of the dominant kernel on this rank: the f64-MFMA update launches (tile_gemm_kernel_v2) -- or, where the fused
+    # block steps dominate (many small leaves), the fused tile launches (tile_fused_kernel: update + solve)
     alg_flops, _ = ctx.work()
+    alg_fused, _ = ctx.work_fused()
     roof = None
-    if not args.no_profile and cats.get("chol_update", 0.0) > 0:
-        avg_launch = cats["chol_update"] / max(1, upd_launches)
-        flops_per_launch = alg_flops * args.steps / max(1, upd_launches)
+    fused_dominant = cats.get("chol_fused", 0.0) > cats.get("chol_update", 0.0)
+    if not args.no_profile and max(cats.get("chol_update", 0.0), cats.get("chol_fused", 0.0)) > 0:
+        if fused_dominant:
+            t_cat, n_l, fl_step = cats["chol_fused"], fused_launches, alg_fused
+            kname = ("tile_fused_kernel (fused block steps: update of a tile from the kernel function, solve against the step's "
+                     "diagonal block from the accumulators, one write; algorithmic flops = update + c_k^2 per solved row)")
+        else:
+            t_cat, n_l, fl_step = cats["chol_update"], upd_launches, alg_flops
+            kname = ("tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along, each task "
+                     "evaluating the kernel function of its own tile; <false, 0, true> in launches with >= 10 % short tiles; "
+                     "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel, the shallow block steps "
+                     "(K <= 512) as diag_fused_kernel + tile_fused_kernel: all timed apart, device_seconds_per_step)")
+        avg_launch = t_cat / max(1, n_l)
+        flops_per_launch = fl_step * args.steps / max(1, n_l)
         achieved = flops_per_launch / avg_launch / 1e12
         traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-        if os.path.exists(tpath) and world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard:
+        if os.path.exists(tpath) and world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard and not fused_dominant:
             # PMC counters cannot be collected inside this run: the figure is the one of the committed rocprofv3 --pmc
             # passes of this same command (tools/profile_round.sh), NOT a measurement of this run -- and it is quoted only
             # while the sources it was taken on are the sources that run now
@@ -419,13 +437,8 @@ def main():
                                   f"this tree is {source_stamp()}")
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along, each task "
-                          "evaluating the kernel function of its own tile; <false, 0, true> "
-                          "in launches with >= 10 % padding-row tiles; "
-                          "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel; the reduce "
-                          "launches are timed apart: device_seconds_per_step.chol_reduce)",
-                "avg_launch_ms": avg_launch * 1e3, "launches_per_step": upd_launches // args.steps,
-                "alg_flops_per_step": alg_flops}
+                "kernel": kname, "avg_launch_ms": avg_launch * 1e3, "launches_per_step": n_l // args.steps,
+                "alg_flops_per_step": fl_step}
     nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)
     matrix_flops_total = float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2 * np.diff(ptr)))   # Cholesky + predict solves
 

@@ -84,6 +84,21 @@ struct StepLists {
     int nsteps = 0;
 };
 
+// Merged schedule of two leaf groups A and B over their common prefix of fused steps (step_fused_kernel): launch 2k carries
+// the diagonal blocks of A's step k next to the tiles of B's step k - 1, launch 2k + 1 the tiles of A's step k next to the
+// diagonal blocks of B's step k, and a last one B's remaining tiles.  A diagonal block is a long dependent chain that
+// leaves the matrix pipe idle, a tile task is pipe-bound: mixed, a CU mostly holds one of each.
+struct MergedPlan {
+    struct Launch {
+        const DiagFusedTask* dt;
+        const FusedTask* tt;
+        int n, off;
+    };
+    int ksteps = 0;                 // block steps covered (both groups fused in all of them)
+    std::vector<Launch> launches;
+    DevBuf<int> order;
+};
+
 // Collects the update tiles of one block step and splits their K range over several workgroups when
 // the step has too few tiles to fill the chip (tail of the factorisation, prediction sweeps).
 // Cost model in units of one K column on one CU: a workgroup costs (K/S + C0), rounds = ceil(T*S / CUs).
@@ -344,17 +359,20 @@ struct dsmgp_ctx {
     //                   tile_fused_kernel starting from the bulk's tile: rank-128 update + factorisation / solve) on a side
     //                   stream after the bulk, beside the bulk of step k + 1: the chain diagonal block -> panel solve no
     //                   longer sits between two update launches (src/AdvancedCholeskey.jl:161-171 per step, pipelined)
-    std::vector<char> fused_step[2];
+    std::vector<char> fused_step[3];
     hipStream_t side = nullptr;     // the finish launches of lookahead steps
     std::vector<hipEvent_t> ev_bulk, ev_fin;   // per block step (grown on demand, no timing)
-    StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
+    StepLists phase[3];             // 0: FULL leaves (group A), 1: PREFIX leaves (need their source first), 2: FULL leaves, group B
+    std::vector<char> leaf_group;   // per leaf: the phase it belongs to (COPY leaves ride with their source)
+    bool two_groups = false;        // many leaves: the FULL leaves are two groups whose fused steps run merged (MergedPlan)
+    MergedPlan mergedF, mergedJ;
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
     // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
     // allocation (5 s per 230 GB group measured), which dominated the streaming mode's wall time.
     char* pool_base = nullptr;
     size_t pool_cap = 0, pool_top = 0, pool_mark_plan = 0;
     double* slabF = nullptr;        // split-K workspace of the factorisation
-    StepLists phaseJ[2];            // the same with the resident test rows riding along (built by set_test)
+    StepLists phaseJ[3];            // the same with the resident test rows riding along (built by set_test)
     double* slabJ = nullptr;
     double alg_flops_joint = 0.0;
     bool joint = true;              // fit advances the resident test rows too
@@ -434,6 +452,8 @@ struct dsmgp_ctx {
     double timings[DSMGP_N_TIMINGS] = {0};
     std::vector<hipEvent_t> event_pool;   // PhaseTimer's events, reused across calls
     double alg_flops_update = 0.0;  // algorithmic flops of the Cholesky update launches
+    double alg_flops_fused = 0.0, alg_flops_fused_joint = 0.0;   // ... of the fused tile launches (update + solve), fit alone / joint
+    int n_fused_launches = 0;
     bool phase_ready = false;       // `phase` (fit! without resident test rows) has been built for the current plan
     int n_update_launches = 0;
 };
@@ -534,6 +554,8 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.ftile.p);
     }
     arena_put(c, c->slabF);
+    dev_free(c->mergedF.order.p);
+    c->mergedF = MergedPlan{};
     dev_free(c->fwd.p);
     dev_free(c->bwd.p);
     free_grad(c);
@@ -580,6 +602,8 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.ftile.p);
     }
     arena_put(c, c->slabJ);
+    dev_free(c->mergedJ.order.p);
+    c->mergedJ = MergedPlan{};
     c->joint_ready = false;
     c->vt_valid = false;
     c->test_ready = false;
@@ -696,20 +720,20 @@ bool gram_fused(const dsmgp_ctx* c) { return c->fuse_gram && c->D <= GRAM_FUSE_M
 // with_test: the rows of K_tn (Vt) of every leaf are appended below its factor and advance through the same
 // update / panel-solve launches -- prediction's triangular solves (src/gaussianprocess.jl:120) cost no launches
 // of their own when the test set is resident at fit time.
-int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops,
-                       bool slab_outside_pool = false) {
+int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[3], MergedPlan& merged, double*& slab_ws, double& alg_flops,
+                       double& alg_flops_fused, bool slab_outside_pool = false) {
     const int L = c->L;
     alg_flops = 0.0;
     const bool fused = gram_fused(c);
-    UpdateSplitter split[2];
-    for (int ph = 0; ph < 2; ++ph) {
+    UpdateSplitter split[3];
+    for (int ph = 0; ph < 3; ++ph) {
         StepLists& S = phase[ph];
         UpdateSplitter& U = split[ph];
         U.ncu = c->ncu;
         U.xcd = c->xcd_order;
         U.tail_split = c->tail_split;
         U.tail_rounds = c->tail_rounds;
-        auto in_phase = [&](const LeafHost& lf) { return (lf.op == DSMGP_SHARE_PREFIX) == (ph == 1); };
+        auto in_phase = [&](const LeafHost& lf) { return c->leaf_group[&lf - c->leaves.data()] == ph; };
         int nsteps = 0;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
@@ -1009,27 +1033,78 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         if (int rc = dev_upload(c, S.ftile, ftile)) return rc;
     }
     {
-        const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
+        const size_t slabs = std::max(std::max(split[0].max_slabs, split[1].max_slabs), split[2].max_slabs);   // the phases' update launches run one after the other
         arena_put(c, slab_ws);
         if (slabs) {
             if (slab_outside_pool && c->pool_base) HIPCHK(c, hipMalloc(&slab_ws, slabs * TB * TB * sizeof(double)));
             else if (int rc = arena_get(c, slab_ws, slabs * TB * TB)) return rc;
         }
-        for (int ph = 0; ph < 2; ++ph) {
+        for (int ph = 0; ph < 3; ++ph) {
             split[ph].bind(slab_ws);
             if (int rc = dev_upload(c, phase[ph].upd, split[ph].upd)) return rc;
             if (int rc = dev_upload(c, phase[ph].red, split[ph].red)) return rc;
         }
     }
-    // algorithmic flops of the launches timed as "update" (slot 1): 2 K per element of block column k, with K = 128 k --
-    // or 128 (k - 1) where the step runs on the lookahead schedule (its bulk launch stops one block column short; the
-    // last rank-128 update belongs to the finish tasks)
+    dev_free(merged.order.p);
+    merged = MergedPlan{};
+    if (c->two_groups) {
+        StepLists &A = phase[0], &B = phase[2];
+        int ks = 0;
+        while (ks < std::min(A.nsteps, B.nsteps) && A.mode[ks] == STEP_FUSED && B.mode[ks] == STEP_FUSED) ++ks;
+        merged.ksteps = ks;
+        std::vector<int> order;
+        // Tasks are interleaved in runs of 8 (one per XCD slot), so a tile task keeps its position modulo 8: the tiles of a
+        // leaf, listed 8 apart to share their B panel and Dinv_k through one L2, still do.
+        auto emit = [&](const DiagFusedTask* dt, int nd, const FusedTask* tt, int nt) {
+            MergedPlan::Launch la{dt, tt, nd + nt, (int)order.size()};
+            const int cd = (nd + 7) / 8, ct = (nt + 7) / 8;
+            int id = 0, it = 0;
+            for (int q = 0; q < cd + ct; ++q) {
+                const bool take_d = it >= ct || (id < cd && (long)(id + 1) * (cd + ct) <= (long)(q + 1) * cd);
+                if (take_d) {
+                    for (int j = 8 * id; j < std::min(nd, 8 * id + 8); ++j) order.push_back(~j);
+                    ++id;
+                } else {
+                    for (int j = 8 * it; j < std::min(nt, 8 * it + 8); ++j) order.push_back(j);
+                    ++it;
+                }
+            }
+            if (la.n > 0) merged.launches.push_back(la);
+        };
+        for (int k = 0; k < ks; ++k) {
+            emit(A.fdiag.p + A.fdiag_off[k], A.fdiag_off[k + 1] - A.fdiag_off[k],
+                 k > 0 ? B.ftile.p + B.ftile_off[k - 1] : nullptr, k > 0 ? B.ftile_off[k] - B.ftile_off[k - 1] : 0);
+            emit(B.fdiag.p + B.fdiag_off[k], B.fdiag_off[k + 1] - B.fdiag_off[k],
+                 A.ftile.p + A.ftile_off[k], A.ftile_off[k + 1] - A.ftile_off[k]);
+        }
+        if (ks > 0) emit(nullptr, 0, B.ftile.p + B.ftile_off[ks - 1], B.ftile_off[ks] - B.ftile_off[ks - 1]);
+        if (int rc = dev_upload(c, merged.order, order)) return rc;
+    }
+    // algorithmic flops of the launches timed as "update" (slot 1: tile_gemm_kernel_v2): 2 K per element of block column k with
+    // K = 128 k -- 128 (k - 1) where the step runs on the lookahead schedule (its bulk launch stops one block column short),
+    // nothing where it runs fused.  Fused tile launches (slot 18: tile_fused_kernel) are counted apart: their update flops
+    // plus the triangular solve of the tiles below the diagonal block (c_k^2 per row, c_k = columns of block k).
+    alg_flops_fused = 0.0;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
-        const std::vector<char>& md = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
-        auto depth = [&](int k) { return (k < (int)md.size() && md[k] == STEP_LOOKAHEAD) ? std::max(0, k - 1) : k; };
-        if (lf.owner == l) alg_flops += update_flops(lf.n, lf.kb, depth);
-        if (with_test && lf.nt > 0) alg_flops += predict_update_flops(lf.n, lf.nt, depth);
+        const std::vector<char>& md = c->fused_step[(int)c->leaf_group[l]];
+        auto mode = [&](int k) { return k < (int)md.size() ? (int)md[k] : (int)STEP_CLASSIC; };
+        auto depth = [&](int k) { return mode(k) == STEP_FUSED ? 0 : (mode(k) == STEP_LOOKAHEAD ? std::max(0, k - 1) : k); };
+        auto depth_fused = [&](int k) { return mode(k) == STEP_FUSED ? k : 0; };
+        if (lf.owner == l) {
+            alg_flops += update_flops(lf.n, lf.kb, depth);
+            alg_flops_fused += update_flops(lf.n, lf.kb, depth_fused);
+        }
+        if (with_test && lf.nt > 0) {
+            alg_flops += predict_update_flops(lf.n, lf.nt, depth);
+            alg_flops_fused += predict_update_flops(lf.n, lf.nt, depth_fused);
+        }
+        for (int k = 0; k * TB < lf.n; ++k) {
+            if (mode(k) != STEP_FUSED) continue;
+            const double ck = (double)std::min(TB, lf.n - k * TB);
+            if (lf.owner == l) alg_flops_fused += (double)std::max(0, lf.n - std::max(k + 1, lf.kb) * TB) * ck * ck;
+            if (with_test && lf.nt > 0) alg_flops_fused += (double)lf.nt * ck * ck;
+        }
     }
     return 0;
 }
@@ -1124,19 +1199,36 @@ int build_plan(dsmgp_ctx* c) {
         HIPCHK(c, hipGetLastError());
     }
 
+    // Phases: PREFIX leaves run after their sources (phase 1).  With very many leaves factorised in full (two groups of
+    // >= 4 x CUs each), those are split into two groups A (phase 0) and B (phase 2), every other one in table order; COPY
+    // leaves ride with their source.  The fused steps of A and B then run merged (MergedPlan).
+    {
+        int nfull = 0;
+        for (const LeafHost& lf : c->leaves) nfull += (lf.op == DSMGP_SHARE_FULL) ? 1 : 0;
+        c->two_groups = c->fuse_steps && gram_fused(c) && nfull >= 8 * c->ncu;
+        c->leaf_group.assign(L, 0);
+        int q = 0;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.op == DSMGP_SHARE_PREFIX) c->leaf_group[l] = 1;
+            else if (lf.op == DSMGP_SHARE_FULL) c->leaf_group[l] = (c->two_groups && (q++ & 1)) ? 2 : 0;
+        }
+        for (int l = 0; l < L; ++l)
+            if (c->leaves[l].op == DSMGP_SHARE_COPY) c->leaf_group[l] = c->leaf_group[c->leaves[l].src];
+    }
     // How every block step runs (STEP_*).  Fused: the steps whose diagonal blocks alone fill the chip -- the same rule as the
-    // choice of the packed diagonal-block kernel.  Lookahead: the others, when the Gram values are evaluated in the tasks.
-    for (int ph = 0; ph < 2; ++ph) {
+    // choice of the packed diagonal-block kernel.  Lookahead: the others, when asked for (DSMGP_OPT_LOOKAHEAD).
+    for (int ph = 0; ph < 3; ++ph) {
         int ns = 0;
-        for (const LeafHost& lf : c->leaves)
-            if ((lf.op == DSMGP_SHARE_PREFIX) == (ph == 1)) ns = std::max(ns, lf.nb);
+        for (int l = 0; l < L; ++l)
+            if (c->leaf_group[l] == ph) ns = std::max(ns, c->leaves[l].nb);
         c->fused_step[ph].assign(ns, STEP_CLASSIC);
         if (!gram_fused(c)) continue;
         for (int k = 0; k < ns; ++k) {
             int nd = 0;
             for (int l = 0; l < L; ++l) {
                 const LeafHost& lf = c->leaves[l];
-                if ((lf.op == DSMGP_SHARE_PREFIX) == (ph == 1) && lf.owner == l && lf.nb > k && k >= lf.kb) ++nd;
+                if (c->leaf_group[l] == ph && lf.owner == l && lf.nb > k && k >= lf.kb) ++nd;
             }
             // fused: the diagonal blocks alone fill the chip -- or the step is shallow (K <= 512: the one workgroup that
             // updates a diagonal tile before factorising it is done in a few microseconds; deeper, that update belongs in
@@ -1154,7 +1246,7 @@ int build_plan(dsmgp_ctx* c) {
         const LeafHost& lf = c->leaves[l];
         if (lf.owner != l) continue;
         {
-            const std::vector<char>& fs = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
+            const std::vector<char>& fs = c->fused_step[(int)c->leaf_group[l]];
             if (fused && !fs.empty() && fs[0] != STEP_CLASSIC) continue;
         }
         const LeafDev& d = c->h_leaves[l];
@@ -1263,7 +1355,7 @@ int build_plan(dsmgp_ctx* c) {
 int ensure_phase(dsmgp_ctx* c) {
     if (c->phase_ready) return 0;
     HostLog hl("ensure_phase: factor steps");
-    if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update, true)) return rc;
+    if (int rc = build_factor_steps(c, false, c->phase, c->mergedF, c->slabF, c->alg_flops_update, c->alg_flops_fused, true)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase_ready = true;
     return 0;
@@ -1314,7 +1406,7 @@ struct PhaseTimer {
         return (int)used++;
     }
     void begin(int slot, hipStream_t st = nullptr) {
-        on = c->profile >= 2 || (c->profile == 1 && slot == 1);
+        on = c->profile >= 2 || (c->profile == 1 && (slot == 1 || slot == 18));
         if (!on) return;
         const int a = take(), b = take();
         if (a < 0 || b < 0) {
@@ -1353,7 +1445,7 @@ struct PhaseTimer {
 // stream.  Fused step (many leaves): diag_fused_kernel -> tile_fused_kernel, same stream.  Lookahead step k: the bulk update
 // (-> reduce) on the context's stream once step k - 2 is final; the finish -- diag_fused_kernel, tile_fused_kernel -- on the
 // side stream once the bulk and step k - 1 are done.  ev_fin[k] marks step k final on whichever stream finished it.
-int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
+int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches, int k_begin = 0) {
     auto grow = [&](std::vector<hipEvent_t>& v, int n) -> bool {
         while ((int)v.size() < n) {
             hipEvent_t e = nullptr;
@@ -1377,7 +1469,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         if (k >= 0 && fin_on_side[k]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fin[k], 0));
         return 0;
     };
-    for (int k = 0; k < S.nsteps; ++k) {
+    for (int k = k_begin; k < S.nsteps; ++k) {
         const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
         if (S.mode[k] == STEP_LOOKAHEAD) {
@@ -1426,11 +1518,11 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
                 pt.end();
             }
             if (nft > 0) {
-                pt.begin(1);
+                pt.begin(18);
                 tile_fused_kernel<<<nft, 256, 0, c->stream>>>(S.ftile.p + S.ftile_off[k], c->d_kp, c->D);
                 pt.note(k, nft, nft);
                 pt.end();
-                if (count_launches) c->n_update_launches++;
+                if (count_launches) c->n_fused_launches++;
             }
             continue;
         }
@@ -1469,6 +1561,20 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         if (int rc = main_waits_step(k)) return rc;
     HIPCHK(c, hipGetLastError());
     return 0;
+}
+
+// The merged launches of two leaf groups' common fused steps (MergedPlan), then what is left of each group.
+int run_two_groups(dsmgp_ctx* c, StepLists& A, StepLists& B, const MergedPlan& mp, PhaseTimer& pt) {
+    for (const MergedPlan::Launch& la : mp.launches) {
+        pt.begin(18);
+        step_fused_kernel<<<la.n, 256, DIAGP_LDS_BYTES, c->stream>>>(mp.order.p + la.off, la.dt, la.tt, c->d_kp, c->D);
+        pt.note((int)(&la - mp.launches.data()), la.n, la.n);
+        pt.end();
+        c->n_fused_launches++;
+    }
+    HIPCHK(c, hipGetLastError());
+    if (int rc = run_phase(c, A, pt, true, mp.ksteps)) return rc;
+    return run_phase(c, B, pt, true, mp.ksteps);
 }
 
 // alpha = L^-T z by the backward block sweep on w = copy of z (z stays: the predictive mean is m + V^T z).
@@ -1525,6 +1631,8 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(diag_fused_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(step_fused_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     {
         hipDeviceProp_t prop;
@@ -1763,7 +1871,9 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     c->timings[11] = 0.0;
     c->timings[13] = 0.0;
     c->timings[14] = 0.0;
+    c->timings[18] = 0.0;
     c->n_update_launches = 0;
+    c->n_fused_launches = 0;
     PhaseTimer pt(c);
     EventPair ev;
     HIPCHK(c, ev.init());
@@ -1789,7 +1899,11 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
         copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
     }
-    if (int rc = run_phase(c, phases[0], pt, true)) return rc;
+    if (c->two_groups) {
+        if (int rc = run_two_groups(c, phases[0], phases[2], joint ? c->mergedJ : c->mergedF, pt)) return rc;
+    } else if (int rc = run_phase(c, phases[0], pt, true)) {
+        return rc;
+    }
     // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
     bool any_prefix = false;
     for (int l = 0; l < L; ++l) {
@@ -2047,7 +2161,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
             if (lf.nt == 0) continue;
             // where step 0 runs fused, the tasks of block column 0 evaluate their K_tn tile themselves.  A COPY leaf rides
             // with its source's phase (phase 0: a source is factorised in full)
-            const std::vector<char>& fs = c->fused_step[lf.op == DSMGP_SHARE_PREFIX ? 1 : 0];
+            const std::vector<char>& fs = c->fused_step[(int)c->leaf_group[l]];
             const bool step0_fused = gram_fused(c) && !fs.empty() && fs[0] != STEP_CLASSIC;
             for (int ti = 0; ti < lf.ntpad / TB; ++ti)
                 for (int j = 0; j < lf.nb; ++j, ++q)
@@ -2060,7 +2174,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     // the same test rows as riders of the factorisation launches (used by fit while this test set is resident)
     {
         HostLog hl("set_test: joint factor steps");
-        if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint)) return rc;
+        if (int rc = build_factor_steps(c, true, c->phaseJ, c->mergedJ, c->slabJ, c->alg_flops_joint, c->alg_flops_fused_joint)) return rc;
     }
     c->joint_ready = true;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2664,6 +2778,13 @@ int dsmgp_work(dsmgp_ctx* c, double* alg_flops_update, int32_t* n_update_launche
     if (!c) return DSMGP_E_ARG;
     if (alg_flops_update) *alg_flops_update = c->last_fit_joint ? c->alg_flops_joint : c->alg_flops_update;
     if (n_update_launches) *n_update_launches = c->n_update_launches;
+    return 0;
+}
+
+int dsmgp_work_fused(dsmgp_ctx* c, double* alg_flops_fused, int32_t* n_fused_launches) {
+    if (!c) return DSMGP_E_ARG;
+    if (alg_flops_fused) *alg_flops_fused = c->last_fit_joint ? c->alg_flops_fused_joint : c->alg_flops_fused;
+    if (n_fused_launches) *n_fused_launches = c->n_fused_launches;
     return 0;
 }
 

@@ -1811,12 +1811,11 @@ __constant__ const PackedMap PACKED{};
 
 // have_image: the caller has already put the lower blocks of the tile into the image (diag_fused_kernel: straight from
 // the accumulators of the tile's update); the barrier below makes them visible
-// Roles rotate with the workgroup index: the wave that runs the pivot chain (role 0: potrf_inv16, a long dependent VALU
-// sequence) is hardware wave (blockIdx & 3)'s neighbour rather than always wave 0, so the two workgroups sharing a CU usually
-// run their chains on different SIMDs instead of interleaving them on SIMD 0.
+// (Rotating the wave roles with the workgroup index, so that the pivot chains of the two workgroups of a CU run on different
+// SIMDs, measured no difference: depth 4 0.0604 / 0.0593 / 0.0594 s without, 0.0596 / 0.0597 / 0.0586 s with, same box.)
 __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double* S, bool have_image) {
     const int t = threadIdx.x, lane = t & 63;
-    const int w = (__builtin_amdgcn_readfirstlane(t >> 6) + (int)(blockIdx.x & 3)) & 3;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     double* wl = S + PIMG;                 // right-hand side block w_k, updated in place by the fused forward substitution
     double* zl = S + PIMG + TB;            // z_k = L_kk^-1 w_k
@@ -1848,8 +1847,16 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
             *reinterpret_cast<d2*>(dst + 2) = v[q][1];
         }
     }
-    if (tk.wk != nullptr && t < TB) wl[t] = tk.wk[t];
+    if (tk.wk != nullptr && t < TB) {
+        wl[t] = tk.wk[t];
+        zl[t] = 0.0;                       // (block steps of pure padding are skipped: their z is the zero right-hand side)
+    }
     __syncthreads();
+    // Block steps that hold data.  The last block of a leaf is padded with the identity (n mod 128 rows of data): the 16x16
+    // blocks from JN on are the identity -- their own factor and inverse -- and everything below and beside them is zero,
+    // so the factorisation stops after step JN - 1 (whose lookahead still passes block JN through diag_block: it writes that
+    // block's L and L^-1) and the diagonal blocks beyond are written as they are.
+    const int JN = (tk.nvalid + 15) >> 4;
 
     int bad = 0;
     // diagonal block J on wave 0: L_JJ -> global tile (from registers), L_JJ^-1 -> its slot in the image and -> Dinv
@@ -1927,6 +1934,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
     if (w == 0) diag_block(0);
     __syncthreads();
     for (int J = 0; J < 8; ++J) {
+        if (J >= JN) break;
         const int mytask = DIAG_TASKS.e[J][lane < 36 ? lane : 0];
         {   // P1: S(I,J) <- S(I,J) L_JJ^-T, I > J; wave w takes I = J+1+w and J+1+w+4
             const int m = 7 - J;
@@ -1979,6 +1987,21 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
     }
     bad = __shfl(bad, 0);
     if (fuse && t < TB) tk.zk[t] = zl[t];
+    if (w == 0 && lane < 32) {             // identity diagonal blocks of the skipped steps (block JN went through diag_block)
+        const int c = l15;
+        const bool isb = (lane & 16) != 0;
+        for (int J = JN + 1; J < 8; ++J) {
+            double* gdst = isb ? tk.Dinv + (size_t)(16 * J) + (size_t)(16 * J + c) * TB
+                               : tk.T + (size_t)(16 * J) + (size_t)(16 * J + c) * tk.ld;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                d2 v;
+                v[0] = (r == c) ? 1.0 : 0.0;
+                v[1] = (r + 1 == c) ? 1.0 : 0.0;
+                *reinterpret_cast<d2*>(gdst + r) = v;
+            }
+        }
+    }
     // ---- off-diagonal blocks of L -> tile, zeros above the diagonal (diagonal blocks were written by diag_block);
     //      the same sweep zeroes the upper blocks of Dinv.  16 of the 64 blocks per wave.
     {

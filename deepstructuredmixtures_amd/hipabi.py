@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 
-N_TIMINGS = 18
+N_TIMINGS = 19
 AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
 OPT_ARD_LENGTHSCALE_GRADIENT = 1
 OPT_FUSED_GRAM = 2
@@ -24,7 +24,7 @@ def agg_width(family, n_groups=0):
     return 3 if family == AGG_MIXTURE else (2 * int(n_groups) if family == AGG_RBCM else 2)
 TIMING_NAMES = ("gram", "chol_update", "chol_diag", "chol_trsm", "solve", "mll", "predict_gram",
                 "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce", "alpha",
-                "grad_inverse", "grad_contraction", "grad_traces")
+                "grad_inverse", "grad_contraction", "grad_traces", "chol_fused")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -58,6 +58,7 @@ SIGNATURES = {
     "dsmgp_set_joint": (C.c_int, [_ctx, C.c_int32]),
     "dsmgp_timings": (C.c_int, [_ctx, _dp]),
     "dsmgp_work": (C.c_int, [_ctx, _dp, _ip]),
+    "dsmgp_work_fused": (C.c_int, [_ctx, _dp, _ip]),
     "dsmgp_work_gradients": (C.c_int, [_ctx, _dp, _dp, _ip]),
     "dsmgp_release": (C.c_int, [_ctx]),
     "dsmgp_reserve": (C.c_int, [_ctx, C.c_int64]),
@@ -391,6 +392,13 @@ class Context:
         self._chk(self.lib.dsmgp_work(self.h, C.byref(f), C.byref(n)))
         return f.value, n.value
 
+    def work_fused(self):
+        """(algorithmic flops, launches) of the fused tile launches of the last fit (update + solve of fused block steps)."""
+        f = C.c_double(0.0)
+        n = C.c_int32(0)
+        self._chk(self.lib.dsmgp_work_fused(self.h, C.byref(f), C.byref(n)))
+        return f.value, n.value
+
     def work_gradients(self):
         """(algorithmic flops of L^-T, of the contraction, number of contraction tiles) of dsmgp_gradients."""
         a, b, n = C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
@@ -621,6 +629,10 @@ class MultiContext:
         ws = [s.work() for s in self.act]
         return sum(w[0] for w in ws), max(w[1] for w in ws)
 
+    def work_fused(self):
+        ws = [s.work_fused() for s in self.act]
+        return sum(w[0] for w in ws), max(w[1] for w in ws)
+
     def work_gradients(self):
         ws = [s.work_gradients() for s in self.act]
         return sum(w[0] for w in ws), sum(w[1] for w in ws), sum(w[2] for w in ws)
@@ -832,6 +844,7 @@ class StreamingContext:
         seconds, tpred = 0.0, 0.0
         tsum = {}
         flops, launches = 0.0, 0
+        fflops, flaunches = 0.0, 0
         import time as _time
         host = {"set_leaves": 0.0, "set_sharing": 0.0, "set_test": 0.0, "fit": 0.0, "release": 0.0}   # wall seconds
 
@@ -882,11 +895,14 @@ class StreamingContext:
             f_, n_ = c.work()
             flops += f_
             launches += n_
+            ff_, fn_ = c.work_fused()
+            fflops += ff_
+            flaunches += fn_
             timed("release", c.release)
         self.passes += 1
         self.host_seconds = host
         self._res = dict(mll=mll, info=info, mu=mu, var=var, grads=grads, seconds=seconds, tpred=tpred, timings=tsum,
-                         work=(flops, launches), has_test=self._test is not None, alpha=alphas)
+                         work=(flops, launches), work_fused=(fflops, flaunches), has_test=self._test is not None, alpha=alphas)
 
     def fit(self):
         self._pass()
@@ -918,6 +934,9 @@ class StreamingContext:
 
     def work(self):
         return self._res["work"] if self._res else (0.0, 0)
+
+    def work_fused(self):
+        return self._res["work_fused"] if self._res else (0.0, 0)
 
     def alpha(self, leaf):
         """alpha of a leaf listed in `keep_alpha` before the last pass (factors themselves are discarded)."""

@@ -1276,7 +1276,9 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
     block / panel solve launches.  Same arithmetic up to the order of one addition per entry: log-marginals 1e-12, the
     factor of sampled leaves 1e-11, moments 1e-9 (conditioning-limited); three leaves against the oracle at the
     north-star tolerance.  All three kernel kinds (the Gram values are evaluated inside the tasks)."""
-    N, D, L = 60_000, 3, 700
+    # kind 0: 2200 leaves -- enough (>= 8 x CUs) for the two-group merged schedule, where one launch carries the diagonal
+    # blocks of one half of the leaves next to the tiles of the other half (step_fused_kernel)
+    N, D, L = 60_000, 3, (2200 if kind == 0 else 700)
     X, y, Xt = regression_data(N, D, n_test=160, seed=5150 + kind)
     rng = np.random.default_rng(11 + kind)
     sizes = rng.integers(130, 701, size=L)
@@ -1313,7 +1315,7 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
         assert np.all(info == 0)
         ctx.predict_run()
         mu, var = ctx.predict_fetch()
-        fa = [ctx.download_factor(j, obs[j].size) for j in (0, 5, 11, 300, 699)]
+        fa = [ctx.download_factor(j, obs[j].size) for j in (0, 5, 11, 300, 699, L - 1)]
         return mll, mu, var, fa, t
 
     try:
