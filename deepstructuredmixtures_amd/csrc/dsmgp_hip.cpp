@@ -84,21 +84,6 @@ struct StepLists {
     int nsteps = 0;
 };
 
-// Merged schedule of two leaf groups A and B over their common prefix of fused steps (step_fused_kernel): launch 2k carries
-// the diagonal blocks of A's step k next to the tiles of B's step k - 1, launch 2k + 1 the tiles of A's step k next to the
-// diagonal blocks of B's step k, and a last one B's remaining tiles.  A diagonal block is a long dependent chain that
-// leaves the matrix pipe idle, a tile task is pipe-bound: mixed, a CU mostly holds one of each.
-struct MergedPlan {
-    struct Launch {
-        const DiagFusedTask* dt;
-        const FusedTask* tt;
-        int n, off;
-    };
-    int ksteps = 0;                 // block steps covered (both groups fused in all of them)
-    std::vector<Launch> launches;
-    DevBuf<int> order;
-};
-
 // Collects the update tiles of one block step and splits their K range over several workgroups when
 // the step has too few tiles to fill the chip (tail of the factorisation, prediction sweeps).
 // Cost model in units of one K column on one CU: a workgroup costs (K/S + C0), rounds = ceil(T*S / CUs).
@@ -359,20 +344,18 @@ struct dsmgp_ctx {
     //                   tile_fused_kernel starting from the bulk's tile: rank-128 update + factorisation / solve) on a side
     //                   stream after the bulk, beside the bulk of step k + 1: the chain diagonal block -> panel solve no
     //                   longer sits between two update launches (src/AdvancedCholeskey.jl:161-171 per step, pipelined)
-    std::vector<char> fused_step[3];
+    std::vector<char> fused_step[2];
     hipStream_t side = nullptr;     // the finish launches of lookahead steps
     std::vector<hipEvent_t> ev_bulk, ev_fin;   // per block step (grown on demand, no timing)
-    StepLists phase[3];             // 0: FULL leaves (group A), 1: PREFIX leaves (need their source first), 2: FULL leaves, group B
+    StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
     std::vector<char> leaf_group;   // per leaf: the phase it belongs to (COPY leaves ride with their source)
-    bool two_groups = false;        // many leaves: the FULL leaves are two groups whose fused steps run merged (MergedPlan)
-    MergedPlan mergedF, mergedJ;
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
     // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
     // allocation (5 s per 230 GB group measured), which dominated the streaming mode's wall time.
     char* pool_base = nullptr;
     size_t pool_cap = 0, pool_top = 0, pool_mark_plan = 0;
     double* slabF = nullptr;        // split-K workspace of the factorisation
-    StepLists phaseJ[3];            // the same with the resident test rows riding along (built by set_test)
+    StepLists phaseJ[2];            // the same with the resident test rows riding along (built by set_test)
     double* slabJ = nullptr;
     double alg_flops_joint = 0.0;
     bool joint = true;              // fit advances the resident test rows too
@@ -554,8 +537,6 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.ftile.p);
     }
     arena_put(c, c->slabF);
-    dev_free(c->mergedF.order.p);
-    c->mergedF = MergedPlan{};
     dev_free(c->fwd.p);
     dev_free(c->bwd.p);
     free_grad(c);
@@ -602,8 +583,6 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.ftile.p);
     }
     arena_put(c, c->slabJ);
-    dev_free(c->mergedJ.order.p);
-    c->mergedJ = MergedPlan{};
     c->joint_ready = false;
     c->vt_valid = false;
     c->test_ready = false;
@@ -720,13 +699,13 @@ bool gram_fused(const dsmgp_ctx* c) { return c->fuse_gram && c->D <= GRAM_FUSE_M
 // with_test: the rows of K_tn (Vt) of every leaf are appended below its factor and advance through the same
 // update / panel-solve launches -- prediction's triangular solves (src/gaussianprocess.jl:120) cost no launches
 // of their own when the test set is resident at fit time.
-int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[3], MergedPlan& merged, double*& slab_ws, double& alg_flops,
+int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops,
                        double& alg_flops_fused, bool slab_outside_pool = false) {
     const int L = c->L;
     alg_flops = 0.0;
     const bool fused = gram_fused(c);
-    UpdateSplitter split[3];
-    for (int ph = 0; ph < 3; ++ph) {
+    UpdateSplitter split[2];
+    for (int ph = 0; ph < 2; ++ph) {
         StepLists& S = phase[ph];
         UpdateSplitter& U = split[ph];
         U.ncu = c->ncu;
@@ -820,7 +799,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[3], Merg
                             f.kid = lf.kid;
                             f.mrows = tile_mrows(lf.n - i * TB);
                             f.zpad = 1;
-                            if (ph == 0) {
+                            if (ph != 1) {
                                 f.zk = d.z + (size_t)k * TB;
                                 f.wi = d.w + (size_t)i * TB;
                             }
@@ -862,7 +841,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[3], Merg
                             s.k1 = TB;
                             s.update = 0;
                             s.mrows = tile_mrows(lf.n - i * TB);
-                            if (ph == 0) {   // fused forward substitution for leaves factorised in full
+                            if (ph != 1) {   // fused forward substitution for leaves factorised in full
                                 s.zk = d.z + (size_t)k * TB;
                                 s.wi = d.w + (size_t)i * TB;
                             }
@@ -873,7 +852,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[3], Merg
                         DiagTask g{};
                         g.T = d.F + (size_t)k * TB + (size_t)k * TB * ld;
                         g.Dinv = d.Dinv + (size_t)k * TB * TB;
-                        if (ph == 0) {
+                        if (ph != 1) {
                             g.wk = d.w + (size_t)k * TB;
                             g.zk = d.z + (size_t)k * TB;
                         }
@@ -1033,52 +1012,17 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[3], Merg
         if (int rc = dev_upload(c, S.ftile, ftile)) return rc;
     }
     {
-        const size_t slabs = std::max(std::max(split[0].max_slabs, split[1].max_slabs), split[2].max_slabs);   // the phases' update launches run one after the other
+        const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
         arena_put(c, slab_ws);
         if (slabs) {
             if (slab_outside_pool && c->pool_base) HIPCHK(c, hipMalloc(&slab_ws, slabs * TB * TB * sizeof(double)));
             else if (int rc = arena_get(c, slab_ws, slabs * TB * TB)) return rc;
         }
-        for (int ph = 0; ph < 3; ++ph) {
+        for (int ph = 0; ph < 2; ++ph) {
             split[ph].bind(slab_ws);
             if (int rc = dev_upload(c, phase[ph].upd, split[ph].upd)) return rc;
             if (int rc = dev_upload(c, phase[ph].red, split[ph].red)) return rc;
         }
-    }
-    dev_free(merged.order.p);
-    merged = MergedPlan{};
-    if (c->two_groups) {
-        StepLists &A = phase[0], &B = phase[2];
-        int ks = 0;
-        while (ks < std::min(A.nsteps, B.nsteps) && A.mode[ks] == STEP_FUSED && B.mode[ks] == STEP_FUSED) ++ks;
-        merged.ksteps = ks;
-        std::vector<int> order;
-        // Tasks are interleaved in runs of 8 (one per XCD slot), so a tile task keeps its position modulo 8: the tiles of a
-        // leaf, listed 8 apart to share their B panel and Dinv_k through one L2, still do.
-        auto emit = [&](const DiagFusedTask* dt, int nd, const FusedTask* tt, int nt) {
-            MergedPlan::Launch la{dt, tt, nd + nt, (int)order.size()};
-            const int cd = (nd + 7) / 8, ct = (nt + 7) / 8;
-            int id = 0, it = 0;
-            for (int q = 0; q < cd + ct; ++q) {
-                const bool take_d = it >= ct || (id < cd && (long)(id + 1) * (cd + ct) <= (long)(q + 1) * cd);
-                if (take_d) {
-                    for (int j = 8 * id; j < std::min(nd, 8 * id + 8); ++j) order.push_back(~j);
-                    ++id;
-                } else {
-                    for (int j = 8 * it; j < std::min(nt, 8 * it + 8); ++j) order.push_back(j);
-                    ++it;
-                }
-            }
-            if (la.n > 0) merged.launches.push_back(la);
-        };
-        for (int k = 0; k < ks; ++k) {
-            emit(A.fdiag.p + A.fdiag_off[k], A.fdiag_off[k + 1] - A.fdiag_off[k],
-                 k > 0 ? B.ftile.p + B.ftile_off[k - 1] : nullptr, k > 0 ? B.ftile_off[k] - B.ftile_off[k - 1] : 0);
-            emit(B.fdiag.p + B.fdiag_off[k], B.fdiag_off[k + 1] - B.fdiag_off[k],
-                 A.ftile.p + A.ftile_off[k], A.ftile_off[k + 1] - A.ftile_off[k]);
-        }
-        if (ks > 0) emit(nullptr, 0, B.ftile.p + B.ftile_off[ks - 1], B.ftile_off[ks] - B.ftile_off[ks - 1]);
-        if (int rc = dev_upload(c, merged.order, order)) return rc;
     }
     // algorithmic flops of the launches timed as "update" (slot 1: tile_gemm_kernel_v2): 2 K per element of block column k with
     // K = 128 k -- 128 (k - 1) where the step runs on the lookahead schedule (its bulk launch stops one block column short),
@@ -1199,26 +1143,16 @@ int build_plan(dsmgp_ctx* c) {
         HIPCHK(c, hipGetLastError());
     }
 
-    // Phases: PREFIX leaves run after their sources (phase 1).  With very many leaves factorised in full (two groups of
-    // >= 4 x CUs each), those are split into two groups A (phase 0) and B (phase 2), every other one in table order; COPY
-    // leaves ride with their source.  The fused steps of A and B then run merged (MergedPlan).
-    {
-        int nfull = 0;
-        for (const LeafHost& lf : c->leaves) nfull += (lf.op == DSMGP_SHARE_FULL) ? 1 : 0;
-        c->two_groups = c->fuse_steps && gram_fused(c) && nfull >= 8 * c->ncu;
-        c->leaf_group.assign(L, 0);
-        int q = 0;
-        for (int l = 0; l < L; ++l) {
-            const LeafHost& lf = c->leaves[l];
-            if (lf.op == DSMGP_SHARE_PREFIX) c->leaf_group[l] = 1;
-            else if (lf.op == DSMGP_SHARE_FULL) c->leaf_group[l] = (c->two_groups && (q++ & 1)) ? 2 : 0;
-        }
-        for (int l = 0; l < L; ++l)
-            if (c->leaves[l].op == DSMGP_SHARE_COPY) c->leaf_group[l] = c->leaf_group[c->leaves[l].src];
-    }
+    // Phases: PREFIX leaves run after their sources (phase 1), everything else in phase 0 (COPY leaves ride with their source).
+    // (Round 3 also built a split of the phase-0 leaves into two groups whose fused steps ran merged -- one launch carrying the
+    // diagonal blocks of one group next to the tiles of the other, so that a CU mostly holds one latency-bound and one
+    // pipe-bound workgroup: correct, and no faster -- depth 4 0.0601 s against 0.0586-0.0604 s -- so it is not in the tree.)
+    c->leaf_group.assign(L, 0);
+    for (int l = 0; l < L; ++l)
+        if (c->leaves[l].op == DSMGP_SHARE_PREFIX) c->leaf_group[l] = 1;
     // How every block step runs (STEP_*).  Fused: the steps whose diagonal blocks alone fill the chip -- the same rule as the
     // choice of the packed diagonal-block kernel.  Lookahead: the others, when asked for (DSMGP_OPT_LOOKAHEAD).
-    for (int ph = 0; ph < 3; ++ph) {
+    for (int ph = 0; ph < 2; ++ph) {
         int ns = 0;
         for (int l = 0; l < L; ++l)
             if (c->leaf_group[l] == ph) ns = std::max(ns, c->leaves[l].nb);
@@ -1273,7 +1207,7 @@ int build_plan(dsmgp_ctx* c) {
     c->phase_ready = false;
 
     // solve sweeps.  Forward: only leaves whose factor came from elsewhere (COPY, PREFIX) -- leaves factorised
-    // in full get z = L^-1 y from the factorisation itself (chol_diag_kernel + the panel-solve epilogue).
+    // in full get z = L^-1 y from the factorisation itself (chol_diag_packed_kernel + the panel-solve epilogue).
     // Backward: every leaf.
     {
         int nsteps = 0;
@@ -1355,7 +1289,7 @@ int build_plan(dsmgp_ctx* c) {
 int ensure_phase(dsmgp_ctx* c) {
     if (c->phase_ready) return 0;
     HostLog hl("ensure_phase: factor steps");
-    if (int rc = build_factor_steps(c, false, c->phase, c->mergedF, c->slabF, c->alg_flops_update, c->alg_flops_fused, true)) return rc;
+    if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update, c->alg_flops_fused, true)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase_ready = true;
     return 0;
@@ -1542,9 +1476,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches, i
         const int nd = S.diag_off[k + 1] - S.diag_off[k];
         if (nd > 0) {
             pt.begin(2);
-            // more blocks than CUs: the throughput form (two workgroups per CU); else the latency form
-            if (nd > c->ncu) chol_diag_packed_kernel<<<nd, 256, DIAGP_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
-            else chol_diag_kernel<<<nd, 256, DIAG_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
+            chol_diag_packed_kernel<<<nd, 256, DIAGP_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
             pt.note(k, nd, 0);
             pt.end();
         }
@@ -1561,20 +1493,6 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches, i
         if (int rc = main_waits_step(k)) return rc;
     HIPCHK(c, hipGetLastError());
     return 0;
-}
-
-// The merged launches of two leaf groups' common fused steps (MergedPlan), then what is left of each group.
-int run_two_groups(dsmgp_ctx* c, StepLists& A, StepLists& B, const MergedPlan& mp, PhaseTimer& pt) {
-    for (const MergedPlan::Launch& la : mp.launches) {
-        pt.begin(18);
-        step_fused_kernel<<<la.n, 256, DIAGP_LDS_BYTES, c->stream>>>(mp.order.p + la.off, la.dt, la.tt, c->d_kp, c->D);
-        pt.note((int)(&la - mp.launches.data()), la.n, la.n);
-        pt.end();
-        c->n_fused_launches++;
-    }
-    HIPCHK(c, hipGetLastError());
-    if (int rc = run_phase(c, A, pt, true, mp.ksteps)) return rc;
-    return run_phase(c, B, pt, true, mp.ksteps);
 }
 
 // alpha = L^-T z by the backward block sweep on w = copy of z (z stays: the predictive mean is m + V^T z).
@@ -1626,13 +1544,9 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
             c->side = nullptr;
         }
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(diag_fused_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(step_fused_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     {
         hipDeviceProp_t prop;
@@ -1899,11 +1813,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
         copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
     }
-    if (c->two_groups) {
-        if (int rc = run_two_groups(c, phases[0], phases[2], joint ? c->mergedJ : c->mergedF, pt)) return rc;
-    } else if (int rc = run_phase(c, phases[0], pt, true)) {
-        return rc;
-    }
+    if (int rc = run_phase(c, phases[0], pt, true)) return rc;
     // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
     bool any_prefix = false;
     for (int l = 0; l < L; ++l) {
@@ -2174,7 +2084,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     // the same test rows as riders of the factorisation launches (used by fit while this test set is resident)
     {
         HostLog hl("set_test: joint factor steps");
-        if (int rc = build_factor_steps(c, true, c->phaseJ, c->mergedJ, c->slabJ, c->alg_flops_joint, c->alg_flops_fused_joint)) return rc;
+        if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint, c->alg_flops_fused_joint)) return rc;
     }
     c->joint_ready = true;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2927,90 +2837,6 @@ int dsmgp_probe_coissue(dsmgp_ctx* c, double* out) {
     }
     dev_free(sink);
     dev_free(st);
-    return 0;
-}
-
-// Diagnostic: the diagonal-block kernel on its own, with in-kernel phase stamps.
-int dsmgp_probe_diag(dsmgp_ctx* c, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us) {
-    if (!c || ntiles <= 0 || ld < TB || reps <= 0 || !kernel_us || !phases_us) return DSMGP_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t tile = (size_t)ld * TB;
-    std::vector<double> h(tile, 0.0);
-    uint64_t st = 0x9E3779B97F4A7C15ull;
-    auto rnd = [&]() {
-        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
-        return (double)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5;
-    };
-    for (int cidx = 0; cidx < TB; ++cidx)
-        for (int r = cidx; r < TB; ++r) h[r + (size_t)cidx * ld] = (r == cidx) ? 64.0 + rnd() : rnd();
-    double *T0 = nullptr, *T = nullptr, *Dinv = nullptr, *wz = nullptr;
-    int* info = nullptr;
-    unsigned long long* stamps = nullptr;
-    DiagTask* dt = nullptr;
-    HIPCHK(c, hipMalloc(&T0, tile * sizeof(double)));
-    HIPCHK(c, hipMalloc(&T, ntiles * tile * sizeof(double)));
-    HIPCHK(c, hipMalloc(&Dinv, (size_t)ntiles * TB * TB * sizeof(double)));
-    HIPCHK(c, hipMalloc(&wz, (size_t)ntiles * 2 * TB * sizeof(double)));
-    HIPCHK(c, hipMalloc(&info, ntiles * sizeof(int)));
-    HIPCHK(c, hipMalloc(&stamps, (size_t)ntiles * 24 * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&dt, ntiles * sizeof(DiagTask)));
-    HIPCHK(c, hipMemcpy(T0, h.data(), tile * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemset(wz, 0, (size_t)ntiles * 2 * TB * sizeof(double)));
-    HIPCHK(c, hipMemset(info, 0, ntiles * sizeof(int)));
-    std::vector<DiagTask> tasks(ntiles);
-    for (int i = 0; i < ntiles; ++i) {
-        DiagTask g{};
-        g.T = T + i * tile;
-        g.Dinv = Dinv + (size_t)i * TB * TB;
-        g.wk = wz + (size_t)i * 2 * TB;
-        g.zk = wz + (size_t)i * 2 * TB + TB;
-        g.info = info + i;
-        g.ld = ld;
-        g.nvalid = TB;
-        g.row0 = 0;
-        tasks[i] = g;
-    }
-    HIPCHK(c, hipMemcpy(dt, tasks.data(), ntiles * sizeof(DiagTask), hipMemcpyHostToDevice));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_stamp_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
-    const size_t lds = DIAG_LDS_BYTES;
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
-    auto refill = [&]() {
-        for (int i = 0; i < ntiles; ++i)
-            (void)hipMemcpyAsync(T + i * tile, T0, tile * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
-    };
-    double total = 0.0;
-    for (int r = 0; r < reps + 1; ++r) {
-        refill();
-        HIPCHK(c, hipEventRecord(e0, c->stream));
-        chol_diag_kernel<<<ntiles, 256, lds, c->stream>>>(dt);
-        HIPCHK(c, hipEventRecord(e1, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-        if (r > 0) total += ms;
-    }
-    *kernel_us = total / reps * 1e3;
-    refill();
-    chol_diag_stamp_kernel<<<ntiles, 256, lds, c->stream>>>(dt, stamps);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    unsigned long long hs[24];
-    HIPCHK(c, hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 19; ++i) phases_us[i] = (double)(hs[i + 1] - hs[i]) * 0.01;   // 100 MHz
-    // inside wave 0's share of J3.P2: block product, LDS reads, potrf_inv16, LDS writes
-    phases_us[19] = (double)(hs[20] - hs[8]) * 0.01;
-    phases_us[20] = (double)(hs[21] - hs[20]) * 0.01;
-    phases_us[21] = (double)(hs[22] - hs[21]) * 0.01;
-    phases_us[22] = (double)(hs[23] - hs[22]) * 0.01;
-    int bad = 0;
-    HIPCHK(c, hipMemcpy(&bad, info, sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(T0); (void)hipFree(T); (void)hipFree(Dinv); (void)hipFree(wz);
-    (void)hipFree(info); (void)hipFree(stamps); (void)hipFree(dt);
-    if (bad != 0) return fail(c, DSMGP_E_STATE, "probe block was not positive definite");
     return 0;
 }
 

@@ -5,8 +5,7 @@
 // factor F (npad x npad) is produced by a LEFT-LOOKING blocked Cholesky, batched over all leaves:
 //   step k:  F[i,k] -= F[i,0:k] F[k,0:k]^T   (tile_gemm_kernel_v2, v_mfma_f64_16x16x4_f64; diagonal tiles optionally by
 //                                              tile_syrk_body; K-split pieces summed by tile_reduce_kernel)
-//            F[k,k]  = chol(F[k,k]), Dinv_k = F[k,k]^-1   (chol_diag_kernel: one block per CU, latency form;
-//                                              chol_diag_packed_kernel: two per CU, throughput form)
+//            F[k,k]  = chol(F[k,k]), Dinv_k = F[k,k]^-1   (chol_diag_packed_kernel: 75 KB LDS image, two per CU)
 //            F[i,k]  = F[i,k] Dinv_k^T       (tile_trsm_kernel: triangular product; fused forward solve and, for test
 //                                              rows, the predictive moments)
 // which is update_cholesky!/potrf! of the reference (src/gaussianprocess.jl:82-108) and, started at
@@ -1451,22 +1450,6 @@ struct DiagTask {
     int pad;
 };
 
-// LDS image: column-major, leading dimension DLD = 144 rows (128 + one spare block row), 128 columns.
-//   factor blocks  S(I,K), I >= K : rows 16I.., cols 16K..
-//   inverse blocks B(I,K), K <  I : stored in the unused upper triangle at rows 16K.., cols 16I..
-//                  B(I,I)         : spare block row 128..143, cols 16I..
-// Blocked right-looking Cholesky on 16x16 sub-blocks.  Per block step J:
-//   P0  wave 0: potrf + inverse of the 16x16 diagonal block in registers (potrf_inv16: lanes 0..15 a column of
-//       the block, lanes 16..31 a column of the identity), cross-lane traffic by v_readlane broadcasts (no LDS, no
-//       barrier inside); for J > 0 it runs inside P2 of step J-1, right after wave 0 has updated that block
-//   P1  all waves: panel S(I,J) = S(I,J) Linv^T (I > J) and B(J,K) = Linv B(J,K) (K < J)        [MFMA]
-//   P2  waves 1..3: trailing S(I,K) -= S(I,J) S(K,J)^T (I >= K > J), B(I,K) -= S(I,J) B(J,K)    [MFMA, two
-//       independent 16x16 products in flight per wave]
-// B accumulates L^-1 by forward substitution on the identity, interleaved with the factorisation.
-// tools/probe_diag.py prints the time of every phase (in-kernel stamps of chol_diag_stamp_kernel).
-constexpr int DLD = 144;
-constexpr int DIAG_LDS_BYTES = (TB * DLD + 256 + TB) * (int)sizeof(double);   // image + Winv + rhs block
-
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -1554,217 +1537,20 @@ struct DiagTaskTable {
 };
 __constant__ const DiagTaskTable DIAG_TASKS{};
 
-// STAMP: thread 0 records wall_clock64() (100 MHz) after every phase (tools/probe_diag.py)
-template <bool STAMP>
-__device__ __forceinline__ void chol_diag_body(const DiagTask& tk, double* S, unsigned long long* stamps) {
-    double* Winv = S + TB * DLD;                                  // 256 spare doubles (the panel steps read L_JJ^-1 from B(J,J))
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: task indices and block offsets stay scalar
-    auto stamp = [&](int i) {
-        if (STAMP && t == 0) stamps[i] = wall_clock64();
-    };
-    stamp(0);
-    const int l15 = lane & 15, l4 = lane >> 4;
-    auto offS = [](int I, int K) { return (K * 16) * DLD + I * 16; };
-    auto offB = [](int I, int K) { return (I == K) ? (I * 16) * DLD + TB : (I * 16) * DLD + K * 16; };
-
-    {
-        // lower block triangle of the tile -> LDS, upper blocks zero; wave w takes columns 32w..32w+31, lanes
-        // two rows each, eight columns' loads in flight (the tile comes from HBM / a remote L2: latency-bound)
-        const gd2_cptr Tg = AS_GLOBAL_D2(tk.T + 2 * lane);
-#pragma unroll 1
-        for (int c0 = w * 32; c0 < w * 32 + 32; c0 += 8) {
-            d2 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = Tg[((size_t)(c0 + j) * tk.ld) >> 1];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const d2 zero = {0.0, 0.0};
-                *reinterpret_cast<d2*>(S + (c0 + j) * DLD + 2 * lane) = ((lane >> 3) >= ((c0 + j) >> 4)) ? v[j] : zero;
-            }
-        }
-    }
-    for (int e = t; e < TB * 16; e += 256) S[(e >> 4) * DLD + TB + (e & 15)] = 0.0;
-    double* wl = Winv + 256;                                      // right-hand side block of the fused forward solve
-    if (tk.wk != nullptr && t < TB) wl[t] = tk.wk[t];
-    __syncthreads();
-    stamp(1);
-
-    int bad = 0;
-    // diagonal block J on wave 0: S(J,J) <- L_JJ (upper part zeroed), B(J,J) <- L_JJ^-1
-    auto diag_block = [&](int J) {
-        const int c = l15;
-        const bool isb = (lane & 16) != 0;
-        double x[16], xs, xd;
-        const d2* src = reinterpret_cast<const d2*>(S + offS(J, J) + c * DLD);
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const d2 v = src[r >> 1];
-            x[r] = isb ? ((r == c) ? 1.0 : 0.0) : v[0];
-            x[r + 1] = isb ? ((r + 1 == c) ? 1.0 : 0.0) : v[1];
-        }
-        if (J == 4) stamp(21);
-        const int bj = potrf_inv16(x, xs, xd, lane);
-        if (J == 4) stamp(22);
-        if (bj != 0 && bad == 0) bad = J * 16 + bj;
-        // lanes 0..15 write column c of L (strict lower part scaled by 1/sqrt(d_c), diagonal from xd, zeros
-        // above), lanes 16..31 column c of L^-1 (to B(J,J)): one instruction stream for both groups
-        if (lane < 32) {
-            const int thr = isb ? c : c + 1;
-            const double mul = isb ? 1.0 : xs;
-            d2* dst = reinterpret_cast<d2*>((isb ? S + offB(J, J) : S + offS(J, J)) + c * DLD);
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                d2 v;
-                v[0] = (r >= thr) ? x[r] * mul : ((r == c) ? xd : 0.0);
-                v[1] = (r + 1 >= thr) ? x[r + 1] * mul : ((r + 1 == c) ? xd : 0.0);
-                dst[r >> 1] = v;
-            }
-        }
-    };
-    // One 16x16 block product on this wave: dst (-)= Aop Bop (operand addressing as in blk_mma)
-    struct BlkOp {
-        const double* pa; int saa, sak;
-        const double* pb; int sbk;
-        double* dst;
-    };
-    auto op_trailing = [&](int J, int I, int K) {   // S(I,K) -= S(I,J) S(K,J)^T
-        return BlkOp{S + offS(K, J), 1, DLD, S + offS(I, J), DLD, S + offS(I, K)};
-    };
-    auto op_inverse = [&](int J, int I, int K) {    // B(I,K) -= S(I,J) B(J,K)
-        return BlkOp{S + offB(J, K), DLD, 1, S + offS(I, J), DLD, S + offB(I, K)};
-    };
-    // two independent block products at once: all 16 operand reads are issued before the first MFMA, and the two
-    // accumulation chains interleave (a single chain leaves the wave waiting on LDS and MFMA latency)
-    auto run_pair = [&](const BlkOp& o0, const BlkOp& o1, bool two, bool subtract) {
-        double a0[4], b0[4], a1[4], b1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int kk = 4 * q + l4;
-            a0[q] = o0.pa[l15 * o0.saa + kk * o0.sak];
-            b0[q] = o0.pb[l15 + kk * o0.sbk];
-            a1[q] = o1.pa[l15 * o1.saa + kk * o1.sak];
-            b1[q] = o1.pb[l15 + kk * o1.sbk];
-        }
-        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        double c0[4], c1[4];
-        if (subtract) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                c0[r] = o0.dst[(l4 + 4 * r) * DLD + l15];
-                c1[r] = o1.dst[(l4 + 4 * r) * DLD + l15];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o0.dst[(l4 + 4 * r) * DLD + l15] = subtract ? c0[r] - acc0[r] : acc0[r];
-        if (two) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o1.dst[(l4 + 4 * r) * DLD + l15] = subtract ? c1[r] - acc1[r] : acc1[r];
-        }
-    };
-
-    if (w == 0) diag_block(0);
-    __syncthreads();
-    for (int J = 0; J < 8; ++J) {
-        // this step's P2 task list, one entry per lane (read back with v_readlane: a scalar load per task would put
-        // its latency on every pair of products); issued here so that it arrives during P1
-        const int mytask = DIAG_TASKS.e[J][lane < 36 ? lane : 0];
-        // ---- P1: panel solve S(I,J) <- S(I,J) Linv^T (I > J) and the inverse's row J: B(J,K) <- Linv B(J,K) (K < J);
-        //      7 block products, wave w takes w and w + 4 as a pair
-        {
-            auto op_p1 = [&](int task) {
-                if (task < 7 - J) {
-                    double* dst = S + offS(J + 1 + task, J);
-                    return BlkOp{S + offB(J, J), 1, DLD, dst, DLD, dst};
-                }
-                double* dst = S + offB(J, task - (7 - J));
-                return BlkOp{dst, DLD, 1, S + offB(J, J), DLD, dst};
-            };
-            const bool two = w + 4 < 7;
-            const BlkOp o0 = op_p1(w);
-            run_pair(o0, two ? op_p1(w + 4) : o0, two, false);
-        }
-        __syncthreads();
-        stamp(2 + 2 * J);
-        // ---- P2 with lookahead: wave 0 updates the next diagonal block and factorises it at once
-        //      (nothing else in P2 touches S(J+1,J+1) or B(J+1,J+1)), waves 1..3 do the rest of the
-        //      trailing update S(I,K) -= S(I,J) S(K,J)^T and of B(I,K) -= S(I,J) B(J,K), two products at a time.
-        const int m = 7 - J;
-        if (w == 0) {
-            if (m > 0) {
-                const BlkOp o = op_trailing(J, J + 1, J + 1);
-                run_pair(o, o, false, true);
-                if (J == 3) stamp(20);
-                diag_block(J + 1);
-                if (J == 3) stamp(23);
-            }
-        } else {
-            const int total = DIAG_TASKS.ntotal[J];
-            auto op_p2 = [&](int task) {
-                const int e = __builtin_amdgcn_readlane(mytask, task);
-                const int I = (e >> 4) & 15, K = e & 15;
-                return (e >> 8) ? op_inverse(J, I, K) : op_trailing(J, I, K);
-            };
-            for (int task = 1 + (w - 1); task < total; task += 6) {   // task 0 = (J+1,J+1): wave 0
-                const bool two = task + 3 < total;
-                const BlkOp o0 = op_p2(task);
-                run_pair(o0, two ? op_p2(task + 3) : o0, two, true);
-            }
-        }
-        __syncthreads();
-        stamp(3 + 2 * J);
-    }
-    bad = __shfl(bad, 0);   // wave 0 holds it; the info store below runs on (w == 0, lane == 0)
-    // ---- write L back to the tile (upper blocks and upper parts of diagonal blocks are zero) and L^-1 to Dinv:
-    //      wave w takes columns 32w.., lanes two rows each (16 B LDS reads, 1 KiB contiguous global stores)
-    {
-        const int R = lane >> 3, ri = 2 * (lane & 7);
-        const d2 zero = {0.0, 0.0};
-#pragma unroll 4
-        for (int c = w * 32; c < w * 32 + 32; ++c) {
-            const int Cb = c >> 4, ci = c & 15;
-            const d2 l = *reinterpret_cast<const d2*>(S + c * DLD + 2 * lane);
-            const d2 x = *reinterpret_cast<const d2*>(S + (R * 16 + ci) * DLD + ((R == Cb) ? TB : Cb * 16) + ri);
-            *reinterpret_cast<d2*>(tk.T + 2 * lane + (size_t)c * tk.ld) = (R >= Cb) ? l : zero;
-            *reinterpret_cast<d2*>(tk.Dinv + 2 * lane + (size_t)c * TB) = (R >= Cb) ? x : zero;
-        }
-    }
-    if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
-    stamp(18);
-    if (tk.wk != nullptr) {
-        // z_k = L_kk^-1 w_k from the inverse blocks still in LDS: thread (r = t >> 1, h = t & 1) sums the columns
-        // [64h, 64h+64) of row r of the lower-triangular inverse; no barrier, so the stores above keep draining
-        const int r = t >> 1, h = t & 1;
-        const int R = r >> 4, ri = r & 15;
-        double s = 0.0;
-        const int cend = min(r, 64 * h + 63);
-        for (int c = 64 * h; c <= cend; ++c) {
-            const int Cb = c >> 4, ci = c & 15;
-            const double x = (R == Cb) ? S[(R * 16 + ci) * DLD + TB + ri] : S[(R * 16 + ci) * DLD + Cb * 16 + ri];
-            s = fma(x, wl[c], s);
-        }
-        s += __shfl_xor(s, 1);
-        if (h == 0) tk.zk[r] = s;
-    }
-    stamp(19);
-}
-
-__global__ __launch_bounds__(256) void chol_diag_kernel(const DiagTask* __restrict__ tasks) {
-    extern __shared__ __attribute__((aligned(16))) double S[];   // [128 cols][DLD rows] + Winv[256] + rhs[128]
-    const DiagTask tk = tasks[blockIdx.x];
-    chol_diag_body<false>(tk, S, nullptr);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Throughput form of the diagonal-block kernel: the same factorisation with a 75 KB LDS image, so TWO workgroups fit a
-// CU (the latency form above holds L and L^-1 side by side in 147 KB: one per CU).  Used when a launch has more
-// blocks than the chip has CUs (thousands of small leaves: depth >= 3 trees); launches of the headline regime, where
-// the kernel sits on the chain of dependent launches with fewer blocks than CUs, keep the latency form.
+// The diagonal-block kernel: blocked right-looking Cholesky of one 128x128 tile on 16x16 sub-blocks in a 75 KB LDS image,
+// so TWO workgroups fit a CU (and one fits next to a tile workgroup).  Per block step J:
+//   P0  wave 0: potrf + inverse of the 16x16 diagonal block in registers (potrf_inv16: lanes 0..15 a column of the block,
+//       lanes 16..31 a column of the identity), cross-lane traffic by v_readlane broadcasts (no LDS, no barrier inside);
+//       for J > 0 it runs inside P2 of step J-1, right after wave 0 has updated that block
+//   P1  all waves: panel S(I,J) = S(I,J) Linv^T (I > J)                                          [MFMA]
+//   P2  waves 1..3: trailing S(I,K) -= S(I,J) S(K,J)^T (I >= K > J)                              [MFMA, two independent
+//       16x16 products in flight per wave]
+// Until round 3 a second, "latency" form of this kernel (L and L^-1 side by side in a 147 KB image: one workgroup per CU, the
+// inverse accumulated by forward substitution on the identity during the factorisation) served the launches with fewer
+// blocks than CUs.  With the inverse phase below barrier-free the packed form is the faster one there too (a launch of
+// 144 blocks: 52.3 against 55.0 us, same box), has no LDS bank conflicts where the other had 42 % (its inverse blocks were
+// read lane-per-column), and can share a CU with a tile workgroup: the latency form is gone.
 //   image : the 36 lower 16x16 blocks in a 9 x 4 block rectangle (PLD = 144 rows, 64 columns): block (I,K) with
 //           K < 4 at block position (I, K); the ten blocks with K >= 4 fill the six free positions above the
 //           diagonal of the first four block columns and the ninth block row (PackedMap)
@@ -1894,7 +1680,8 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
         const double* pb; int sbk;
         double* dst;
     };
-    // two independent block products at once (see chol_diag_body): dst (-)= Bop Aop^T
+    // two independent block products at once: all 16 operand reads are issued before the first MFMA, and the two
+    // accumulation chains interleave (a single chain leaves the wave waiting on LDS and MFMA latency): dst (-)= Bop Aop^T
     auto run_pair = [&](const BlkOp& o0, const BlkOp& o1, bool two, bool subtract) {
         double a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
@@ -2072,14 +1859,6 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
     chol_diag_packed_body(tk, S, false);
 }
 
-#ifdef DSMGP_DIAG
-__global__ __launch_bounds__(256) void chol_diag_stamp_kernel(const DiagTask* __restrict__ tasks,
-                                                              unsigned long long* __restrict__ stamps) {
-    extern __shared__ __attribute__((aligned(16))) double S[];
-    const DiagTask tk = tasks[blockIdx.x];
-    chol_diag_body<true>(tk, S, stamps + 24 * (size_t)blockIdx.x);
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // Triangular solves alpha = L^-T (L^-1 y) (src/gaussianprocess.jl:105) as block sweeps that reuse

@@ -538,46 +538,4 @@ __global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask*
     chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
 }
 
-// Both task kinds in ONE launch (dsmgp_hip.cpp, merged schedule of two leaf groups): the factorisation of a diagonal block
-// is a long dependent chain that leaves the matrix pipe idle, the tile tasks are pipe-bound; a launch that carries the
-// diagonal blocks of one half of the leaves next to the tiles of the other half puts one of each on a CU most of the time.
-// order[b] >= 0: tile task tt[order[b]]; < 0: diagonal-block task dt[~order[b]].
-__global__ __launch_bounds__(256, 2) void step_fused_kernel(const int* __restrict__ order, const DiagFusedTask* __restrict__ dt,
-                                                            const FusedTask* __restrict__ tt, const KParam* __restrict__ kp, int D) {
-    extern __shared__ __attribute__((aligned(16))) double S[];   // DIAGP_LDS_BYTES >= the tile task's ring
-    static_assert(2 * NRING * KC2 * LDP * (int)sizeof(double) <= DIAGP_LDS_BYTES, "the tile task's ring must fit the diagonal task's LDS");
-    const int e = order[blockIdx.x];
-    if (e < 0) {
-        const DiagFusedTask ft = dt[~e];
-        TileTask t2{};
-        t2.A = ft.A;
-        t2.lda = ft.d.ld;
-        t2.k0 = 0;
-        t2.k1 = ft.k1;
-        t2.kid = ft.kid;
-        t2.gxa = ft.gx;
-        t2.glda = ft.glda;
-        t2.gna = t2.gnb = ft.d.nvalid;
-        t2.C = ft.d.T;
-        t2.ldc = ft.d.ld;
-        const bool mem = ft.mem != 0;
-        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w == 3) {
-            const int blk[6] = {0, 1, 3, 4, 6, 7};
-            diag_fused_front<1>(t2, mem, kp, D, S, blk);
-        } else {
-            const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
-            const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
-            diag_fused_front<0>(t2, mem, kp, D, S, blk);
-        }
-        chol_diag_packed_body(ft.d, S, true);
-    } else {
-        double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
-        double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S + NRING * KC2 * LDP);
-        const FusedTask tk = tt[e];
-        if (tk.mrows != 0 && tk.mrows <= 64) tile_fused_body<1>(tk, sA, sB, kp, D);
-        else tile_fused_body<2>(tk, sA, sB, kp, D);
-    }
-}
-
 }  // namespace dsmgp

@@ -20,11 +20,6 @@ int dsmgp_probe_coissue(dsmgp_ctx* ctx, double* out);
 int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,
                      double* seconds_per_launch);
 
-/* diagnostic: chol_diag_kernel on `ntiles` independent SPD 128x128 blocks (leading dimension ld >= 128):
- * kernel_us = average launch time; phases_us[23]: [0..18] time between the kernel's 20 in-kernel stamps on block 0
- * (load, then P1/P2 of the 8 block columns, store, fused z), [19..22] wave 0's share of the fourth P2
- * (block product, LDS reads, potrf_inv16 in registers, LDS writes) */
-int dsmgp_probe_diag(dsmgp_ctx* ctx, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us);
 
 #ifdef __cplusplus
 }

@@ -977,10 +977,12 @@ def test_aggregate_error_paths(ctx):
 
 
 def test_throughput_and_latency_forms_of_the_diagonal_block_kernel_agree(ctx):
-    """A launch with more diagonal blocks than CUs takes the 75 KB packed kernel (two workgroups per CU, L^-1 formed in
-    place after L), smaller launches the 147 KB latency kernel: same factors, inverses (through alpha and the
-    prediction) and fused forward solves, to rounding.  600 leaves of 140..330 rows in one table against the same
-    leaves fitted 100 at a time, and a sample against the oracle."""
+    """The diagonal-block kernel (75 KB packed LDS image, L^-1 formed block column by block column in registers after L,
+    forward substitution riding along, pure-padding block steps skipped) in launches of every kind -- 600 blocks per launch
+    (two workgroups per CU, fused steps: the tile arrives in the image straight from its update) against the same leaves
+    fitted 100 at a time (fewer blocks than CUs; until round 3 a second, 147 KB "latency" form of the kernel ran there):
+    same factors, inverses (through alpha and the prediction) and fused forward solves, to rounding; a sample against the
+    oracle.  Leaves of 140..330 rows: last blocks of 12..128 data rows."""
     N, D, L = 40_000, 3, 600
     X, y, Xt = regression_data(N, D, n_test=40, seed=4711)
     rng = np.random.default_rng(3)
@@ -1001,8 +1003,8 @@ def test_throughput_and_latency_forms_of_the_diagonal_block_kernel_agree(ctx):
         alphas = [ctx.download_factor(i, obs[j].size)[1] for i, j in enumerate(sel[:5])]
         return mll, mu.reshape(len(sel), nt), var.reshape(len(sel), nt), alphas
 
-    big = run(list(range(L)))                                   # 600 blocks per launch > 256 CUs: packed kernel
-    for a in range(0, L, 100):                                  # 100 blocks per launch: latency kernel
+    big = run(list(range(L)))                                   # 600 blocks per launch > 256 CUs
+    for a in range(0, L, 100):                                  # 100 blocks per launch
         sel = list(range(a, a + 100))
         small = run(sel)
         assert np.allclose(big[0][a:a + 100], small[0], rtol=1e-12)
@@ -1276,9 +1278,7 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
     block / panel solve launches.  Same arithmetic up to the order of one addition per entry: log-marginals 1e-12, the
     factor of sampled leaves 1e-11, moments 1e-9 (conditioning-limited); three leaves against the oracle at the
     north-star tolerance.  All three kernel kinds (the Gram values are evaluated inside the tasks)."""
-    # kind 0: 2200 leaves -- enough (>= 8 x CUs) for the two-group merged schedule, where one launch carries the diagonal
-    # blocks of one half of the leaves next to the tiles of the other half (step_fused_kernel)
-    N, D, L = 60_000, 3, (2200 if kind == 0 else 700)
+    N, D, L = 60_000, 3, 700
     X, y, Xt = regression_data(N, D, n_test=160, seed=5150 + kind)
     rng = np.random.default_rng(11 + kind)
     sizes = rng.integers(130, 701, size=L)
