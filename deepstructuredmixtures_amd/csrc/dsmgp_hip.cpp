@@ -2964,6 +2964,92 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     dev_free(C);
     return 0;
 }
+// Diagnostic: the diagonal-block kernel alone on `ntiles` well-conditioned blocks (microseconds per launch over `reps`
+// launches) and the wall-clock phases of block 0's wave 0 from one stamped launch: phases_us[0..19] = load, first
+// 16x16 block, then (P1, P2) of the 8 block steps, write-back, inverse phase; [20], [21] = inside step 3's P2 on wave 0:
+// the trailing product of the next diagonal block, its potrf + inverse (potrf_inv16 with its LDS reads and writes);
+// [22] = shader cycles of [21].
+int dsmgp_probe_diag(dsmgp_ctx* c, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us) {
+    if (!c || ntiles <= 0 || ld < TB || reps <= 0 || !kernel_us || !phases_us) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t tile = (size_t)ld * TB;
+    std::vector<double> h(tile, 0.0);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        return (double)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    };
+    for (int cidx = 0; cidx < TB; ++cidx)
+        for (int r = cidx; r < TB; ++r) h[r + (size_t)cidx * ld] = (r == cidx) ? 64.0 + rnd() : rnd();
+    double *T0 = nullptr, *T = nullptr, *Dinv = nullptr, *wz = nullptr;
+    int* info = nullptr;
+    unsigned long long* stamps = nullptr;
+    DiagTask* dt = nullptr;
+    HIPCHK(c, hipMalloc(&T0, tile * sizeof(double)));
+    HIPCHK(c, hipMalloc(&T, ntiles * tile * sizeof(double)));
+    HIPCHK(c, hipMalloc(&Dinv, (size_t)ntiles * TB * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&wz, (size_t)ntiles * 2 * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&info, ntiles * sizeof(int)));
+    HIPCHK(c, hipMalloc(&stamps, (size_t)ntiles * 24 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&dt, ntiles * sizeof(DiagTask)));
+    HIPCHK(c, hipMemcpy(T0, h.data(), tile * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(wz, 0, (size_t)ntiles * 2 * TB * sizeof(double)));
+    HIPCHK(c, hipMemset(info, 0, ntiles * sizeof(int)));
+    std::vector<DiagTask> tasks(ntiles);
+    for (int i = 0; i < ntiles; ++i) {
+        DiagTask g{};
+        g.T = T + i * tile;
+        g.Dinv = Dinv + (size_t)i * TB * TB;
+        g.wk = wz + (size_t)i * 2 * TB;
+        g.zk = wz + (size_t)i * 2 * TB + TB;
+        g.info = info + i;
+        g.ld = ld;
+        g.nvalid = TB;
+        g.row0 = 0;
+        tasks[i] = g;
+    }
+    HIPCHK(c, hipMemcpy(dt, tasks.data(), ntiles * sizeof(DiagTask), hipMemcpyHostToDevice));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_stamp_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
+    const size_t lds = DIAGP_LDS_BYTES;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    auto refill = [&]() {
+        for (int i = 0; i < ntiles; ++i)
+            (void)hipMemcpyAsync(T + i * tile, T0, tile * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    };
+    double total = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {
+        refill();
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        chol_diag_packed_kernel<<<ntiles, 256, lds, c->stream>>>(dt);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+    }
+    *kernel_us = total / reps * 1e3;
+    refill();
+    chol_diag_packed_stamp_kernel<<<ntiles, 256, lds, c->stream>>>(dt, stamps);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long hs[24];
+    HIPCHK(c, hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 20; ++i) phases_us[i] = (double)(hs[i + 1] - hs[i]) * 0.01;   // 100 MHz
+    phases_us[20] = (double)(hs[21] - hs[9]) * 0.01;
+    phases_us[21] = (double)(hs[22] - hs[21]) * 0.01;
+    phases_us[22] = (double)hs[23];                       // shader cycles of the interval of [21]
+    int bad = 0;
+    HIPCHK(c, hipMemcpy(&bad, info, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(T0); (void)hipFree(T); (void)hipFree(Dinv); (void)hipFree(wz);
+    (void)hipFree(info); (void)hipFree(stamps); (void)hipFree(dt);
+    if (bad != 0) return fail(c, DSMGP_E_STATE, "probe block was not positive definite");
+    return 0;
+}
+
 #endif  // DSMGP_DIAG
 
 // -------------------------------------------------------------------------------------------------

@@ -1516,6 +1516,80 @@ __device__ __forceinline__ int potrf_inv16(double (&x)[16], double& x_scale, dou
     return badmask ? __builtin_ctz(badmask) + 1 : 0;
 }
 
+// potrf + inverse of one 16x16 diagonal block on the matrix pipe, one wave, everything in accumulator layout
+// (register r of lane l = element (4r + (l >> 4), l & 15)).  The block is eliminated four pivots at a time:
+//   D   = the 4x4 diagonal block of group g (ten v_readlane pairs out of register g), factorised and inverted by the
+//         same ~50 scalar-like VALU operations on every lane (four rsqrt chains): Linv_g
+//   P^T = Linv_g M(G,:)                one MFMA: A = Linv_g in the first four rows of a 16x4 operand, B = register g of M
+//                                      as it stands (rows 4g..4g+3 of the symmetric block = the operand's k-slab);
+//                                      register 0 of the result holds P(l & 15, l >> 4) -- which is P as an A operand
+//                                      AND P^T as a B operand
+//   M  -= P P^T                        one MFMA with that register as both operands: the rank-4 trailing update of all
+//                                      16 x 16 entries (rows and columns of finished groups pick up rounding residue that
+//                                      nothing reads)
+//   X_G = Linv_g R(G,:),  R -= P X_G   the same two MFMAs on the identity: X = L^-1 by forward substitution
+// Register 0 of the P^T products, group by group, IS L^T in accumulator layout, that of the X_G products IS L^-1.
+// Against the column-per-lane form it replaces (rank-1 updates, a v_readlane pair per row and pivot: ~870 VALU
+// instructions, 7200 cycles measured) this is ~400 VALU instructions and 16 MFMAs.
+// Returns the 1-based index of the first non-positive pivot (0 = none); lt = L^T (upper part incl. rounding residue
+// below its diagonal: the caller masks), xinv = L^-1.
+__device__ __forceinline__ int potrf_inv16_mfma(d4 m, d4& lt, d4& xinv, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4 R;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[r] = (4 * r + l4 == l15) ? 1.0 : 0.0;
+    unsigned badmask = 0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const double mg = m[g];
+        const double d00 = readlane_f64(mg, 4 * g);
+        const double d10 = readlane_f64(mg, 16 + 4 * g), d11 = readlane_f64(mg, 16 + 4 * g + 1);
+        const double d20 = readlane_f64(mg, 32 + 4 * g), d21 = readlane_f64(mg, 32 + 4 * g + 1), d22 = readlane_f64(mg, 32 + 4 * g + 2);
+        const double d30 = readlane_f64(mg, 48 + 4 * g), d31 = readlane_f64(mg, 48 + 4 * g + 1), d32 = readlane_f64(mg, 48 + 4 * g + 2),
+                     d33 = readlane_f64(mg, 48 + 4 * g + 3);
+        const double r0 = rsqrt_nr(d00);
+        const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+        const double e11 = fma(-l10, l10, d11);
+        const double r1 = rsqrt_nr(e11);
+        const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+        const double e22 = fma(-l21, l21, fma(-l20, l20, d22));
+        const double r2 = rsqrt_nr(e22);
+        const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
+        const double e33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+        const double r3 = rsqrt_nr(e33);
+        badmask |= ((d00 > 0.0) ? 0u : 1u) << (4 * g) | ((e11 > 0.0) ? 0u : 2u) << (4 * g) | ((e22 > 0.0) ? 0u : 4u) << (4 * g) |
+                   ((e33 > 0.0) ? 0u : 8u) << (4 * g);
+        // Linv_g (lower): columns of the inverse by forward substitution
+        const double i10 = -(l10 * r0) * r1;
+        const double i21 = -(l21 * r1) * r2;
+        const double i32 = -(l32 * r2) * r3;
+        const double i20 = -fma(l21, i10, l20 * r0) * r2;
+        const double i31 = -fma(l32, i21, l31 * r1) * r3;
+        const double i30 = -fma(l32, i20, fma(l31, i10, l30 * r0)) * r3;
+        // A operand: lane (a = l & 15, k = l >> 4) supplies Linv_g(a, k) for k <= a < 4, zero elsewhere
+        double a2 = 0.0;
+        a2 = (lane == 0) ? r0 : a2;
+        a2 = (lane == 1) ? i10 : a2;
+        a2 = (lane == 2) ? i20 : a2;
+        a2 = (lane == 3) ? i30 : a2;
+        a2 = (lane == 17) ? r1 : a2;
+        a2 = (lane == 18) ? i21 : a2;
+        a2 = (lane == 19) ? i31 : a2;
+        a2 = (lane == 34) ? r2 : a2;
+        a2 = (lane == 35) ? i32 : a2;
+        a2 = (lane == 51) ? r3 : a2;
+        const d4 pt = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, mg, zero, 0, 0, 0);
+        const double p = pt[0];
+        m = __builtin_amdgcn_mfma_f64_16x16x4f64(-p, p, m, 0, 0, 0);
+        const d4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, R[g], zero, 0, 0, 0);
+        R = __builtin_amdgcn_mfma_f64_16x16x4f64(-p, xt[0], R, 0, 0, 0);
+        lt[g] = p;
+        xinv[g] = xt[0];
+    }
+    return badmask ? __builtin_ctz(badmask) + 1 : 0;
+}
+
 // P2 task list of every block step J of chol_diag_kernel, fixed at compile time: first the trailing products
 // S(I,K) -= S(I,J) S(K,J)^T (K = J+1.., I = K..7; task 0 = (J+1,J+1) belongs to wave 0), then the inverse products
 // B(I,K) -= S(I,J) B(J,K) (I = J+1..7, K = 0..J).  Entry = kind << 8 | I << 4 | K.  Looked up with scalar loads; the
@@ -1599,8 +1673,21 @@ __constant__ const PackedMap PACKED{};
 // the accumulators of the tile's update); the barrier below makes them visible
 // (Rotating the wave roles with the workgroup index, so that the pivot chains of the two workgroups of a CU run on different
 // SIMDs, measured no difference: depth 4 0.0604 / 0.0593 / 0.0594 s without, 0.0596 / 0.0597 / 0.0586 s with, same box.)
-__device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double* S, bool have_image) {
+template <bool STAMP = false>
+__device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double* S, bool have_image,
+                                                      unsigned long long* st = nullptr) {
     const int t = threadIdx.x, lane = t & 63;
+    // STAMP (diagnostic build only): wave 0 records the 100 MHz wall clock at the phase boundaries of its block
+    auto stamp = [&](int i) {
+        if constexpr (STAMP) {
+            if (t == 0) {
+                unsigned long long now;
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+                st[i] = now;
+            }
+        }
+    };
+    stamp(0);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     double* wl = S + PIMG;                 // right-hand side block w_k, updated in place by the fused forward substitution
@@ -1638,6 +1725,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
         zl[t] = 0.0;                       // (block steps of pure padding are skipped: their z is the zero right-hand side)
     }
     __syncthreads();
+    stamp(1);
     // Block steps that hold data.  The last block of a leaf is padded with the identity (n mod 128 rows of data): the 16x16
     // blocks from JN on are the identity -- their own factor and inverse -- and everything below and beside them is zero,
     // so the factorisation stops after step JN - 1 (whose lookahead still passes block JN through diag_block: it writes that
@@ -1647,32 +1735,22 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
     int bad = 0;
     // diagonal block J on wave 0: L_JJ -> global tile (from registers), L_JJ^-1 -> its slot in the image and -> Dinv
     auto diag_block = [&](int J) {
-        const int c = l15;
-        const bool isb = (lane & 16) != 0;
-        double x[16], xs, xd;
-        double* slot = S + off(J, J) + c * PLD;
-        const d2* src = reinterpret_cast<const d2*>(slot);
+        double* slot = S + off(J, J);
+        d4 m, lt, xi;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const d2 v = src[r >> 1];
-            x[r] = isb ? ((r == c) ? 1.0 : 0.0) : v[0];
-            x[r + 1] = isb ? ((r + 1 == c) ? 1.0 : 0.0) : v[1];
-        }
-        const int bj = potrf_inv16(x, xs, xd, lane);
+        for (int r = 0; r < 4; ++r) m[r] = slot[(4 * r + l4) * PLD + l15];     // (c, r) for (r, c): the block is symmetric
+        const int bj = potrf_inv16_mfma(m, lt, xi, lane);
         if (bj != 0 && bad == 0) bad = J * 16 + bj;
-        if (lane < 32) {
-            const int thr = isb ? c : c + 1;
-            const double mul = isb ? 1.0 : xs;
-            double* gdst = isb ? tk.Dinv + (size_t)(16 * J) + (size_t)(16 * J + c) * TB
-                               : tk.T + (size_t)(16 * J) + (size_t)(16 * J + c) * tk.ld;
+        // lt register g = L(l15, 4g + l4), xi register g = L^-1(4g + l4, l15)
+        const gf64_ptr gT = AS_GLOBAL_F64(tk.T + (size_t)(16 * J + l15) + (size_t)(16 * J + l4) * tk.ld);
+        const gf64_ptr gD = AS_GLOBAL_F64(tk.Dinv + (size_t)(16 * J + l4) + (size_t)(16 * J + l15) * TB);
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                d2 v;
-                v[0] = (r >= thr) ? x[r] * mul : ((r == c) ? xd : 0.0);
-                v[1] = (r + 1 >= thr) ? x[r + 1] * mul : ((r + 1 == c) ? xd : 0.0);
-                *reinterpret_cast<d2*>(gdst + r) = v;
-                if (isb) *reinterpret_cast<d2*>(slot + r) = v;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const int q = 4 * g + l4;
+            gT[(size_t)(4 * g) * tk.ld] = (l15 >= q) ? lt[g] : 0.0;
+            const double x = (q >= l15) ? xi[g] : 0.0;
+            gD[4 * g] = x;
+            slot[l15 * PLD + q] = x;
         }
     };
     struct BlkOp {
@@ -1720,6 +1798,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
     // ---- phase 1: factorisation
     if (w == 0) diag_block(0);
     __syncthreads();
+    stamp(2);
     for (int J = 0; J < 8; ++J) {
         if (J >= JN) break;
         const int mytask = DIAG_TASKS.e[J][lane < 36 ? lane : 0];
@@ -1742,12 +1821,24 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
             }
         }
         __syncthreads();
+        stamp(3 + 2 * J);
         const int m = 7 - J;
         if (w == 0) {
             if (m > 0) {
                 const BlkOp o = op_trailing(J, J + 1, J + 1);
                 run_pair(o, o, false, true);
+                unsigned long long cyc0 = 0;
+                if (J == 3) {
+                    stamp(21);
+                    if constexpr (STAMP) cyc0 = stamp_now();
+                }
                 diag_block(J + 1);
+                if (J == 3) {
+                    if constexpr (STAMP) {
+                        if (t == 0) st[23] = stamp_now() - cyc0;     // shader cycles of the same interval
+                    }
+                    stamp(22);
+                }
             }
         } else {
             const int total = DIAG_TASKS.ntrail[J];
@@ -1771,6 +1862,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
             }
         }
         __syncthreads();
+        stamp(4 + 2 * J);
     }
     bad = __shfl(bad, 0);
     if (fuse && t < TB) tk.zk[t] = zl[t];
@@ -1812,6 +1904,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
             }
         }
     }
+    stamp(19);
     // ---- phase 2: L^-1, two block columns per wave, blocks in registers, no barrier (the image is only read)
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -1850,6 +1943,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
             for (int r = 0; r < 4; ++r) gD[4 * r] = xr[i][r];
         }
     }
+    stamp(20);
     if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
 }
 
@@ -1858,6 +1952,13 @@ __global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* _
     const DiagTask tk = tasks[blockIdx.x];
     chol_diag_packed_body(tk, S, false);
 }
+#ifdef DSMGP_DIAG
+__global__ __launch_bounds__(256) void chol_diag_packed_stamp_kernel(const DiagTask* __restrict__ tasks, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double S[];
+    const DiagTask tk = tasks[blockIdx.x];
+    chol_diag_packed_body<true>(tk, S, false, stamps + 24 * blockIdx.x);
+}
+#endif
 
 
 // ---------------------------------------------------------------------------------------------

@@ -86,6 +86,7 @@ SIGNATURES = {
 DIAG_SIGNATURES = {
     "dsmgp_probe_coissue": (C.c_int, [_ctx, _dp]),
     "dsmgp_bench_tile": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "dsmgp_probe_diag": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
 }
 DIAG_LIB_PATH = os.path.join(_HERE, "libdsmgp_hip_diag.so")
 
@@ -421,6 +422,13 @@ class Context:
         self._chk(self.lib.dsmgp_probe_coissue(self.h, out.ctypes.data_as(_dp)))
         return {m: dict(mfma_tflops=out[3 * i], valu_tflops=out[3 * i + 1], ms=out[3 * i + 2])
                 for i, m in enumerate(("mfma_only", "valu_only", "both"))}
+
+    def probe_diag(self, ntiles, ld=8192, reps=20):
+        """(diagnostic library) microseconds per launch of the diagonal-block kernel on ntiles blocks, phases of one block"""
+        us = C.c_double(0.0)
+        ph = np.zeros(23)
+        self._chk(self.lib.dsmgp_probe_diag(self.h, int(ntiles), int(ld), int(reps), C.byref(us), ph.ctypes.data_as(_dp)))
+        return us.value, ph
 
     def bench_tile(self, ntiles, K, mode=0, group=16, reps=3):
         """TFLOP/s of the tile GEMM on a uniform batch (diagnostic)."""

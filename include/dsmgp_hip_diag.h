@@ -19,7 +19,10 @@ int dsmgp_probe_coissue(dsmgp_ctx* ctx, double* out);
  * (mode 0: own A panel per tile, B panel shared by `group` tiles; mode 1: all operands shared, L2-resident) */
 int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,
                      double* seconds_per_launch);
-
+/* diagnostic: the diagonal-block kernel alone on ntiles blocks (us per launch) and the wall-clock phases of one block:
+ * phases_us[23] = load, first 16x16 block, (P1, P2) x 8 block steps, write-back, inverse phase, and inside step 3's P2 on
+ * wave 0 the trailing product and the potrf + inverse of the next 16x16 diagonal block (us, then shader cycles) */
+int dsmgp_probe_diag(dsmgp_ctx* ctx, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us);
 
 #ifdef __cplusplus
 }
