@@ -1102,6 +1102,8 @@ int build_plan(dsmgp_ctx* c) {
         HostLog hl("build_plan: arenas");
         if (int rc = arena_get(c, c->arenaF, fTot)) return rc;
         if (int rc = arena_get(c, c->arenaDinv, dTot)) return rc;
+        // the diagonal-block kernel writes the lower blocks of Dinv_k only: the blocks above the diagonal are zero from here on
+        HIPCHK(c, hipMemsetAsync(c->arenaDinv, 0, std::max<size_t>(1, dTot) * sizeof(double), c->stream));
         if (int rc = arena_get(c, c->arenaVec, vTot)) return rc;
         if (int rc = arena_get(c, c->arenaXg, xTot)) return rc;
     }
@@ -2994,6 +2996,7 @@ int dsmgp_probe_diag(dsmgp_ctx* c, int32_t ntiles, int32_t ld, int32_t reps, dou
     HIPCHK(c, hipMalloc(&dt, ntiles * sizeof(DiagTask)));
     HIPCHK(c, hipMemcpy(T0, h.data(), tile * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemset(wz, 0, (size_t)ntiles * 2 * TB * sizeof(double)));
+    HIPCHK(c, hipMemset(Dinv, 0, (size_t)ntiles * TB * TB * sizeof(double)));
     HIPCHK(c, hipMemset(info, 0, ntiles * sizeof(int)));
     std::vector<DiagTask> tasks(ntiles);
     for (int i = 0; i < ntiles; ++i) {

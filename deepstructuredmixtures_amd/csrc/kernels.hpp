@@ -1450,6 +1450,13 @@ struct DiagTask {
     int pad;
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on this target
+// waits for every outstanding GLOBAL store of the wave as well (s_waitcnt vmcnt(0)): in the diagonal-block kernel, whose
+// results stream out to the tile and to Dinv while it runs, that put the store latency on the chain of all 17 barriers.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -1479,41 +1486,6 @@ __device__ __forceinline__ double rcp_nr(double d) {
     const double r = __builtin_amdgcn_rcp(d);
     const double e = fma(-d, r, 1.0);                  // 1 - d r
     return fma(r * e, 1.0 + e, r);                     // r (1 + e + e^2)
-}
-
-// potrf + inverse of one 16x16 diagonal block, in registers of one wave.  Lanes 0..15 hold column c = lane & 15 of
-// the symmetric block, lanes 16..31 column c of the identity that is forward-substituted into L^-1 (lanes 32..63
-// mirror), both in x[]: one fma per row and pivot updates the factorisation and the inverse together.
-// Per pivot j: d = A(j,j) by v_readlane; the rank-1 update uses the *unscaled* column j (broadcast by v_readlane)
-// against m = A(j,c)/d resp. X'(j,c)/d, so the chain from one pivot to the next is readlane -> 1/d -> one
-// multiply -> one fma; 1/sqrt(d), which only scales finished values (x_scale for column j, applied once at the
-// end; X(j,c) = X'(j,c)/sqrt(d); the diagonal entry sqrt(d), kept aside in x_diag), runs beside that chain.
-// Lane j and the finished columns see m = 0: the loop body is two readlanes and one fma, no selects.
-// Returns the 1-based index of the first non-positive pivot (0 = none).
-__device__ __forceinline__ int potrf_inv16(double (&x)[16], double& x_scale, double& x_diag, int lane) {
-    const int c = lane & 15;
-    const bool isb = (lane & 16) != 0;
-    unsigned badmask = 0;      // bit j: pivot j was not positive (no dependent chain: the first one is picked at the end)
-    x_scale = 1.0;
-    x_diag = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double d = readlane_f64(x[j], j);
-        badmask |= (d > 0.0) ? 0u : (1u << j);
-        const double xsel = (!isb && c <= j) ? 0.0 : x[j];
-        const double m = xsel * rcp_nr(d);
-#pragma unroll
-        for (int r = j + 1; r < 16; ++r) x[r] = fma(-readlane_f64(x[r], j), m, x[r]);
-        const double inv = rsqrt_nr(d);
-        double sd = d * inv;
-        sd = fma(fma(-sd, sd, d), 0.5 * inv, sd);
-        if (isb) x[j] *= inv;                 // X(j,c), final
-        if (!isb && c == j) {
-            x_scale = inv;
-            x_diag = sd;
-        }
-    }
-    return badmask ? __builtin_ctz(badmask) + 1 : 0;
 }
 
 // potrf + inverse of one 16x16 diagonal block on the matrix pipe, one wave, everything in accumulator layout
@@ -1579,10 +1551,11 @@ __device__ __forceinline__ int potrf_inv16_mfma(d4 m, d4& lt, d4& xinv, int lane
         a2 = (lane == 34) ? r2 : a2;
         a2 = (lane == 35) ? i32 : a2;
         a2 = (lane == 51) ? r3 : a2;
+        // (a dependent f64 MFMA waits ~100 cycles for its predecessor: the independent product on R goes in between)
         const d4 pt = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, mg, zero, 0, 0, 0);
+        const d4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, R[g], zero, 0, 0, 0);
         const double p = pt[0];
         m = __builtin_amdgcn_mfma_f64_16x16x4f64(-p, p, m, 0, 0, 0);
-        const d4 xt = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, R[g], zero, 0, 0, 0);
         R = __builtin_amdgcn_mfma_f64_16x16x4f64(-p, xt[0], R, 0, 0, 0);
         lt[g] = p;
         xinv[g] = xt[0];
@@ -1590,26 +1563,6 @@ __device__ __forceinline__ int potrf_inv16_mfma(d4 m, d4& lt, d4& xinv, int lane
     return badmask ? __builtin_ctz(badmask) + 1 : 0;
 }
 
-// P2 task list of every block step J of chol_diag_kernel, fixed at compile time: first the trailing products
-// S(I,K) -= S(I,J) S(K,J)^T (K = J+1.., I = K..7; task 0 = (J+1,J+1) belongs to wave 0), then the inverse products
-// B(I,K) -= S(I,J) B(J,K) (I = J+1..7, K = 0..J).  Entry = kind << 8 | I << 4 | K.  Looked up with scalar loads; the
-// closed forms (a search loop and an integer division per task) cost more than the product itself.
-struct DiagTaskTable {
-    unsigned short e[8][36];
-    unsigned char ntrail[8], ntotal[8];
-    constexpr DiagTaskTable() : e{}, ntrail{}, ntotal{} {
-        for (int J = 0; J < 8; ++J) {
-            int n = 0;
-            for (int K = J + 1; K < 8; ++K)
-                for (int I = K; I < 8; ++I) e[J][n++] = (unsigned short)(I << 4 | K);
-            ntrail[J] = (unsigned char)n;
-            for (int I = J + 1; I < 8; ++I)
-                for (int K = 0; K <= J; ++K) e[J][n++] = (unsigned short)(1 << 8 | I << 4 | K);
-            ntotal[J] = (unsigned char)n;
-        }
-    }
-};
-__constant__ const DiagTaskTable DIAG_TASKS{};
 
 // ---------------------------------------------------------------------------------------------
 // The diagonal-block kernel: blocked right-looking Cholesky of one 128x128 tile on 16x16 sub-blocks in a 75 KB LDS image,
@@ -1701,39 +1654,56 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
     if (t < 64) soff[t] = mytab;
     auto off = [&](int I, int K) { return __builtin_amdgcn_readlane(mytab, I * 8 + K); };
 
-    if (!have_image) {   // lower blocks of the tile -> image: 9 blocks per wave, a lane moves four rows of one column of a block
-        const int bc = lane >> 2, br = 4 * (lane & 3);
+    // Block <-> global mapping of the bulk moves: a lane moves 16 B, the 8 lanes of a column its 16 rows = one whole
+    // 128-B line, an instruction 8 columns (two per block); in the image those 16 lanes of a pass hit 64 different banks
+    const int mc = lane >> 3, mr = 2 * (lane & 7);
+    if (!have_image) {   // lower blocks of the tile -> image: 9 blocks per wave
         d2 v[9][2];
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
             const int I = e >> 4, K = e & 15;
-            const gd2_cptr src = AS_GLOBAL_D2(tk.T + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * tk.ld);
-            v[q][0] = src[0];
-            v[q][1] = src[1];
+            const double* src = tk.T + (size_t)(16 * I + mr) + (size_t)(16 * K + mc) * tk.ld;
+            v[q][0] = *AS_GLOBAL_D2(src);
+            v[q][1] = *AS_GLOBAL_D2(src + (size_t)8 * tk.ld);
         }
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
-            double* dst = S + off(e >> 4, e & 15) + bc * PLD + br;
+            double* dst = S + off(e >> 4, e & 15) + mc * PLD + mr;
             *reinterpret_cast<d2*>(dst) = v[q][0];
-            *reinterpret_cast<d2*>(dst + 2) = v[q][1];
+            *reinterpret_cast<d2*>(dst + 8 * PLD) = v[q][1];
         }
     }
     if (tk.wk != nullptr && t < TB) {
         wl[t] = tk.wk[t];
         zl[t] = 0.0;                       // (block steps of pure padding are skipped: their z is the zero right-hand side)
     }
-    __syncthreads();
-    stamp(1);
     // Block steps that hold data.  The last block of a leaf is padded with the identity (n mod 128 rows of data): the 16x16
     // blocks from JN on are the identity -- their own factor and inverse -- and everything below and beside them is zero,
     // so the factorisation stops after step JN - 1 (whose lookahead still passes block JN through diag_block: it writes that
     // block's L and L^-1) and the diagonal blocks beyond are written as they are.
     const int JN = (tk.nvalid + 15) >> 4;
-
+    // What is known to be zero in the tile goes out NOW, while the image settles: the blocks above the diagonal and the
+    // off-diagonal blocks of the skipped block columns.  (At the end of the kernel these stores, then with the upper blocks
+    // of Dinv, were 2 of its 3.4 us of write-back: the store queue, not the LDS, was the limit.)  The blocks of Dinv above
+    // the diagonal are never written: the arena is zeroed when the leaf table is set and only this kernel writes to it.
+    {
+        const d2 zero = {0.0, 0.0};
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int b = w + 4 * q, I = b >> 3, K = b & 7;
+            if (I < K || (I > K && K >= JN)) {
+                double* gT = tk.T + (size_t)(16 * I + mr) + (size_t)(16 * K + mc) * tk.ld;
+                *reinterpret_cast<d2*>(gT) = zero;
+                *reinterpret_cast<d2*>(gT + (size_t)8 * tk.ld) = zero;
+            }
+        }
+    }
+    lds_barrier();
+    stamp(1);
     int bad = 0;
-    // diagonal block J on wave 0: L_JJ -> global tile (from registers), L_JJ^-1 -> its slot in the image and -> Dinv
+    // diagonal block J on wave 0: L_JJ -> global tile (from registers), L_JJ^-1 -> Dinv and -> its slot in the image
     auto diag_block = [&](int J) {
         double* slot = S + off(J, J);
         d4 m, lt, xi;
@@ -1753,63 +1723,75 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
             slot[l15 * PLD + q] = x;
         }
     };
-    struct BlkOp {
-        const double* pa; int saa, sak;
-        const double* pb; int sbk;
-        double* dst;
+    // Operand fragment of a 16x16 block for either side of the MFMA: element (l15, 4q + l4) of a column-major block is the
+    // A operand A[i = l15][k = 4q + l4]; element (4q + l4, l15) of a ROW-major block is the B operand B[k][j = l15]; and the
+    // B operand of the transpose of a column-major block is that same address again.  16 lanes along the contiguous index,
+    // 4 along the leading dimension (144 = 16 mod 32 doubles): conflict-free.
+    auto frag = [&](const double* blk, double (&f)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = blk[(4 * q + l4) * PLD + l15];
     };
-    // two independent block products at once: all 16 operand reads are issued before the first MFMA, and the two
-    // accumulation chains interleave (a single chain leaves the wave waiting on LDS and MFMA latency): dst (-)= Bop Aop^T
-    auto run_pair = [&](const BlkOp& o0, const BlkOp& o1, bool two, bool subtract) {
-        double a0[4], b0[4], a1[4], b1[4];
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    // one block product alone: two half chains (a dependent f64 MFMA waits ~100 cycles for its predecessor where an
+    // independent one issues after 64), summed
+    auto mma4 = [&](const double (&fa)[4], const double (&fb)[4]) {
+        d4 u = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], zero4, 0, 0, 0);
+        d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1], fb[1], zero4, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[2], fb[2], u, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[3], fb[3], v, 0, 0, 0);
+        return u + v;
+    };
+    // two block products at once, their chains interleaved
+    auto mma4x2 = [&](const double (&fa)[4], const double (&fb)[4], d4& acc0, const double (&ga)[4], const double (&gb)[4], d4& acc1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int kk = 4 * q + l4;
-            a0[q] = o0.pa[l15 * o0.saa + kk * o0.sak];
-            b0[q] = o0.pb[l15 + kk * o0.sbk];
-            a1[q] = o1.pa[l15 * o1.saa + kk * o1.sak];
-            b1[q] = o1.pb[l15 + kk * o1.sbk];
-        }
-        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        double c0[4], c1[4];
-        if (subtract) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                c0[r] = o0.dst[(l4 + 4 * r) * PLD + l15];
-                c1[r] = o1.dst[(l4 + 4 * r) * PLD + l15];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o0.dst[(l4 + 4 * r) * PLD + l15] = subtract ? c0[r] - acc0[r] : acc0[r];
-        if (two) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o1.dst[(l4 + 4 * r) * PLD + l15] = subtract ? c1[r] - acc1[r] : acc1[r];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q], fb[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[q], gb[q], acc1, 0, 0, 0);
         }
     };
-    auto op_trailing = [&](int J, int I, int K) {   // S(I,K) -= S(I,J) S(K,J)^T
-        return BlkOp{S + off(K, J), 1, PLD, S + off(I, J), PLD, S + off(I, K)};
-    };
-
+    // entry `lane` of the list of trailing blocks (see P2): column K = 7, 6, ... with its blocks I = K..7
+    int mytask = 0x77;
+    {
+        int start = 0;
+#pragma unroll
+        for (int K = 7; K >= 1; --K) {
+            if (lane >= start && lane < start + 8 - K) mytask = (K + lane - start) << 4 | K;
+            start += 8 - K;
+        }
+    }
     // ---- phase 1: factorisation
     if (w == 0) diag_block(0);
-    __syncthreads();
+    lds_barrier();
     stamp(2);
     for (int J = 0; J < 8; ++J) {
         if (J >= JN) break;
-        const int mytask = DIAG_TASKS.e[J][lane < 36 ? lane : 0];
-        {   // P1: S(I,J) <- S(I,J) L_JJ^-T, I > J; wave w takes I = J+1+w and J+1+w+4
+        {   // P1: S(I,J) <- S(I,J) L_JJ^-T, I > J; wave w takes I = J+1+w and J+1+w+4.  register r = element (l15, l4 + 4r)
+            // of the block: it goes to the image and, being final, to the tile in global memory
             const int m = 7 - J;
             if (w < m) {
                 double* d0 = S + off(J + 1 + w, J);
                 const bool two = w + 4 < m;
                 double* d1 = two ? S + off(J + 1 + w + 4, J) : d0;
-                const double* linv = S + off(J, J);
-                run_pair(BlkOp{linv, 1, PLD, d0, PLD, d0}, BlkOp{linv, 1, PLD, d1, PLD, d1}, two, false);
+                double la[4], b0[4], b1[4];
+                frag(S + off(J, J), la);            // (the slot's upper part is zero)
+                frag(d0, b0);
+                frag(d1, b1);
+                d4 acc0 = zero4, acc1 = zero4;
+                if (two) mma4x2(la, b0, acc0, la, b1, acc1);
+                else acc0 = mma4(la, b0);
+                const gf64_ptr g0 = AS_GLOBAL_F64(tk.T + (size_t)(16 * (J + 1 + w) + l15) + (size_t)(16 * J + l4) * tk.ld);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d0[(l4 + 4 * r) * PLD + l15] = acc0[r];
+                    g0[(size_t)(4 * r) * tk.ld] = acc0[r];
+                }
+                if (two) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        d1[(l4 + 4 * r) * PLD + l15] = acc1[r];
+                        g0[(size_t)(4 * r) * tk.ld + 64] = acc1[r];
+                    }
+                }
             }
             // z_J = L_JJ^-1 w_J (w_J had its last update in P2 of step J - 1; the slot's upper part is zero)
             if (fuse && w == 3 && lane < 16) {
@@ -1820,13 +1802,20 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
                 zl[16 * J + lane] = sum;
             }
         }
-        __syncthreads();
+        lds_barrier();
         stamp(3 + 2 * J);
         const int m = 7 - J;
         if (w == 0) {
-            if (m > 0) {
-                const BlkOp o = op_trailing(J, J + 1, J + 1);
-                run_pair(o, o, false, true);
+            if (m > 0) {   // S(J+1,J+1) -= S(J+1,J) S(J+1,J)^T, then its factorisation: the chain every block step waits for
+                {
+                    double fa[4], c[4];
+                    double* dst = S + off(J + 1, J + 1);
+                    frag(S + off(J + 1, J), fa);
+                    frag(dst, c);
+                    const d4 acc = mma4(fa, fa);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(l4 + 4 * r) * PLD + l15] = c[r] - acc[r];
+                }
                 unsigned long long cyc0 = 0;
                 if (J == 3) {
                     stamp(21);
@@ -1841,15 +1830,39 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
                 }
             }
         } else {
-            const int total = DIAG_TASKS.ntrail[J];
-            auto op_p2 = [&](int task) {
-                const int e = __builtin_amdgcn_readlane(mytask, task);
-                return op_trailing(J, (e >> 4) & 15, e & 15);
+            // trailing products S(I,K) -= S(I,J) S(K,J)^T, I >= K > J, two at a time (independent chains interleave on the
+            // matrix pipe).  Task list: the blocks (I,K) column by column from the LAST column backwards -- column K has 8 - K
+            // blocks whatever the step, so the list of step J is the first (7-J)(8-J)/2 entries of one fixed list (lane l keeps
+            // entry l, set up before the loop: no table in memory).  (J+1,J+1) -- the first block of the last column of the
+            // step -- is wave 0's; the others go round-robin over waves 1..3.
+            const int total = (7 - J) * (8 - J) / 2, own0 = total - (7 - J);
+            auto block_of = [&](int p, const double*& pa, const double*& pb) {      // position p among the others
+                const int e = __builtin_amdgcn_readlane(mytask, p < own0 ? p : p + 1);
+                const int I = (e >> 4) & 15, K = e & 15;
+                pa = S + off(K, J);
+                pb = S + off(I, J);
+                return S + off(I, K);
             };
-            for (int task = 1 + (w - 1); task < total; task += 6) {
-                const bool two = task + 3 < total;
-                const BlkOp o0 = op_p2(task);
-                run_pair(o0, two ? op_p2(task + 3) : o0, two, true);
+            for (int p = w - 1; p < total - 1; p += 6) {
+                const bool two = p + 3 < total - 1;
+                const double *pa0, *pb0, *pa1, *pb1;
+                double* d0 = block_of(p, pa0, pb0);
+                double* d1 = block_of(two ? p + 3 : p, pa1, pb1);
+                double fa[4], fb[4], c0[4], ga[4], gb[4], c1[4];
+                frag(pa0, fa);
+                frag(pb0, fb);
+                frag(pa1, ga);
+                frag(pb1, gb);
+                frag(d0, c0);
+                frag(d1, c1);
+                d4 acc0 = zero4, acc1 = zero4;
+                mma4x2(fa, fb, acc0, ga, gb, acc1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d0[(l4 + 4 * r) * PLD + l15] = c0[r] - acc0[r];
+                if (two) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d1[(l4 + 4 * r) * PLD + l15] = c1[r] - acc1[r];
+                }
             }
             // w_I -= L(I,J) z_J for the rows below block J, one row per thread of the waves 1..3
             const int row = 16 * (J + 1) + 64 * (w - 1) + lane;      // (w = role 1..3: 192 threads for at most 112 rows)
@@ -1861,7 +1874,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
                 wl[row] -= sum;
             }
         }
-        __syncthreads();
+        lds_barrier();
         stamp(4 + 2 * J);
     }
     bad = __shfl(bad, 0);
@@ -1881,31 +1894,13 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
             }
         }
     }
-    // ---- off-diagonal blocks of L -> tile, zeros above the diagonal (diagonal blocks were written by diag_block);
-    //      the same sweep zeroes the upper blocks of Dinv.  16 of the 64 blocks per wave.
-    {
-        const int bc = lane >> 2, br = 4 * (lane & 3);
-        const d2 zero = {0.0, 0.0};
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int b = w + 4 * q, I = b >> 3, K = b & 7;
-            if (I == K) continue;
-            double* gT = tk.T + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * tk.ld;
-            if (I > K) {
-                const double* src = S + off(I, K) + bc * PLD + br;
-                *reinterpret_cast<d2*>(gT) = *reinterpret_cast<const d2*>(src);
-                *reinterpret_cast<d2*>(gT + 2) = *reinterpret_cast<const d2*>(src + 2);
-            } else {
-                double* gD = tk.Dinv + (size_t)(16 * I + br) + (size_t)(16 * K + bc) * TB;
-                *reinterpret_cast<d2*>(gT) = zero;
-                *reinterpret_cast<d2*>(gT + 2) = zero;
-                *reinterpret_cast<d2*>(gD) = zero;
-                *reinterpret_cast<d2*>(gD + 2) = zero;
-            }
-        }
-    }
     stamp(19);
-    // ---- phase 2: L^-1, two block columns per wave, blocks in registers, no barrier (the image is only read)
+    // ---- phase 2: L^-1 = X, block column by block column WITHOUT barriers: X(K,K) = L_KK^-1 is in the image, and
+    //      X(I,K) = -L_II^-1 sum_{J=K..I-1} L(I,J) X(J,K) depends on the same column's earlier blocks only.  Wave w takes the
+    //      columns K = w and 7 - w and keeps its X blocks in registers: a 16x16 result in accumulator layout is the B operand
+    //      of the next product as it stands (register q = k-slab q), so the image is only read (blocks of L as A operands)
+    //      and every finished block goes straight to Dinv.  The sum runs on two accumulators (even and odd J): a dependent
+    //      f64 MFMA waits ~100 cycles for its predecessor where an independent one issues after 64.
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         const int K = half ? 7 - w : w;
@@ -1913,30 +1908,31 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
         d4 xr[8];
         {   // X(K,K) = L_KK^-1 into accumulator layout: a product with the identity (reading it lane-per-column
             // from the image would be a 8-way bank conflict)
-            const double* lk = S + off(K, K);
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            double lk[4], id[4];
+            frag(S + off(K, K), lk);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lk[(4 * q + l4) * PLD + l15], (l15 == 4 * q + l4) ? 1.0 : 0.0, acc, 0, 0, 0);
-            xr[0] = acc;
+            for (int q = 0; q < 4; ++q) id[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
+            xr[0] = mma4(lk, id);
         }
 #pragma unroll
         for (int i = 1; i <= 7; ++i) {
             if (i > m) break;
             const int I = K + i;
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            d4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
-            for (int s2 = 0; s2 < i; ++s2) {     // sum_J L(I,J) X(J,K): X(J,K) register q is the operand's k-slab q
-                const double* lb = S + off(I, K + s2);
+            for (int s2 = 0; s2 < i; ++s2) {     // sum_J L(I,J) X(J,K)
+                double lb[4];
+                frag(S + off(I, K + s2), lb);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[(4 * q + l4) * PLD + l15], xr[s2][q], acc, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    if (s2 & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[q], xr[s2][q], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[q], xr[s2][q], acc0, 0, 0, 0);
+                }
             }
-            const double* li = S + off(I, I);
-            d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(li[(4 * q + l4) * PLD + l15], acc[q], x, 0, 0, 0);
-            xr[i] = -x;
+            const d4 acc = acc0 + acc1;
+            double li[4], ta[4] = {acc[0], acc[1], acc[2], acc[3]};
+            frag(S + off(I, I), li);
+            xr[i] = -mma4(li, ta);
             // register r holds X(row 16 I + l4 + 4 r, column 16 K + l15)
             const gf64_ptr gD = AS_GLOBAL_F64(tk.Dinv + (size_t)(16 * I + l4) + (size_t)(16 * K + l15) * TB);
 #pragma unroll
@@ -1947,13 +1943,13 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
     if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
 }
 
-__global__ __launch_bounds__(256) void chol_diag_packed_kernel(const DiagTask* __restrict__ tasks) {
+__global__ __launch_bounds__(256, 2) void chol_diag_packed_kernel(const DiagTask* __restrict__ tasks) {
     extern __shared__ __attribute__((aligned(16))) double S[];   // image [64 cols][PLD rows] + rhs[128] + z[128] + int off[64]
     const DiagTask tk = tasks[blockIdx.x];
     chol_diag_packed_body(tk, S, false);
 }
 #ifdef DSMGP_DIAG
-__global__ __launch_bounds__(256) void chol_diag_packed_stamp_kernel(const DiagTask* __restrict__ tasks, unsigned long long* stamps) {
+__global__ __launch_bounds__(256, 2) void chol_diag_packed_stamp_kernel(const DiagTask* __restrict__ tasks, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double S[];
     const DiagTask tk = tasks[blockIdx.x];
     chol_diag_packed_body<true>(tk, S, false, stamps + 24 * blockIdx.x);
