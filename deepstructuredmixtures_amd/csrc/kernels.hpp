@@ -1567,22 +1567,32 @@ __device__ __forceinline__ int potrf_inv16_mfma(d4 m, d4& lt, d4& xinv, int lane
 // ---------------------------------------------------------------------------------------------
 // The diagonal-block kernel: blocked right-looking Cholesky of one 128x128 tile on 16x16 sub-blocks in a 75 KB LDS image,
 // so TWO workgroups fit a CU (and one fits next to a tile workgroup).  Per block step J:
-//   P0  wave 0: potrf + inverse of the 16x16 diagonal block in registers (potrf_inv16: lanes 0..15 a column of the block,
-//       lanes 16..31 a column of the identity), cross-lane traffic by v_readlane broadcasts (no LDS, no barrier inside);
-//       for J > 0 it runs inside P2 of step J-1, right after wave 0 has updated that block
-//   P1  all waves: panel S(I,J) = S(I,J) Linv^T (I > J)                                          [MFMA]
+//   P0  wave 0: potrf + inverse of the 16x16 diagonal block on the matrix pipe (potrf_inv16_mfma: four pivots at a time,
+//       rank-4 MFMA updates, everything in accumulator layout; no LDS, no barrier inside); for J > 0 it runs inside P2 of
+//       step J-1, right after wave 0 has updated that block
+//   P1  all waves: panel S(I,J) = S(I,J) Linv^T (I > J); the result goes to the image AND, being final, from the
+//       accumulators straight to the tile in global memory                                       [MFMA]
 //   P2  waves 1..3: trailing S(I,K) -= S(I,J) S(K,J)^T (I >= K > J)                              [MFMA, two independent
 //       16x16 products in flight per wave]
+// Measured on one block (tools/probe_diag.py, wall-clock stamps in the diagnostic build), round 3: 46.1 us at the start
+// (diagonal 16x16 blocks 3.1 us each in a column-per-lane form with a v_readlane pair per row and pivot -- 870 VALU
+// instructions, and a wave alone on its SIMD issues one dependent instruction per ~8 cycles --, panel products 0.65,
+// write-back 3.4, inverse phase 6.7) -> 34.4 us: diagonal blocks 1.75 us (MFMA form), the blocks known to be zero written
+// at the START from all waves (the upper blocks of Dinv not at all: the arena is zeroed once), L blocks stored by P1 from
+// its accumulators, whole-line block moves, barriers that wait for the LDS only (__syncthreads() also waits for the global
+// stores in flight).  One wave issues an f64 MFMA about every 100 cycles whether or not it depends on the last one, so the
+// inverse phase (148 MFMAs on wave 0) stays at 6.3 us.  Folding that phase into the slack waves 1..3 have in P2 (rows of
+// L^-1 computed step by step, written into the slots of the L blocks they replace, a mirrored L_JJ^-1 in the diagonal slots
+// for conflict-free operand reads) was built and measured: correct, but 41.6 us a block and 262 against 226 us for 2048
+// blocks -- the bookkeeping costs more instructions than the overlap wins: not kept.
 // Until round 3 a second, "latency" form of this kernel (L and L^-1 side by side in a 147 KB image: one workgroup per CU, the
-// inverse accumulated by forward substitution on the identity during the factorisation) served the launches with fewer
-// blocks than CUs.  With the inverse phase below barrier-free the packed form is the faster one there too (a launch of
-// 144 blocks: 52.3 against 55.0 us, same box), has no LDS bank conflicts where the other had 42 % (its inverse blocks were
-// read lane-per-column), and can share a CU with a tile workgroup: the latency form is gone.
+// inverse accumulated by forward substitution on the identity during the factorisation, 42 % LDS bank conflicts) served the
+// launches with fewer blocks than CUs; the packed form overtook it (a launch of 144 blocks: 52.3 against 55.0 us before
+// today's work, 41.3 us after) and it is gone.
 //   image : the 36 lower 16x16 blocks in a 9 x 4 block rectangle (PLD = 144 rows, 64 columns): block (I,K) with
 //           K < 4 at block position (I, K); the ten blocks with K >= 4 fill the six free positions above the
 //           diagonal of the first four block columns and the ninth block row (PackedMap)
-//   phase 1: blocked right-looking Cholesky exactly as above (potrf_inv16 on wave 0 with lookahead, panel products,
-//           trailing products) without the inverse products.  L_JJ goes from registers straight to the tile in global
+//   phase 1: blocked right-looking Cholesky exactly as above.  L_JJ goes from registers straight to the tile in global
 //           memory; its slot in the image keeps L_JJ^-1 (operand of the panel products and of phase 2)
 //           The forward substitution z = L_kk^-1 w_k rides along: z_J = L_JJ^-1 w_J in P1 (one wave, 16 lanes), then
 //           w_I -= L(I,J) z_J for the rows below in P2 (waves 1..3, one row per thread): no inverse is needed for it
@@ -1591,8 +1601,7 @@ __device__ __forceinline__ int potrf_inv16_mfma(d4 m, d4& lt, d4& xinv, int lane
 //           the columns K = w and 7 - w (37, 31, 27 and 25 block products) and keeps its X blocks in REGISTERS: a 16x16
 //           result in accumulator layout is the second operand of the next product as it stands (register r = rows
 //           4r..4r+3 of the block = the operand's k-slab r), so the image is only read (blocks of L, conflict-free
-//           column reads) and every finished block goes straight to Dinv in global memory.  35 of the kernel's 88 us
-//           were this phase in its barrier-per-column form (two barriers and a round trip through the image per column).
+//           column reads) and every finished block goes straight to Dinv in global memory.
 constexpr int PLD = 144;
 constexpr int PIMG = 64 * PLD;
 constexpr int DIAGP_LDS_BYTES = (PIMG + 2 * TB + 64) * (int)sizeof(double);   // image + rhs block + z + block-offset table
