@@ -81,7 +81,9 @@ def default_sub(world):
     """Concurrent contexts per GPU (hipabi.MultiContext): with the leaves of a multi-GPU shard split over 2-3 contexts
     driven from host threads, one context's dependent chain of diagonal block / panel solve / reduce launches runs
     under another's update launches (measured on one GPU with --simulate-shard: 8 ranks 0.0651 -> 0.0614 s with 3,
-    4 ranks 0.1159 -> 0.1129 s with 2, 2 ranks 0.2176 -> 0.2137 s with 2; nothing to gain on a full GPU)."""
+    4 ranks 0.1159 -> 0.1129 s with 2, 2 ranks 0.2176 -> 0.2137 s with 2).  On a full GPU two contexts measure -1.4 % on
+    the headline step and -2.7 % at depth 4 since round 3, but N = 1 stays at one context: with two
+    contexts' kernels sharing the chip the per-launch duration behind `roofline` is no longer a property of the kernel."""
     return 3 if world >= 8 else (2 if world >= 2 else 1)
 
 

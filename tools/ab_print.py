@@ -9,6 +9,6 @@ for f in sorted(glob.glob("gpurun_out/ab_*.json")):
         print(f, "unreadable:", e)
         continue
     c = d["device_seconds_per_step"]
-    keys = ("gram", "chol_update", "chol_reduce", "chol_diag", "chol_trsm", "total_fit")
+    keys = ("gram", "chol_update", "chol_fused", "chol_reduce", "chol_diag", "chol_trsm", "total_fit")
     print(f, round(d["value"], 4), "frac", round(d["roofline"]["frac"], 4),
           {k: round(v * 1e3, 2) for k, v in c.items() if k in keys}, d.get("root_mll"))
