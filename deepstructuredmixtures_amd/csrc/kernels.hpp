@@ -1913,7 +1913,8 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         const int K = half ? 7 - w : w;
-        const int m = 7 - K;
+        if (K >= JN) continue;      // identity padding: the diagonal block is written above, everything below it is zero
+        const int m = (JN < 8 ? JN - 1 : 7) - K;     // rows I >= JN of the column are zero (and stay so in the zeroed arena)
         d4 xr[8];
         {   // X(K,K) = L_KK^-1 into accumulator layout: a product with the identity (reading it lane-per-column
             // from the image would be a 8-way bank conflict)
