@@ -78,13 +78,17 @@ def build_model(cfg, rank, world, device, n_sub=1):
 
 
 def default_sub(world):
-    """Concurrent contexts per GPU (hipabi.MultiContext): with the leaves of a multi-GPU shard split over 2-3 contexts
-    driven from host threads, one context's dependent chain of diagonal block / panel solve / reduce launches runs
-    under another's update launches (measured on one GPU with --simulate-shard: 8 ranks 0.0651 -> 0.0614 s with 3,
-    4 ranks 0.1159 -> 0.1129 s with 2, 2 ranks 0.2176 -> 0.2137 s with 2).  On a full GPU two contexts measure -1.4 % on
-    the headline step and -2.7 % at depth 4 since round 3, but N = 1 stays at one context: with two
-    contexts' kernels sharing the chip the per-launch duration behind `roofline` is no longer a property of the kernel."""
-    return 3 if world >= 8 else (2 if world >= 2 else 1)
+    """Concurrent contexts per GPU (hipabi.MultiContext: the leaves of this rank split over several contexts driven from
+    host threads, so that one context's dependent chain of diagonal block / panel solve / reduce launches runs under
+    another's update launches).  ONE since round 3, at every world size: with the chain itself shortened (diagonal-block
+    launch 51 -> 35 us, fused shallow steps) extra contexts no longer pay on the shards of a multi-GPU job -- one shard at
+    a time on one GPU, same box, 1 / 2 / 3 contexts: 2 ranks 0.1996 / 0.1979 / 0.2054 s, 4 ranks 0.1051 / 0.1067 / 0.1142
+    and 0.1062 / 0.1072 / 0.1144, 8 ranks 0.0582 / 0.0638 / 0.0646 and 0.0593 / 0.0581 / 0.0635 (round 2 ran 8 ranks with
+    3, 4 and 2 ranks with 2 contexts: 0.0651 -> 0.0614 s then) -- and with one context per GPU the exchange of a `nccl` job
+    stays on the device (dist.Shard.device_comm).  On a full GPU two contexts measure -1.4 % on the headline step and
+    -2.7 % at depth 4; N = 1 stays at one too: with two contexts' kernels sharing the chip the per-launch
+    duration behind `roofline` is no longer a property of the kernel.  --sub N overrides."""
+    return 1
 
 
 def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
