@@ -3072,8 +3072,25 @@ struct RcclApi {
     std::string err;
     bool load() {
         if (lib) return true;
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // First choice: the librccl that sits NEXT TO the HIP runtime this library is bound to.  A process can hold two
+        // ROCm runtimes -- the system's, and the one a PyTorch wheel bundles and maps under the plain names "librccl.so" /
+        // "libamdhip64.so" -- and only the first of them to initialise owns the GPU.  dlopen("librccl.so") returns whichever
+        // copy is already mapped under that name: with this library loaded first and torch imported later that was torch's
+        // librccl on top of torch's never-initialised runtime, and ncclCommInitRank failed with 'no ROCm-capable device is
+        // detected'.  (Loaded after torch, this library binds to torch's runtime by SONAME and the first choice IS torch's copy.)
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &di) && di.dli_fname) {
+            const std::string f(di.dli_fname);
+            const size_t p = f.rfind('/');
+            if (p != std::string::npos) {
+                names.push_back(f.substr(0, p + 1) + "librccl.so.1");
+                names.push_back(f.substr(0, p + 1) + "librccl.so");
+            }
+        }
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) names.push_back(n);
+        for (const std::string& name : names) {
+            lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
         }
         if (!lib) {
