@@ -1599,3 +1599,25 @@ def test_lookahead_schedule_agrees_with_the_classic_steps(ctx, kind):
         mo, vo = g.prediction(Xt[ridx[rptr[j]:rptr[j + 1]]])
         assert np.allclose(a[1][rptr[j]:rptr[j + 1]], mo, rtol=RTOL, atol=1e-9)
         assert np.allclose(a[2][rptr[j]:rptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
+
+
+@pytest.mark.parametrize("order", ["none", "import", "first"])
+def test_rccl_communicator_comes_up_in_every_import_order(order):
+    """A PyTorch wheel bundles its own ROCm runtime; a process holds one or two runtimes depending on who came first, and
+    the library's RCCL loader must pick the librccl of the runtime the library is bound to.  Child processes:
+    no torch at all; the library first and torch imported afterwards (two runtimes: the system's owns the GPU, RCCL must be
+    the system's); torch.cuda first (the order of every torch.distributed job: the library binds to torch's runtime by
+    SONAME, ONE libamdhip64 in the process, torch keeps working)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_rccl_maps.py"), order], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "comm_init ok: [[0. 1. 2.]]" in r.stdout, r.stdout[-2000:]
+    end = [ln for ln in r.stdout.splitlines() if ln.startswith("at the end:")][-1]
+    if order == "first":
+        assert "torch still works: 8.0" in r.stdout
+        assert end.count("libamdhip64") == 1 and "/opt/rocm" not in end, end
+    elif order == "none":
+        assert "torch/lib" not in end
