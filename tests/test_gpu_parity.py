@@ -176,7 +176,12 @@ def test_first_bad_minor_is_reported_exactly(ctx):
     (1-based), inside the first 128-block and, with D = 131 orthogonal directions, at row 131 of the second block (the
     blocked path: panel solve, update of the next diagonal tile, global row offset of the block)."""
     import scipy.linalg as sla
-    for D, n, rep in ((3, 140, 3), (131, 140, 130)):
+    # the two cases of round 3's first version, then one case per place a pivot can sit in since the diagonal 16x16 blocks
+    # are eliminated four pivots at a time on the matrix pipe: every position inside a group of four, first and last group of
+    # a 16x16 block, first / inner / last 16x16 block of a tile, first and second row of the second and third tile
+    cases = [(3, 140, 3), (131, 140, 130)] + [(rep + 1, 300, rep) for rep in (1, 2, 4, 5, 6, 7, 12, 15, 16, 19, 47, 62, 64, 111,
+                                                                               126, 127, 128, 129, 143, 200, 255, 256, 257, 299)]
+    for D, n, rep in cases:
         X = np.zeros((n, D))
         for i in range(min(n, D)):
             X[i, i] = 2.0 ** 27
