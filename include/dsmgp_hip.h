@@ -149,15 +149,17 @@ int dsmgp_gradients(dsmgp_ctx* ctx, double* grad_out, int32_t stride);
  * memory first.  Changing it discards the leaf plan and a registered test set: set it before dsmgp_set_test. */
 #define DSMGP_OPT_FUSED_GRAM 2
 /* DSMGP_OPT_FUSED_STEPS: 1 (default) = a block step of the factorisation whose diagonal blocks alone fill the chip (more
- * leaves in the step than CUs: depth >= 3 trees, large PoE models), and every shallow step (K <= 512), runs as two launches -- the diagonal block's task also
- * updates its tile, the tasks of the tiles below update AND solve them, each tile written once (the per-step order of
- * src/AdvancedCholeskey.jl:161-171, batched over leaves); 0 = every step as update / diagonal block / panel solve
- * launches.  Same arithmetic in the same order: bit-identical results.  Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing
- * it discards the leaf plan and a registered test set. */
+ * leaves in the step than CUs: depth >= 3 trees, large PoE models), and every shallow step (K <= 512), runs as two
+ * launches -- the diagonal block's task also updates its tile, the tasks of the tiles below update AND solve them, each
+ * tile written once (the per-step order of src/AdvancedCholeskey.jl:161-171, batched over leaves); 0 = every step as
+ * update / diagonal block / panel solve launches.  Diagonal blocks come out bit-identical either way; the tiles below
+ * agree to rounding (a fused task accumulates the product on -k(row, col) where the classic update subtracts the finished
+ * product from k(row, col)).  Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing it discards the leaf plan and a registered
+ * test set. */
 #define DSMGP_OPT_FUSED_STEPS 3
 /* DSMGP_OPT_LOOKAHEAD: 1 = the block steps that are not fused (few leaves, deep K: the headline regime) run on a
- * lookahead schedule (default 0: measured slower on one GPU): the update of step k is cut at its last block column; the bulk runs on the context's stream as
- * soon as step k - 2 is final, the rest -- rank-128 update + factorisation of the diagonal block, rank-128 update + solve
+ * lookahead schedule (default 0: measured slower on one GPU): the update of step k is cut at its
+ * last block column; the bulk runs on the context's stream as soon as step k - 2 is final, the rest -- rank-128 update + factorisation of the diagonal block, rank-128 update + solve
  * of the tiles below -- on a second stream beside the bulk of step k + 1, so the dependent chain diagonal block ->
  * panel solve no longer sits between two update launches.  0 = update / reduce / diagonal block / panel solve launches
  * one after the other.  Results agree to rounding (one addition per entry changes place).  Needs DSMGP_OPT_FUSED_GRAM. */
