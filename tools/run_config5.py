@@ -32,8 +32,10 @@ if args.train:                        # one train! iteration: fit + gradients pe
     t0 = time.perf_counter()
     dsm.train(model, dsm.ADAM(), iterations=1)
     out["train_1_iteration_plus_final_fit_s"] = time.perf_counter() - t0
-    out["passes"] = model.ctx.passes
-    out["groups"] = [int(len(g)) for g in model.ctx.groups]
+    print(f"# train: {out['train_1_iteration_plus_final_fit_s']:.1f} s", flush=True)
+    out["passes"] = getattr(model.ctx, "passes", None)
+    g_ = getattr(model.ctx, "groups", None)     # (train() restores the plain streaming context when it is done)
+    out["groups"] = [int(len(g)) for g in g_] if g_ is not None else None
     out["root_mll"] = dsm.update(model)
     print(json.dumps(out))
     sys.exit(0)
