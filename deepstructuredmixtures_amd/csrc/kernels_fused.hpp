@@ -67,7 +67,7 @@ struct DiagFusedTask {
 struct RowsplitPrefetch {
     d2 ra0[2], rb0[2], ra1[2], rb1[2];
 };
-template <int NRW>
+template <int NRW, int NCB = 8>
 __device__ __forceinline__ void rowsplit_prefetch(const double* A, int lda, const double* B, int ldb, int K, RowsplitPrefetch& pf) {
     const int t = threadIdx.x;
     const int nch = K / KC2;
@@ -79,27 +79,28 @@ __device__ __forceinline__ void rowsplit_prefetch(const double* A, int lda, cons
     pf.ra0[0] = *AS_GLOBAL_D2(gA);
     if (NRW > 1) pf.ra0[1] = *AS_GLOBAL_D2(gA + 64);
     pf.rb0[0] = *AS_GLOBAL_D2(gB);
-    pf.rb0[1] = *AS_GLOBAL_D2(gB + 64);
+    if (NCB > 4) pf.rb0[1] = *AS_GLOBAL_D2(gB + 64);
     pf.ra1[0] = *AS_GLOBAL_D2(gA + o1a);
     if (NRW > 1) pf.ra1[1] = *AS_GLOBAL_D2(gA + o1a + 64);
     pf.rb1[0] = *AS_GLOBAL_D2(gB + o1b);
-    pf.rb1[1] = *AS_GLOBAL_D2(gB + o1b + 64);
+    if (NCB > 4) pf.rb1[1] = *AS_GLOBAL_D2(gB + o1b + 64);
 }
 
-template <int NRW>
+template <int NRW, int NCB = 8>
 __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda, const double* B, int ldb, int K,
-                                                       d4 (&acc)[8][NRW], double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
+                                                       d4 (&acc)[NCB][NRW], double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
                                                        const RowsplitPrefetch& pf) {
     // acc comes in initialised by the caller (-K(i,k): rowsplit_gram_init) and goes out as acc + A B^T
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    constexpr bool AHI = NRW > 1;
-    constexpr int NMEM_G = AHI ? 4 : 3;
-    constexpr int NFRAG = (8 + NRW + 1) / 2;
-    constexpr int NMFMA = 8 * NRW;
-    constexpr int NI_A = NMEM_G;
+    constexpr bool AHI = NRW > 1;       // rows 64.. of the A panel are staged
+    constexpr bool BHI = NCB > 4;       // rows 64.. of the B panel (= columns 64.. of the tile) are staged
+    constexpr int NMEM_G = (AHI ? 2 : 1) + (BHI ? 2 : 1);
+    constexpr int NFRAG = (NCB + NRW + 1) / 2;
+    constexpr int NMFMA = NCB * NRW;
+    constexpr int NI_A = NMEM_G < NMFMA ? NMEM_G : NMFMA;
     constexpr int NI_B = (NMFMA - NI_A) < NFRAG ? (NMFMA - NI_A) : NFRAG;
     constexpr int NI_REST = NMFMA - NI_A - NI_B;
     const int scol = t >> 5, srow = 2 * (t & 31);
@@ -121,25 +122,25 @@ __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda,
         RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
         if (AHI) RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                           \
         RB[0] = *AS_GLOBAL_D2(gB + ob_);                                                         \
-        RB[1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                                    \
+        if (BHI) RB[1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                           \
     } while (0)
 #define FSWRITE(RA, RB, BUF)                                                                     \
     do {                                                                                         \
         *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA[0];                                          \
         if (AHI) *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                            \
         *reinterpret_cast<d2*>(&sB[BUF][sOff]) = RB[0];                                          \
-        *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = RB[1];                                     \
+        if (BHI) *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = RB[1];                            \
     } while (0)
 #define FFRAGS(FA, FB, BUF, G)                                                                   \
     do {                                                                                         \
         const double* pa_ = &sB[BUF][((G) * 4 + l4) * LDP + l15];                                \
         const double* pb_ = &sA[BUF][((G) * 4 + l4) * LDP + rowoff];                             \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) FA[i_] = pa_[16 * i_];                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NCB; ++i_) FA[i_] = pa_[16 * i_];                \
         _Pragma("unroll") for (int i_ = 0; i_ < NRW; ++i_) FB[i_] = pb_[16 * i_];                \
     } while (0)
 #define FMFMA(FA, FB)                                                                            \
     do {                                                                                         \
-        _Pragma("unroll") for (int cb_ = 0; cb_ < 8; ++cb_)                                      \
+        _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_)                                    \
             _Pragma("unroll") for (int rn_ = 0; rn_ < NRW; ++rn_)                                \
                 acc[cb_][rn_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[cb_], FB[rn_], acc[cb_][rn_], 0, 0, 0); \
     } while (0)
@@ -164,7 +165,7 @@ __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda,
         FSWRITE(ra0, rb0, 2);
     }
     __syncthreads();
-    double fa0[8], fb0[NRW], fa1[8], fb1[NRW];
+    double fa0[NCB], fb0[NRW], fa1[NCB], fb1[NRW];
     if (nch > 0) FFRAGS(fa0, fb0, 0, 0);
 #define FCHUNK(C, LRA, LRB, WRA, WRB)                                                            \
     do {                                                                                         \
@@ -223,18 +224,18 @@ static_assert(lower_block_base(7) == 0 && lower_block_base(6) == 8 && lower_bloc
 // gram_finish): the values the Gram launch would have written, negated.  The product is then accumulated ON it, so the
 // task starts with the kernel function -- under the memory latency of its first operand loads, with the accumulators not
 // yet live -- and the accumulators end as -(K - A B^T) = -C.
-template <int KIND, int NRW>
-__device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KParam& p, int D, d4 (&acc)[8][NRW], const double* sa,
+template <int KIND, int NRW, int NCB = 8>
+__device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KParam& p, int D, d4 (&acc)[NCB][NRW], const double* sa,
                                                       const double* sb) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     const int rowbase = 16 * NRW * w + l15;
     const double* pa = sa + rowbase;
-    constexpr int CG = (NRW == 1) ? 2 : 1;      // column blocks per pass: 8 entries per lane and pass either way
+    constexpr int CG = (NRW == 1 && NCB >= 2) ? 2 : 1;      // column blocks per pass: 8 entries per lane and pass where possible
     constexpr int NJ = 4 * CG;
 #pragma unroll
-    for (int cp = 0; cp < 8 / CG; ++cp) {
+    for (int cp = 0; cp < NCB / CG; ++cp) {
         const double* pb = sb + 16 * CG * cp + l4;
         double z[NRW][NJ];
 #pragma unroll
@@ -260,31 +261,39 @@ __device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KP
     }
 }
 
-template <int NRW>
+// NCB = number of 16-column blocks of the tile that hold data (8, or 4 / 2 / 1 for a tile in the LAST block column of a leaf with
+// at most 64 / 32 / 16 valid columns: the test-row tile of every leaf's last block step, and 43 % of the matrix work of a PoE of
+// 391-row experts).  Columns beyond are padding -- K is zero there, the padding rows of the B panel are zero, Dinv_k is the
+// identity there -- so X is exactly zero in them: they are neither accumulated, nor evaluated, nor solved, only stored as zeros;
+// rows 64.. of the B panel are not staged and only the block rows of Dinv_k below NCB are fetched.
+template <int NRW, int NCB>
 __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
                                                 const KParam* __restrict__ kp, int D) {
+    static_assert(NCB == 8 || NCB == 4 || NCB == 2 || NCB == 1, "column-block classes");
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    // Dinv_k's 36 lower blocks go global (L2: the diagonal-block launch of this step wrote them) -> registers -> LDS in two
-    // halves of 9 loads per thread, both issued when the product is done: the second lands under the first two block
-    // columns of the solve.  (Issuing the first half before the product, held in registers across it, measured the same:
-    // depth 4 0.0584 / 0.0598 / 0.0589 without against 0.0625 / 0.0596 / 0.0586 s with, same box, alternating.)
-    // Thread t moves the doubles 2 (t & 127), + 1 of block 2 e + (t >> 7).
+    // Dinv_k's lower blocks of the block rows < NCB (all 36 for NCB = 8) go global (L2: the diagonal-block launch of this
+    // step wrote them) -> registers -> LDS; for NCB = 8 in two halves of 9 loads per thread, both issued when the product
+    // is done: the second lands under the first two block columns of the solve.  (Issuing the first half before the
+    // product, held in registers across it, measured the same: depth 4 0.0584 / 0.0598 / 0.0589 without against 0.0625 /
+    // 0.0596 / 0.0586 s with, same box, alternating.)  Thread t moves the doubles 2 (t & 127), + 1 of block B0 + 2 e + (t >> 7).
+    constexpr int B0 = lower_block_base(NCB - 1);         // LOWER_BLOCKS lists the block rows from the last one up
+    constexpr int NBLK = 36 - B0, NE = (NBLK + 1) / 2;
     const int dj = (t & 127) >> 3, di = 2 * (t & 7), dhalf = __builtin_amdgcn_readfirstlane(t >> 7);
     auto dinv_load = [&](int e) {
-        const int b = 2 * e + dhalf;
+        const int b = min(B0 + 2 * e + dhalf, 35);
         const int cb = LOWER_BLOCKS.cb[b], jb = LOWER_BLOCKS.jb[b];
         return *AS_GLOBAL_D2(tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB);
     };
     RowsplitPrefetch pf;
-    rowsplit_prefetch<NRW>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, pf);
-    d4 acc[8][NRW];
-    if (tk.mem) {   // acc = the tile as the bulk update left it (-C over the earlier columns): 64 NRW loads in flight per lane
+    rowsplit_prefetch<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, pf);
+    d4 acc[NCB][NRW];
+    if (NCB == 8 && tk.mem) {   // acc = the tile as the bulk update left it (-C over the earlier columns): 64 NRW loads in flight per lane
         const unsigned lofs0 = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * q) * (size_t)tk.ldc);
@@ -301,56 +310,64 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
             sb[e] = (r < tk.gnb) ? tk.gxb[r + (size_t)d * tk.gldb] : 0.0;
         }
         __syncthreads();
-        if (p.kind == 0) rowsplit_gram_init<0, NRW>(tk, p, D, acc, sa, sb);
-        else if (p.kind == 1) rowsplit_gram_init<1, NRW>(tk, p, D, acc, sa, sb);
-        else rowsplit_gram_init<2, NRW>(tk, p, D, acc, sa, sb);
+        if (p.kind == 0) rowsplit_gram_init<0, NRW, NCB>(tk, p, D, acc, sa, sb);
+        else if (p.kind == 1) rowsplit_gram_init<1, NRW, NCB>(tk, p, D, acc, sa, sb);
+        else rowsplit_gram_init<2, NRW, NCB>(tk, p, D, acc, sa, sb);
         __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
     }
-    gemm_mainloop_rowsplit<NRW>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB, pf);   // acc = -C; ends on a barrier: the ring is free
-    double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256
-    d2 dv[9];
+    gemm_mainloop_rowsplit<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB, pf);   // acc = -C; ends on a barrier: the ring is free
+    double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256; block b sits at 256 b
+    constexpr int NE1 = (NCB == 8) ? 9 : NE;            // first stage (NCB = 8: block rows 7, 6 and three blocks of row 5)
+    d2 dv[NE1];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) dv[e] = dinv_load(e);
+    for (int e = 0; e < NE1; ++e) dv[e] = dinv_load(e);
     d2 dw[9];
+    if (NCB == 8) {
 #pragma unroll
-    for (int e = 0; e < 9; ++e) dw[e] = dinv_load(9 + e);
+        for (int e = 0; e < 9; ++e) dw[e] = dinv_load(9 + e);
+    }
 #pragma unroll
-    for (int e = 0; e < 9; ++e) *reinterpret_cast<d2*>(sD + (size_t)(2 * e + dhalf) * 256 + 2 * (t & 127)) = dv[e];
+    for (int e = 0; e < NE1; ++e)
+        if (B0 + 2 * e + dhalf < 36) *reinterpret_cast<d2*>(sD + (size_t)(B0 + 2 * e + dhalf) * 256 + 2 * (t & 127)) = dv[e];
     __syncthreads();
     // -X = (-C) Dinv_k^T, column blocks from the right: X(:, cb) = sum_{jb <= cb} C(:, jb) Dinv(cb, jb)^T reads the blocks of
     // C up to cb and is the last to read C(:, cb), whose registers it takes over.  The accumulators are the second operand
     // as they stand: register q of C(:, jb) holds the columns 16 jb + l4 + 4 q = the k-slab q of the product.
     auto solve_block_column = [&](auto cbc) {
         constexpr int cb = decltype(cbc)::value;
-        d4 x[NRW];
+        if constexpr (cb < NCB) {
+            d4 x[NRW];
 #pragma unroll
-        for (int rn = 0; rn < NRW; ++rn) x[rn] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int rn = 0; rn < NRW; ++rn) x[rn] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int jb = 0; jb <= cb; ++jb) {
-            const double* blk = sD + (lower_block_base(cb) + jb) * 256 + l15;
+            for (int jb = 0; jb <= cb; ++jb) {
+                const double* blk = sD + (lower_block_base(cb) + jb) * 256 + l15;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double a = blk[(4 * q + l4) * 16];
+                for (int q = 0; q < 4; ++q) {
+                    const double a = blk[(4 * q + l4) * 16];
 #pragma unroll
-                for (int rn = 0; rn < NRW; ++rn) x[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x[rn], 0, 0, 0);
+                    for (int rn = 0; rn < NRW; ++rn) x[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x[rn], 0, 0, 0);
+                }
             }
-        }
 #pragma unroll
-        for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = -x[rn];     // X itself from here on
-        __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later column blocks from piling up in registers
+            for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = -x[rn];     // X itself from here on
+            __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later column blocks from piling up in registers
+        }
     };
     solve_block_column(std::integral_constant<int, 7>{});
     solve_block_column(std::integral_constant<int, 6>{});
+    if (NCB == 8) {
 #pragma unroll
-    for (int e = 0; e < 9; ++e) *reinterpret_cast<d2*>(sD + (size_t)(2 * (9 + e) + dhalf) * 256 + 2 * (t & 127)) = dw[e];
-    __syncthreads();
+        for (int e = 0; e < 9; ++e) *reinterpret_cast<d2*>(sD + (size_t)(2 * (9 + e) + dhalf) * 256 + 2 * (t & 127)) = dw[e];
+        __syncthreads();
+    }
     solve_block_column(std::integral_constant<int, 5>{});
     solve_block_column(std::integral_constant<int, 4>{});
     solve_block_column(std::integral_constant<int, 3>{});
     solve_block_column(std::integral_constant<int, 2>{});
     solve_block_column(std::integral_constant<int, 1>{});
     solve_block_column(std::integral_constant<int, 0>{});
-    // store: register q of acc[cb][rn] is X(row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q)
+    // store: register q of acc[cb][rn] is X(row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q); zeros beyond NCB
     const unsigned lofs = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
     const size_t ldc = (size_t)tk.ldc;
 #pragma unroll
@@ -359,7 +376,7 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
         for (int q = 0; q < 4; ++q) {
             const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * q) * ldc);
 #pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) col[lofs + 16 * rn] = acc[cb][rn][q];
+            for (int rn = 0; rn < NRW; ++rn) col[lofs + 16 * rn] = (cb < NCB) ? acc[cb < NCB ? cb : 0][rn][q] : 0.0;
             if (NRW == 1 && tk.zpad) col[lofs + 64] = 0.0;      // rows 64.. of a short tile of the factor: padding
         }
     if (tk.wi != nullptr) {     // riders, reduced inside the wave as in tile_trsm_kernel (same order: same bits)
@@ -367,7 +384,7 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
 #pragma unroll
         for (int rn = 0; rn < NRW; ++rn) p[rn] = q2[rn] = 0.0;
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double z = tk.zk[16 * cb + l4 + 4 * q];
@@ -406,8 +423,22 @@ __global__ __launch_bounds__(256, 2) void tile_fused_kernel(const FusedTask* __r
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
     double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem + NRING * KC2 * LDP);
     const FusedTask tk = tasks[blockIdx.x];
-    if (tk.mrows != 0 && tk.mrows <= 64) tile_fused_body<1>(tk, sA, sB, kp, D);
-    else tile_fused_body<2>(tk, sA, sB, kp, D);
+    const bool half = tk.mrows != 0 && tk.mrows <= 64;
+    // valid columns of the tile: fewer than 128 only in the last block column of a leaf (padding columns: X = 0 exactly)
+    const int ncb = tk.mem ? 8 : (tk.gnb + 15) >> 4;
+    if (ncb <= 1) {
+        if (half) tile_fused_body<1, 1>(tk, sA, sB, kp, D);
+        else tile_fused_body<2, 1>(tk, sA, sB, kp, D);
+    } else if (ncb <= 2) {
+        if (half) tile_fused_body<1, 2>(tk, sA, sB, kp, D);
+        else tile_fused_body<2, 2>(tk, sA, sB, kp, D);
+    } else if (ncb <= 4) {
+        if (half) tile_fused_body<1, 4>(tk, sA, sB, kp, D);
+        else tile_fused_body<2, 4>(tk, sA, sB, kp, D);
+    } else {
+        if (half) tile_fused_body<1, 8>(tk, sA, sB, kp, D);
+        else tile_fused_body<2, 8>(tk, sA, sB, kp, D);
+    }
 }
 
 // Gram values of a wave's 9 lower blocks of the diagonal tile, S = k - product in place (syrk_gram_epilogue without the
