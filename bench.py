@@ -275,8 +275,6 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
     ap.add_argument("--unfused-gram", action="store_true",
                     help="diagnostic: every Gram tile through memory first (DSMGP_OPT_FUSED_GRAM = 0), for A/B runs")
-    ap.add_argument("--lookahead", action="store_true",
-                    help="diagnostic: DSMGP_OPT_LOOKAHEAD = 1 (bulk update on the main stream, finish on a second one), for A/B runs")
     ap.add_argument("--no-fused-steps", action="store_true", help="diagnostic: DSMGP_OPT_FUSED_STEPS = 0, for A/B runs")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
@@ -341,19 +339,27 @@ def main():
     else:
         n_sub = args.sub if args.sub is not None else default_sub(world)
         model, X, y, Xt, ptr, idx = build_model(args.config, rank, world, local_rank, n_sub)
+    ctx_ok, ctx_err = 1, None
     try:
         ctx = model.ctx
-    except Exception as e:      # a sub-context failed to come up (several HIP contexts per GPU next to the process group):
-        if n_sub <= 1:          # fall back to one context per GPU and say so
+    except Exception as e:      # a sub-context failed to come up (several HIP contexts per GPU next to the process group)
+        if n_sub <= 1:
             raise
-        print(f"# rank {rank}: {n_sub} contexts per GPU failed ({e}); falling back to one", file=sys.stderr)
-        n_sub = 1
-        model._n_sub, model._ctx = 1, None
-        ctx = model.ctx
+        ctx_ok, ctx_err = 0, e
+    if n_sub > 1:               # fall back to one context per GPU on EVERY rank or on none: creating the single context may
+        if td is not None:      # enter a collective (the opt-in device exchange), which one rank alone must not do
+            flag = torch.tensor([ctx_ok], dtype=torch.int32,
+                                device="cuda" if td.get_backend() == "nccl" else "cpu")
+            td.all_reduce(flag, op=td.ReduceOp.MIN)
+            ctx_ok = int(flag.item())
+        if not ctx_ok:
+            print(f"# rank {rank}: {n_sub} contexts per GPU failed ({ctx_err or 'on another rank'}); falling back to one",
+                  file=sys.stderr)
+            n_sub = 1
+            model._n_sub, model._ctx = 1, None
+            ctx = model.ctx
     if args.unfused_gram:
         ctx.set_option(dsm.hipabi.OPT_FUSED_GRAM, 0)
-    if args.lookahead:
-        ctx.set_option(dsm.hipabi.OPT_LOOKAHEAD, 1)
     if args.no_fused_steps:
         ctx.set_option(dsm.hipabi.OPT_FUSED_STEPS, 0)
     if args.mode == "train":

@@ -65,8 +65,12 @@ struct HostLog {
     }
 };
 
-enum { STEP_CLASSIC = 0, STEP_FUSED = 1, STEP_LOOKAHEAD = 2 };
+enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 constexpr int FUSED_SHALLOW_STEPS = 4;   // block steps 0..4 (K <= 512) always run fused
+#ifndef DSMGP_DFIN_BACK
+#define DSMGP_DFIN_BACK (-1)             // < 0: the diagonal-block tasks of a full update launch go last; >= 0: that many rounds of
+                                         // whole tiles before its tail pieces (diagnostic builds: A/B of the placement)
+#endif
 
 struct StepLists {
     // one phase (wave) of factorisation: per block step k the tasks for update / split-K reduce / diag / trsm
@@ -78,9 +82,14 @@ struct StepLists {
     DevBuf<DiagTask> diag;
     // steps with more diagonal blocks than CUs run fused (kernels_fused.hpp): diag_fused_kernel, then tile_fused_kernel
     std::vector<int> fdiag_off, ftile_off;                   // size nsteps+1; a fused step has no classic tasks and vice versa
-    std::vector<char> mode;                                  // STEP_* per step (lookahead: upd/red hold the bulk, fdiag/ftile the finish)
+    std::vector<char> mode;                                  // STEP_* per step
     DevBuf<DiagFusedTask> fdiag;
     DevBuf<FusedTask> ftile;
+    // classic steps with the diagonal block INSIDE the update launch (DiagFinishTask, kernels_fused.hpp): the update launch of
+    // step k carries dfin[dfin_off[k] .. dfin_off[k+1]) behind its first dpos[k] tile tasks; a leaf whose diagonal block rides
+    // there has no `diag` task in that step
+    std::vector<int> dpos, dfin_off;                         // size nsteps / nsteps+1
+    DevBuf<DiagFinishTask> dfin;
     int nsteps = 0;
 };
 
@@ -161,6 +170,7 @@ struct UpdateSplitter {
     std::vector<TileTask> upd;
     std::vector<ReduceTask> red;
     std::vector<int64_t> upd_slab, red_slab;   // slab index of a task's output / first slab, -1 = none
+    size_t tail_begin = 0;                     // add_step: index in `upd` where the tail pieces of the last step begin (its end if none)
     size_t max_slabs = 0;
 
     static int choose_split(int T, int K, int ncu) {
@@ -202,9 +212,6 @@ struct UpdateSplitter {
             r.nsplit = S;
             // piece 0 stores product - Gram value, or the tile is defined as -product: nothing to read from it
             r.fresh = (tiles[i].gram != 0 || tiles[i].update == 2) ? 1 : 0;
-            // a whole-tile task with the Gram fused and update = 0 stores product - K (bulk tiles of the lookahead
-            // schedule, which the finish task takes as its accumulator start): split, the reduce must leave +sum of slabs
-            r.neg = (tiles[i].gram != 0 && tiles[i].update == 0) ? 1 : 0;
             red.push_back(r);
             red_slab.push_back((int64_t)(first + (i - from) * S));
         }
@@ -233,6 +240,7 @@ struct UpdateSplitter {
         const size_t T = tiles.size();
         size_t slab = 0;
         if ((int)T < ncu) {
+            tail_begin = upd.size();       // every tile is cut along K: one short round
             emit(tiles, 0, T, choose_split((int)T, K, ncu), slab);
         } else {
             // Whole tiles first, in rounds of one per CU; the tail of the launch -- the partial last round plus
@@ -250,6 +258,7 @@ struct UpdateSplitter {
             S = std::min(S, std::max(1, K / 256));
             if (S <= 1 || r == 0) ntail = 0;   // an exact multiple of the CU count already ends evenly
             emit(tiles, 0, T - ntail, 1, slab);
+            tail_begin = upd.size();
             if (ntail) emit(tiles, T - ntail, T, S, slab);
         }
         max_slabs = std::max(max_slabs, slab);
@@ -327,6 +336,7 @@ struct dsmgp_ctx {
     double* arenaVec = nullptr;     // per leaf: yc, w, z, alpha (4 x npad)
     double* arenaXg = nullptr;
     int* d_info = nullptr;
+    int* d_owner = nullptr;         // per leaf: the leaf whose factor (and info slot) it uses (dsmgp_fit_exchange packs info per owner)
     double* d_mll = nullptr;
     LeafDev* d_leaves = nullptr;
     std::vector<LeafDev> h_leaves;
@@ -335,18 +345,17 @@ struct dsmgp_ctx {
     DevBuf<GramTask> gram;          // Gram launch of fit!: every lower tile, or (fused) the tiles no update task writes
     bool fuse_gram = true;          // update tasks of fit! evaluate the Gram values of their tile themselves (TileTask.gram)
     bool fuse_steps = true;         // block steps with more diagonal blocks than CUs run as two fused launches (kernels_fused.hpp)
-    bool lookahead = false;         // opt-in (DSMGP_OPT_LOOKAHEAD): the other steps run on the lookahead schedule (STEP_LOOKAHEAD)
+    bool diag_in_update = true;     // classic steps: the diagonal tile's update runs one step ahead and its factorisation rides in
+                                    // the update launch (DiagFinishTask, kernels_fused.hpp)
     // per phase and block step (decided by build_plan):
     //   STEP_CLASSIC    update (all tiles, split-K) / reduce / diagonal block / panel solve launches, one after the other
     //   STEP_FUSED      many leaves: diag_fused_kernel, then tile_fused_kernel, from the kernel function (kernels_fused.hpp)
-    //   STEP_LOOKAHEAD  few leaves: the update of step k is cut at its last block column -- the BULK (columns before
-    //                   k - 1) runs on the main stream as soon as step k - 2 is final, the FINISH (diag_fused_kernel and
-    //                   tile_fused_kernel starting from the bulk's tile: rank-128 update + factorisation / solve) on a side
-    //                   stream after the bulk, beside the bulk of step k + 1: the chain diagonal block -> panel solve no
-    //                   longer sits between two update launches (src/AdvancedCholeskey.jl:161-171 per step, pipelined)
+    // (A third, lookahead schedule -- the update of step k cut at its last block column, the bulk on this stream, the rank-128
+    // finish + diagonal block + solve on a second, high-priority stream beside the bulk of step k + 1 -- was built in round 3
+    // and measured in every regime it was meant for: headline 0.4037 / 0.4055 s against 0.3906 / 0.3992, config 2 3.51 against
+    // 3.35 ms, 8-rank shards 0.0571 / 0.0569 / 0.0568 / 0.0572 against 0.0577 / 0.0575 / 0.0574 / 0.0575, a 4-rank shard 0.1089 /
+    // 0.1082 against 0.1054 / 0.1053.  Removed in round 4; the numbers are in DESIGN.md section 8d.)
     std::vector<char> fused_step[2];
-    hipStream_t side = nullptr;     // the finish launches of lookahead steps
-    std::vector<hipEvent_t> ev_bulk, ev_fin;   // per block step (grown on demand, no timing)
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
     std::vector<char> leaf_group;   // per leaf: the phase it belongs to (COPY leaves ride with their source)
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
@@ -406,6 +415,7 @@ struct dsmgp_ctx {
     double* d_agg_out = nullptr;    // mu | var (n_t each) | y_test (n_t) | score block sums
     int agg_family = -1, agg_G = 0, agg_W = 0;
     bool agg_partial_ready = false, agg_done = false;
+    bool agg_total = false;         // d_agg_part holds the sum over ranks (dsmgp_aggregate_exchange ran on these partial sums)
 
     // gradients (built on first use)
     bool grad_ready = false;
@@ -525,6 +535,7 @@ void free_plan(dsmgp_ctx* c) {
     arena_put(c, c->arenaVec);
     arena_put(c, c->arenaXg);
     dev_free(c->d_info);
+    dev_free(c->d_owner);
     dev_free(c->d_mll);
     dev_free(c->d_leaves);
     dev_free(c->gram.p);
@@ -535,6 +546,7 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.diag.p);
         dev_free(ph.fdiag.p);
         dev_free(ph.ftile.p);
+        dev_free(ph.dfin.p);
     }
     arena_put(c, c->slabF);
     dev_free(c->fwd.p);
@@ -561,7 +573,7 @@ void free_test(dsmgp_ctx* c) {
     dev_free(c->d_agg_group);
     dev_free(c->d_agg_out);
     c->agg_part_cap = 0;
-    c->agg_partial_ready = c->agg_done = false;
+    c->agg_partial_ready = c->agg_done = c->agg_total = false;
     arena_put(c, c->arenaVt);
     arena_put(c, c->arenaXt);
     arena_put(c, c->arenaPV);
@@ -581,6 +593,7 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.diag.p);
         dev_free(ph.fdiag.p);
         dev_free(ph.ftile.p);
+        dev_free(ph.dfin.p);
     }
     arena_put(c, c->slabJ);
     c->joint_ready = false;
@@ -724,6 +737,9 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         std::vector<DiagTask> diag;
         std::vector<FusedTask> ftile;
         std::vector<DiagFusedTask> fdiag;
+        std::vector<DiagFinishTask> dfin;
+        S.dpos.assign(nsteps, 0);
+        S.dfin_off.assign(nsteps + 1, 0);
         S.upd_off.assign(nsteps + 1, 0);
         S.red_off.assign(nsteps + 1, 0);
         S.trsm_off.assign(nsteps + 1, 0);
@@ -740,14 +756,19 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             S.diag_off[k] = (int)diag.size();
             S.fdiag_off[k] = (int)fdiag.size();
             S.ftile_off[k] = (int)ftile.size();
+            S.dfin_off[k] = (int)dfin.size();
             const int mode = k < (int)c->fused_step[ph].size() ? c->fused_step[ph][k] : STEP_CLASSIC;
             S.mode[k] = (char)mode;
             const bool fstep = mode != STEP_CLASSIC;               // diagonal blocks and tiles below go through the fused kernels
-            const bool look = mode == STEP_LOOKAHEAD && k >= 2;    // ... which start from the tile a bulk update launch wrote
-            const int kfin0 = look ? (k - 1) * TB : 0;             // first column of the finish tasks' K range
-            const int kfin = look ? TB : k * TB;                   // ... and its length
-            const int kbulk = (k - 1) * TB;                        // the bulk's K range is [0, kbulk)
             std::vector<TileTask> tiles;
+            // One-step lookahead of the diagonal blocks (DiagFinishTask): where steps k-1 and k are both classic, the update
+            // launch of step k-1 has left tile (k,k) = K(k,k) - F[k,0:K-128] F[k,0:K-128]^T (`ahead` below, one step on), and
+            // the diagonal-block task of step k -- rank-128 finish + factorisation -- rides in the update launch of step k.
+            auto classic_at = [&](int q) {
+                return q >= 0 && q < nsteps && (q >= (int)c->fused_step[ph].size() || c->fused_step[ph][q] == STEP_CLASSIC);
+            };
+            const bool finish_here = c->diag_in_update && gram_fused(c) && !fstep && k >= 2 && classic_at(k - 1);
+            const bool ahead = c->diag_in_update && gram_fused(c) && !fstep && k >= 1 && classic_at(k + 1);
             size_t nsym = 0;
             for (int l = 0; l < L; ++l) {
                 const LeafHost& lf = c->leaves[l];
@@ -758,39 +779,18 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                     // a PREFIX leaf keeps the copied leading kb x kb blocks: for k < kb only rows >= kb are new
                     const int i_first = (k < lf.kb) ? lf.kb : k;
                     const bool own_diag = (k >= lf.kb);
+                    const bool fin = finish_here && own_diag;    // tile (k,k) got all but its last block column one step ago
                     for (int i = i_first; i < lf.nb; ++i) {
                         if (fstep) {      // fused step: the diagonal tile belongs to the diagonal-block task, the tiles below
-                            if (look) {                                            // are updated and solved in one task each
-                                // lookahead: the bulk of the update (columns before k - 1) is a task of the main stream's
-                                // launch; the diagonal tile keeps K - product, the tiles below product - K: the start
-                                // value of their finish task's accumulators
-                                TileTask u{};
-                                u.A = d.F + (size_t)i * TB;
-                                u.B = d.F + (size_t)k * TB;
-                                u.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
-                                u.lda = u.ldb = u.ldc = ld;
-                                u.k0 = 0;
-                                u.k1 = kbulk;
-                                u.update = (i == k) ? 1 : 0;
-                                u.mrows = tile_mrows(lf.n - i * TB);
-                                u.gram = 1 | (i == k ? 2 : 0) | 4;
-                                u.kid = lf.kid;
-                                u.gxa = d.Xg + (size_t)i * TB;
-                                u.gxb = d.Xg + (size_t)k * TB;
-                                u.glda = u.gldb = ld;
-                                u.gna = std::max(0, std::min(TB, lf.n - i * TB));
-                                u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
-                                tiles.push_back(u);
-                            }
+                                          // are updated and solved in one task each
                             if (i == k) continue;
                             FusedTask f{};
-                            f.A = d.F + (size_t)i * TB + (size_t)kfin0 * ld;
-                            f.B = d.F + (size_t)k * TB + (size_t)kfin0 * ld;
+                            f.A = d.F + (size_t)i * TB;
+                            f.B = d.F + (size_t)k * TB;
                             f.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
                             f.Dinv = d.Dinv + (size_t)k * TB * TB;
                             f.lda = f.ldb = f.ldc = ld;
-                            f.k1 = kfin;
-                            f.mem = look ? 1 : 0;
+                            f.k1 = k * TB;
                             f.gxa = d.Xg + (size_t)i * TB;
                             f.gxb = d.Xg + (size_t)k * TB;
                             f.glda = f.gldb = ld;
@@ -806,7 +806,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             ftile.push_back(f);
                             continue;
                         }
-                        if (k > 0) {
+                        if (k > 0 && !(i == k && fin)) {
                             TileTask u{};
                             u.A = d.F + (size_t)i * TB;
                             u.B = d.F + (size_t)k * TB;
@@ -827,6 +827,27 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                                 u.gna = std::max(0, std::min(TB, lf.n - i * TB));
                                 u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
                             }
+                            tiles.push_back(u);
+                        }
+                        if (i == k + 1 && ahead && k + 1 >= lf.kb) {
+                            // the NEXT step's diagonal tile over the columns this step's tiles cover: same depth, the A panel
+                            // of the tile (k+1, k) beside it; its last block column and its factorisation follow in the
+                            // DiagFinishTask of the next update launch
+                            TileTask u{};
+                            u.A = u.B = d.F + (size_t)i * TB;
+                            u.C = d.F + (size_t)i * TB + (size_t)i * TB * ld;
+                            u.lda = u.ldb = u.ldc = ld;
+                            u.k0 = 0;
+                            u.k1 = k * TB;
+                            u.update = 1;
+                            u.mrows = tile_mrows(lf.n - i * TB);
+                            u.sym = 1;
+                            nsym += 1;
+                            u.gram = 1 | 2 | 4;
+                            u.kid = lf.kid;
+                            u.gxa = u.gxb = d.Xg + (size_t)i * TB;
+                            u.glda = u.gldb = ld;
+                            u.gna = u.gnb = std::max(0, std::min(TB, lf.n - i * TB));
                             tiles.push_back(u);
                         }
                         if (i > k) {
@@ -863,13 +884,17 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         if (fstep) {
                             DiagFusedTask fg{};
                             fg.d = g;
-                            fg.A = d.F + (size_t)k * TB + (size_t)kfin0 * ld;
+                            fg.A = d.F + (size_t)k * TB;
                             fg.gx = d.Xg + (size_t)k * TB;
-                            fg.k1 = kfin;
-                            fg.mem = look ? 1 : 0;
+                            fg.k1 = k * TB;
                             fg.glda = ld;
                             fg.kid = lf.kid;
                             fdiag.push_back(fg);
+                        } else if (fin) {
+                            DiagFinishTask ft{};
+                            ft.d = g;
+                            ft.A = d.F + (size_t)k * TB + (size_t)(k - 1) * TB * ld;
+                            dfin.push_back(ft);
                         } else {
                             diag.push_back(g);
                         }
@@ -879,38 +904,15 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                     for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
                         double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
                         if (fstep) {
-                            if (look) {          // bulk task of the test-row tile: product - K_tn over the columns before k - 1
-                                TileTask u{};
-                                u.A = d.Vt + (size_t)ti * TB;
-                                u.B = d.F + (size_t)k * TB;
-                                u.C = tile;
-                                u.lda = lf.ntpad;
-                                u.ldb = ld;
-                                u.ldc = lf.ntpad;
-                                u.k0 = 0;
-                                u.k1 = kbulk;
-                                u.update = 0;
-                                u.mrows = tile_mrows(lf.nt - ti * TB);
-                                u.gram = 1;
-                                u.kid = lf.kid;
-                                u.gxa = d.Xtg + (size_t)ti * TB;
-                                u.gxb = d.Xg + (size_t)k * TB;
-                                u.glda = lf.ntpad;
-                                u.gldb = ld;
-                                u.gna = std::max(0, std::min(TB, lf.nt - ti * TB));
-                                u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
-                                tiles.push_back(u);
-                            }
                             FusedTask f{};
-                            f.A = d.Vt + (size_t)ti * TB + (size_t)kfin0 * lf.ntpad;
-                            f.B = d.F + (size_t)k * TB + (size_t)kfin0 * ld;
+                            f.A = d.Vt + (size_t)ti * TB;
+                            f.B = d.F + (size_t)k * TB;
                             f.C = tile;
                             f.Dinv = d.Dinv + (size_t)k * TB * TB;
                             f.lda = lf.ntpad;
                             f.ldb = ld;
                             f.ldc = lf.ntpad;
-                            f.k1 = kfin;
-                            f.mem = look ? 1 : 0;
+                            f.k1 = k * TB;
                             f.gxa = d.Xtg + (size_t)ti * TB;
                             f.gxb = d.Xg + (size_t)k * TB;
                             f.glda = lf.ntpad;
@@ -989,8 +991,21 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 }
                 S.pad[k] = (npad * 10 >= ntot && ntot >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
             }
-            U.add_step(tiles, look ? kbulk : k * TB);
+            U.add_step(tiles, k * TB);
             S.step_tiles[k] = (int)tiles.size();
+            // Where the step's diagonal-block tasks sit in its update launch.  They are ~45 us each, and a slot that runs one
+            // finishes its share of the launch that much later: in a launch that keeps every workgroup slot busy from start
+            // to end (rounds of equal tiles) the launch ends that much later wherever they sit (measured: at the front the
+            // update launches of the headline model and of an 8-rank shard grew by 37 and 30 us a step, the diagonal-block
+            // launch they replace was 38).  So: a launch that leaves slots idle anyway (fewer tasks than the chip's 2 x CUs
+            // workgroup slots) takes them first; a fuller one takes them LAST, behind its tail pieces, where they land in the
+            // slots that drain first while the last pieces are still running.
+            {
+                const int nu_k = (int)U.upd.size() - S.upd_off[k], nd_k = (int)dfin.size() - S.dfin_off[k];
+                if (nu_k + nd_k <= 2 * c->ncu) S.dpos[k] = 0;
+                else if (DSMGP_DFIN_BACK < 0) S.dpos[k] = nu_k;
+                else S.dpos[k] = std::max(0, (int)U.tail_begin - S.upd_off[k] - DSMGP_DFIN_BACK * c->ncu);
+            }
             {   // panel solves of a leaf read the same Dinv_k: keep them on one XCD (small leaves have 3-4 of them per
                 // step; dealt round-robin every one of them fetched the 128 KB block from HBM on its own: the depth-4
                 // model's panel-solve launches fetched 2.6x their tile bytes)
@@ -1006,6 +1021,8 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.diag_off[nsteps] = (int)diag.size();
         S.fdiag_off[nsteps] = (int)fdiag.size();
         S.ftile_off[nsteps] = (int)ftile.size();
+        S.dfin_off[nsteps] = (int)dfin.size();
+        if (int rc = dev_upload(c, S.dfin, dfin)) return rc;
         if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
         if (int rc = dev_upload(c, S.fdiag, fdiag)) return rc;
@@ -1025,15 +1042,14 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         }
     }
     // algorithmic flops of the launches timed as "update" (slot 1: tile_gemm_kernel_v2): 2 K per element of block column k with
-    // K = 128 k -- 128 (k - 1) where the step runs on the lookahead schedule (its bulk launch stops one block column short),
-    // nothing where it runs fused.  Fused tile launches (slot 18: tile_fused_kernel) are counted apart: their update flops
+    // K = 128 k, nothing where it runs fused.  Fused tile launches (slot 18: tile_fused_kernel) are counted apart: their update flops
     // plus the triangular solve of the tiles below the diagonal block (c_k^2 per row, c_k = columns of block k).
     alg_flops_fused = 0.0;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
         const std::vector<char>& md = c->fused_step[(int)c->leaf_group[l]];
         auto mode = [&](int k) { return k < (int)md.size() ? (int)md[k] : (int)STEP_CLASSIC; };
-        auto depth = [&](int k) { return mode(k) == STEP_FUSED ? 0 : (mode(k) == STEP_LOOKAHEAD ? std::max(0, k - 1) : k); };
+        auto depth = [&](int k) { return mode(k) == STEP_FUSED ? 0 : k; };
         auto depth_fused = [&](int k) { return mode(k) == STEP_FUSED ? k : 0; };
         if (lf.owner == l) {
             alg_flops += update_flops(lf.n, lf.kb, depth);
@@ -1108,6 +1124,12 @@ int build_plan(dsmgp_ctx* c) {
         if (int rc = arena_get(c, c->arenaXg, xTot)) return rc;
     }
     HIPCHK(c, hipMalloc(&c->d_info, L * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_owner, L * sizeof(int)));
+    {   // the owner table changes with the leaf table / sharing schedule only: uploaded here, once
+        std::vector<int> owner(L);
+        for (int l = 0; l < L; ++l) owner[l] = c->leaves[l].owner;
+        HIPCHK(c, hipMemcpy(c->d_owner, owner.data(), (size_t)L * sizeof(int), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMalloc(&c->d_mll, L * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_leaves, L * sizeof(LeafDev)));
 
@@ -1152,8 +1174,7 @@ int build_plan(dsmgp_ctx* c) {
     c->leaf_group.assign(L, 0);
     for (int l = 0; l < L; ++l)
         if (c->leaves[l].op == DSMGP_SHARE_PREFIX) c->leaf_group[l] = 1;
-    // How every block step runs (STEP_*).  Fused: the steps whose diagonal blocks alone fill the chip -- the same rule as the
-    // choice of the packed diagonal-block kernel.  Lookahead: the others, when asked for (DSMGP_OPT_LOOKAHEAD).
+    // How every block step runs (STEP_*).  Fused: the steps whose diagonal blocks alone fill the chip (or shallow ones).
     for (int ph = 0; ph < 2; ++ph) {
         int ns = 0;
         for (int l = 0; l < L; ++l)
@@ -1170,7 +1191,6 @@ int build_plan(dsmgp_ctx* c) {
             // updates a diagonal tile before factorising it is done in a few microseconds; deeper, that update belongs in
             // the many-workgroup update launch, split along K)
             if (c->fuse_steps && (nd > c->ncu || k <= FUSED_SHALLOW_STEPS)) c->fused_step[ph][k] = STEP_FUSED;
-            else if (c->lookahead) c->fused_step[ph][k] = STEP_LOOKAHEAD;
         }
     }
     // Gram tasks: lower tiles of every owner; with the Gram fused into the update tasks only the tiles that have none --
@@ -1297,18 +1317,21 @@ int ensure_phase(dsmgp_ctx* c) {
     return 0;
 }
 
-void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */, bool pad = false) {
+// dpos / dfin / ndfin: an update launch that carries its step's diagonal-block tasks (tile_gemm_kernel_v2's grid layout)
+void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */, bool pad = false,
+                  int dpos = 0, const DiagFinishTask* dfin = nullptr, int ndfin = 0) {
+    const int g = n + ndfin;
     if (pad) {   // launches with many padding-row tiles (small leaves): waves without data rows stay off the matrix pipe
         if (role == 1) tile_trsm_kernel<true><<<n, 256, 0, c->stream>>>(tasks);
-        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
-        else tile_gemm_kernel_v2<false, 0, true><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
+        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+        else tile_gemm_kernel_v2<false, 0, true><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
         return;
     }
     // ROLE only names the instantiation: with per-launch timing switched off (dsmgp_set_profile(ctx, 0)) the same code
     // runs as <false, 2>, so that a profiler's per-kernel average of <false, 0> covers exactly the launches bench.py times
     if (role == 1) tile_trsm_kernel<false><<<n, 256, 0, c->stream>>>(tasks);   // B = inverse of a diagonal block, K = 128
-    else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
-    else tile_gemm_kernel_v2<false, 0><<<n, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D);
+    else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+    else tile_gemm_kernel_v2<false, 0><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
 }
 
 // Two events bracketing a call on the context's stream; destroyed on every exit path.
@@ -1377,75 +1400,12 @@ struct PhaseTimer {
     }
 };
 
-// One factorisation phase.  Classic step: update (-> split-K reduce) -> diagonal block -> panel solve, on the context's
-// stream.  Fused step (many leaves): diag_fused_kernel -> tile_fused_kernel, same stream.  Lookahead step k: the bulk update
-// (-> reduce) on the context's stream once step k - 2 is final; the finish -- diag_fused_kernel, tile_fused_kernel -- on the
-// side stream once the bulk and step k - 1 are done.  ev_fin[k] marks step k final on whichever stream finished it.
-int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches, int k_begin = 0) {
-    auto grow = [&](std::vector<hipEvent_t>& v, int n) -> bool {
-        while ((int)v.size() < n) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-            v.push_back(e);
-        }
-        return true;
-    };
-    bool any_look = false;
-    for (int k = 0; k < S.nsteps; ++k) any_look = any_look || S.mode[k] == STEP_LOOKAHEAD;
-    if (any_look && (!c->side || !grow(c->ev_bulk, S.nsteps + 1) || !grow(c->ev_fin, S.nsteps + 1)))
-        return fail(c, DSMGP_E_HIP, "lookahead schedule: cannot create events");
-    std::vector<char> fin_on_side(S.nsteps, 0);     // where step k became final
-    hipEvent_t ev_start = nullptr;
-    if (any_look) {   // everything queued on the context's stream so far (Gram launch, rhs copy, a previous phase) precedes the side stream's work
-        ev_start = c->ev_bulk[S.nsteps];
-        HIPCHK(c, hipEventRecord(ev_start, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side, ev_start, 0));
-    }
-    auto main_waits_step = [&](int k) -> int {      // the context's stream needs step k final
-        if (k >= 0 && fin_on_side[k]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fin[k], 0));
-        return 0;
-    };
-    for (int k = k_begin; k < S.nsteps; ++k) {
+// One factorisation phase on the context's stream.  Classic step: update (-> split-K reduce) -> diagonal block -> panel solve.
+// Fused step (many leaves, or shallow): diag_fused_kernel -> tile_fused_kernel.
+int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
+    for (int k = 0; k < S.nsteps; ++k) {
         const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
-        if (S.mode[k] == STEP_LOOKAHEAD) {
-            if (nu > 0) {       // bulk: reads the columns before k - 1
-                if (int rc = main_waits_step(k - 2)) return rc;
-                pt.begin(1);
-                launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0);
-                pt.note(k, nu, S.step_tiles[k]);
-                pt.end();
-                const int nr = S.red_off[k + 1] - S.red_off[k];
-                if (nr > 0) {
-                    pt.begin(13);
-                    tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
-                    pt.end();
-                }
-                if (count_launches) c->n_update_launches++;
-                HIPCHK(c, hipEventRecord(c->ev_bulk[k], c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_bulk[k], 0));
-            }
-            if (k > 0 && !fin_on_side[k - 1]) {     // the previous step finished on the context's stream
-                HIPCHK(c, hipEventRecord(c->ev_fin[k - 1], c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fin[k - 1], 0));
-            }
-            if (nfd > 0) {
-                pt.begin(2, c->side);
-                diag_fused_kernel<<<nfd, 256, DIAGP_LDS_BYTES, c->side>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
-                pt.note(k, nfd, 0);
-                pt.end(c->side);
-            }
-            if (nft > 0) {
-                pt.begin(3, c->side);
-                tile_fused_kernel<<<nft, 256, 0, c->side>>>(S.ftile.p + S.ftile_off[k], c->d_kp, c->D);
-                pt.note(k, nft, 0);
-                pt.end(c->side);
-            }
-            HIPCHK(c, hipEventRecord(c->ev_fin[k], c->side));
-            fin_on_side[k] = 1;
-            continue;
-        }
-        if (int rc = main_waits_step(k - 1)) return rc;
         if (nfd > 0 || nft > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
             if (nfd > 0) {
                 pt.begin(2);
@@ -1462,9 +1422,10 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches, i
             }
             continue;
         }
-        if (nu > 0) {
+        const int ndf = S.dfin_off[k + 1] - S.dfin_off[k];
+        if (nu > 0 || ndf > 0) {
             pt.begin(1);
-            launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0);
+            launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0, S.dpos[k], S.dfin.p + S.dfin_off[k], ndf);
             pt.note(k, nu, S.step_tiles[k]);
             pt.end();
             const int nr = S.red_off[k + 1] - S.red_off[k];
@@ -1490,9 +1451,6 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches, i
             pt.end();
         }
     }
-    // the context's stream continues (next phase, forward solves, mll) only when the last steps are final
-    for (int k = std::max(0, S.nsteps - 2); k < S.nsteps; ++k)
-        if (int rc = main_waits_step(k)) return rc;
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1538,14 +1496,6 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         delete c;
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
-    {   // side stream of the lookahead schedule: its launches are the dependent chain, so they go first when slots free up
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) != hipSuccess) {
-            (void)hipGetLastError();
-            c->side = nullptr;
-        }
-    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(diag_fused_kernel),
@@ -1583,9 +1533,6 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->d_l2);
     (void)dsmgp_comm_destroy(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_bulk) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_fin) (void)hipEventDestroy(e);
-    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1635,14 +1582,13 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
         c->fuse_steps = value != 0;
         return 0;
     }
-    if (option == DSMGP_OPT_LOOKAHEAD) {
-        if (value != 0 && !c->side) return fail(c, DSMGP_E_STATE, "lookahead schedule: no second stream on this device");
-        if ((value != 0) != c->lookahead) {
+    if (option == DSMGP_OPT_DIAG_IN_UPDATE) {
+        if ((value != 0) != c->diag_in_update) {
             HIPCHK(c, hipSetDevice(c->device));
             free_plan(c);
             free_test(c);
         }
-        c->lookahead = value != 0;
+        c->diag_in_update = value != 0;
         return 0;
     }
     return fail(c, DSMGP_E_ARG, "set_option: unknown option");
@@ -2154,7 +2100,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     c->timings[12] = ms * 1e-3;
     if (seconds) *seconds = ms * 1e-3;
     c->predicted = true;
-    c->agg_partial_ready = c->agg_done = false;
+    c->agg_partial_ready = c->agg_done = c->agg_total = false;
     return 0;
 }
 
@@ -2229,6 +2175,7 @@ int dsmgp_aggregate_partial(dsmgp_ctx* c, int32_t family, const double* leaf_coe
     c->agg_G = G;
     c->agg_W = W;
     c->agg_partial_ready = true;
+    c->agg_total = false;
     c->agg_done = false;
     return 0;
 }
@@ -2932,7 +2879,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     if (std::getenv("DSMGP_STAMPS")) {
         unsigned long long* st = nullptr;
         HIPCHK(c, hipMalloc(&st, (size_t)ntiles * 32 * sizeof(unsigned long long)));
-        tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st, nullptr, 0);
+        tile_gemm_kernel_v2<true><<<ntiles, 256, 0, c->stream>>>(dt.p, st, nullptr, 0, 0, nullptr, 0);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::vector<unsigned long long> hs((size_t)ntiles * 32);
         HIPCHK(c, hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -3189,16 +3136,9 @@ int dsmgp_fit_exchange(dsmgp_ctx* c, int64_t count, double* out) {
     const size_t n = 2 * (size_t)count;
     if (int rc = xchg_reserve(c, n)) return rc;
     if (c->L > 0) {
-        // info lives per factor owner: the owner table goes up once per call (L ints)
-        std::vector<int> owner(c->L);
-        for (int l = 0; l < c->L; ++l) owner[l] = c->leaves[l].owner;
-        int* d_owner = nullptr;
-        HIPCHK(c, hipMalloc(&d_owner, (size_t)c->L * sizeof(int)));
-        HIPCHK(c, hipMemcpyAsync(d_owner, owner.data(), (size_t)c->L * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        pack_mll_info_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(c->d_mll, c->d_info, d_owner, c->L, count, c->d_xchg);
+        // info lives per factor owner (the table is the plan's: build_plan)
+        pack_mll_info_kernel<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(c->d_mll, c->d_info, c->d_owner, c->L, count, c->d_xchg);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // owner is stack storage
-        (void)hipFree(d_owner);
     } else {
         HIPCHK(c, hipMemsetAsync(c->d_xchg, 0, n * sizeof(double), c->stream));
     }
@@ -3212,6 +3152,7 @@ int dsmgp_aggregate_exchange(dsmgp_ctx* c, double* total_out) {
     if (!c) return DSMGP_E_ARG;
     if (!c->comm) return fail(c, DSMGP_E_STATE, "aggregate_exchange before comm_init");
     if (!c->agg_partial_ready) return fail(c, DSMGP_E_STATE, "aggregate_exchange before aggregate_partial");
+    if (c->agg_total) return fail(c, DSMGP_E_STATE, "aggregate_exchange: these partial sums already hold the total over ranks");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)c->agg_W * (size_t)c->n_t;
     if (int rc = xchg_reserve(c, n)) return rc;
@@ -3221,6 +3162,7 @@ int dsmgp_aggregate_exchange(dsmgp_ctx* c, double* total_out) {
     HIPCHK(c, hipGetLastError());
     if (total_out) HIPCHK(c, hipMemcpyAsync(total_out, c->d_agg_part, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->agg_total = true;
     return 0;
 }
 

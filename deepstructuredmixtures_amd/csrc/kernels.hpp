@@ -225,6 +225,7 @@ struct TileTask {
                         //    bit 2: short tiles (tile_rows_body) must write the padding rows of C too (tiles of the factor: zeros,
                         //    ones on the diagonal of a diagonal tile; the rows of K_tn already hold theirs)
     int kid;            // kernel id of the leaf (index into the KParam table)
+    int pad;
     const double* gxa;  // coordinates of the tile's rows, column-major [glda x D], offset to the tile's first row
     const double* gxb;  // ... of its columns
     int glda, gldb;
@@ -1015,43 +1016,6 @@ __device__ __forceinline__ void tile_rows_body(const TileTask& tk, double (*sA)[
     }
 }
 
-// ROLE only names the instantiation (same code): 0 = update launches (whole tiles and split-K pieces), 1 = panel
-// solves (K = 128), so that profilers report the two populations as two kernels
-// (tile_gemm_kernel_v2<false, 0> is the dominant kernel of bench.py's roofline).
-// PAD: the launch carries enough short tiles (TileTask.mrows <= 96: padding rows below) for the column-split form
-// (tile_rows_body) to pay; without it the check is compiled out (it costs the other launches ~0.3 % through the register
-// allocation of the main path).
-template <bool STAMP, int ROLE = 0, bool PAD = false>
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
-                                                              unsigned long long* __restrict__ stamps,
-                                                              const KParam* __restrict__ kp, int D) {
-    __shared__ __attribute__((aligned(16))) double sA[NRING][KC2 * LDP];
-    __shared__ __attribute__((aligned(16))) double sB[NRING][KC2 * LDP];
-    static_assert(GRAM_FUSE_MAX_D * TB <= NRING * KC2 * LDP, "coordinate image of a fused-Gram tile must fit the ring");
-    unsigned long long r0 = 0;
-    if (STAMP) r0 = __builtin_amdgcn_s_memrealtime();
-    const TileTask tk = tasks[blockIdx.x];
-    if (tk.sym) {       // diagonal tile of the factorisation: lower blocks only (workgroup-uniform branch)
-        tile_syrk_body(tk, sA, kp, D);
-        return;
-    }
-    if (PAD && !STAMP && tk.update == 1 && tk.mrows != 0 && tk.mrows <= 96 && tk.wi == nullptr && tk.rev == 0) {
-        // short tile (rows mrows.. are padding): the waves split the columns, every SIMD does mrows/128 of a tile's work
-        if (tk.mrows <= 32) tile_rows_body<2>(tk, sA, sB, kp, D);
-        else if (tk.mrows <= 64) tile_rows_body<4>(tk, sA, sB, kp, D);
-        else tile_rows_body<6>(tk, sA, sB, kp, D);
-        return;
-    }
-    d4 acc[4][4];
-    gemm_mainloop_v2<STAMP>(tk, acc, sA, sB, stamps);
-    tile_epilogue(tk, acc, &sA[0][0], kp, D, &sB[0][0]);
-    if (STAMP && (threadIdx.x & 63) == 0) {
-        unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
-        s[6] = r0;                                    // kernel entry / exit of this wave (100 MHz wall ticks)
-        s[7] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Panel solve X = T Dinv^T  (T = tk.A: one 128x128 tile; Dinv = tk.B: inverse of the step's diagonal block, LOWER
 // triangular, ld 128; K = 128).  X(r,c) = sum_{j <= c} T(r,j) Dinv(c,j): the 16-column block cb of X needs only
@@ -1406,8 +1370,7 @@ struct ReduceTask {
     int ldc;
     int nsplit;
     int fresh;             // 1: the tile is not read (C = -(slab_0 + ...)): slab 0 already holds product - Gram value
-    int neg;               // 1: the result is stored negated (C = +(slab_0 + ...) for a fresh tile): tiles the lookahead
-                           //    schedule's finish task starts from hold -(K - product)
+    int pad;
 };
 
 // REDUCE_WGS workgroups per tile (16 columns each); a thread owns two rows of four columns and keeps the loads of
@@ -1431,7 +1394,7 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(const ReduceTask* __re
 #pragma unroll
     for (int i = 0; i < 4; ++i) cv[i] = tk.fresh ? d2{0.0, 0.0} : *reinterpret_cast<const d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc) = tk.neg ? s[i] - cv[i] : cv[i] - s[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(tk.C + r + (size_t)(c0 + 4 * i) * tk.ldc) = cv[i] - s[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1690,7 +1653,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
     }
     // Block steps that hold data.  The last block of a leaf is padded with the identity (n mod 128 rows of data): the 16x16
     // blocks from JN on are the identity -- their own factor and inverse -- and everything below and beside them is zero,
-    // so the factorisation stops after step JN - 1 (whose lookahead still passes block JN through diag_block: it writes that
+    // so the factorisation stops after step JN - 1 (whose look at the next diagonal block still passes block JN through diag_block: it writes that
     // block's L and L^-1) and the diagonal blocks beyond are written as they are.
     const int JN = (tk.nvalid + 15) >> 4;
     // What is known to be zero in the tile goes out NOW, while the image settles: the blocks above the diagonal and the

@@ -42,10 +42,7 @@ struct FusedTask {
     int kid;
     int mrows;            // rows that hold data, rounded up to 16; 0 = all 128.  <= 64: a wave takes 16 rows instead of 32
     int zpad;             // tile of the factor: its padding rows are written here too (zeros)
-    int mem;              // 1: the task starts from the tile in memory, which holds -(K(i,k) - A' B'^T) over the columns BEFORE the
-                          //    K range of this task (lookahead schedule: a bulk update launch wrote it), instead of from the
-                          //    kernel function; A, B then point at the last block column and k1 = 128
-    int pad[2];
+    int pad[3];
 };
 static_assert(sizeof(FusedTask) == 128, "FusedTask is read with scalar loads: keep it two cache lines");
 
@@ -54,8 +51,7 @@ struct DiagFusedTask {
     const double* A;      // F[k, 0:K]: the block row left of the tile, ld = d.ld
     const double* gx;     // coordinates of the block's points, ld glda
     int k1, glda, kid;
-    int mem;              // 1: S starts from the tile in memory (= K(k,k) minus the product over the columns before A's: the bulk
-                          //    update of the lookahead schedule wrote it) instead of from the kernel function
+    int pad;
 };
 
 // Row-split tile product: wave w owns the rows RW w .. RW w + RW - 1 (RW = 16 NRW: 32 for a whole tile, 16 for a tile of
@@ -290,17 +286,7 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
     RowsplitPrefetch pf;
     rowsplit_prefetch<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, pf);
     d4 acc[NCB][NRW];
-    if (NCB == 8 && tk.mem) {   // acc = the tile as the bulk update left it (-C over the earlier columns): 64 NRW loads in flight per lane
-        const unsigned lofs0 = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * q) * (size_t)tk.ldc);
-#pragma unroll
-                for (int rn = 0; rn < NRW; ++rn) acc[cb][rn][q] = col[lofs0 + 16 * rn];
-            }
-    } else {        // acc = -k(row, col): coordinates through the (still unused) ring
+    {               // acc = -k(row, col): coordinates through the (still unused) ring
         const KParam p = kp[tk.kid];
         double* sa = &sA[0][0];
         double* sb = &sB[0][0];
@@ -425,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void tile_fused_kernel(const FusedTask* __r
     const FusedTask tk = tasks[blockIdx.x];
     const bool half = tk.mrows != 0 && tk.mrows <= 64;
     // valid columns of the tile: fewer than 128 only in the last block column of a leaf (padding columns: X = 0 exactly)
-    const int ncb = tk.mem ? 8 : (tk.gnb + 15) >> 4;
+    const int ncb = (tk.gnb + 15) >> 4;
     if (ncb <= 1) {
         if (half) tile_fused_body<1, 1>(tk, sA, sB, kp, D);
         else tile_fused_body<2, 1>(tk, sA, sB, kp, D);
@@ -488,16 +474,18 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
     }
 }
 
-template <int SHAPE>
-__device__ __forceinline__ void diag_fused_front(const TileTask& tt, bool mem, const KParam* __restrict__ kp, int D, double* S,
+// MEM: S starts from the tile in memory -- which holds K(k,k) minus the product over the columns BEFORE this task's K range: an
+// earlier update launch wrote it (the diagonal-block tasks that ride in the update launches, DiagFinishTask) -- instead of from
+// the kernel function.
+template <int SHAPE, bool MEM = false>
+__device__ __forceinline__ void diag_fused_front(const TileTask& tt, const KParam* __restrict__ kp, int D, double* S,
                                                  const int (&blk)[6]) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
     d4 acc[9];
     syrk_mainloop<SHAPE>(tt, acc, sA, blk);                 // ends on a barrier: the ring is free
-    if (mem) {
-        // lookahead schedule: the tile holds K(k,k) minus the product over the earlier columns (the bulk update wrote it):
+    if constexpr (MEM) {
         // S = tile - product over this task's columns, block by block in the accumulator layout (36 loads in flight)
         const size_t ldc = (size_t)tt.ldc;
         double cv[9][4];
@@ -556,17 +544,108 @@ __global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask*
     tt.gna = tt.gnb = ft.d.nvalid;
     tt.C = ft.d.T;
     tt.ldc = ft.d.ld;
-    const bool mem = ft.mem != 0;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w == 3) {
         const int blk[6] = {0, 1, 3, 4, 6, 7};
-        diag_fused_front<1>(tt, mem, kp, D, S, blk);
+        diag_fused_front<1>(tt, kp, D, S, blk);
     } else {
         const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
         const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
-        diag_fused_front<0>(tt, mem, kp, D, S, blk);
+        diag_fused_front<0>(tt, kp, D, S, blk);
     }
     chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
+}
+
+// ---------------------------------------------------------------------------------------------
+// The diagonal block INSIDE the update launch (round 4).  In a classic block step the chain update -> (reduce) -> diagonal
+// block -> panel solve is four dependent launches, and the diagonal-block launch -- one workgroup per leaf, 35 us of a
+// latency-bound pivot chain -- keeps the whole chip waiting: 104 steps x 38 us on the headline model and on every shard of a
+// multi-GPU job, a third of the step time of a single GP (config 2).  Two streams do not hide it (rounds 2 and 3: concurrent
+// kernels slow the update launch by more than the chain they hide), and neither does a task that WAITS inside the update
+// launch for the pieces of its tile (built first in round 4: arrival counter, agent-scope release / acquire -- correct, -6 %
+// on config 2, but the pieces at the front of a many-round launch break the lockstep in which its tiles share their B panels
+// through L2: headline +8 ms of update time for 4 ms of chain).  What does is moving the diagonal tile's update ONE STEP
+// AHEAD, where nothing waits for it:
+//   step k-1  the update launch also carries, per leaf, the tile (k,k) over the columns [0, 128 (k-1)) -- an ordinary tile of
+//             that launch's depth sharing its A panel with the tile (k, k-1) next to it;
+//   step k    the update launch carries one DiagFinishTask per leaf: S = tile - F[k,k-1] F[k,k-1]^T (the one block column the
+//             panel solves of step k-1 have just finished), factorisation, inverse, z_k -- every input final before the launch
+//             starts, so the task is an ordinary member of the grid, running beside the updates of the tiles below it, which
+//             do not need it; the panel-solve launch that follows finds L_kk, Dinv_k and z_k ready.
+// (src/AdvancedCholeskey.jl:161-171 per step, with the potrf of the NEXT diagonal block overlapped with the trailing update:
+// the classic one-step lookahead of a right-looking factorisation, expressed as tasks of one launch.)
+struct DiagFinishTask {
+    DiagTask d;
+    const double* A;         // F[k, K - 128 .. K): the last finished block of the block row, ld = d.ld
+};
+
+__device__ __forceinline__ void diag_finish_body(const DiagFinishTask& ft, double* S) {
+    TileTask tt{};
+    tt.A = ft.A;
+    tt.lda = ft.d.ld;
+    tt.k0 = 0;
+    tt.k1 = TB;
+    tt.C = ft.d.T;
+    tt.ldc = ft.d.ld;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w == 3) {
+        const int blk[6] = {0, 1, 3, 4, 6, 7};
+        diag_fused_front<1, true>(tt, nullptr, 0, S, blk);
+    } else {
+        const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
+        const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
+        diag_fused_front<0, true>(tt, nullptr, 0, S, blk);
+    }
+    chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
+}
+
+// ROLE only names the instantiation (same code): 0 = update launches (whole tiles and split-K pieces), 1 = panel
+// solves (K = 128), so that profilers report the two populations as two kernels
+// (tile_gemm_kernel_v2<false, 0> is the dominant kernel of bench.py's roofline).
+// PAD: the launch carries enough short tiles (TileTask.mrows <= 96: padding rows below) for the column-split form
+// (tile_rows_body) to pay; without it the check is compiled out (it costs the other launches ~0.3 % through the register
+// allocation of the main path).
+// Grid of an update launch that carries diagonal-block tasks: [0, dpos) tile tasks (tasks[0..dpos)), [dpos, dpos + ndfin) the
+// DiagFinishTasks, then the remaining tile tasks (tasks[dpos..]).  ndfin = 0: tile tasks only.
+constexpr int UPD_LDS_DOUBLES = (2 * NRING * KC2 * LDP > PIMG + 2 * TB + 64) ? 2 * NRING * KC2 * LDP : PIMG + 2 * TB + 64;
+template <bool STAMP, int ROLE = 0, bool PAD = false>
+__global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __restrict__ tasks,
+                                                              unsigned long long* __restrict__ stamps,
+                                                              const KParam* __restrict__ kp, int D, int dpos,
+                                                              const DiagFinishTask* __restrict__ dfin, int ndfin) {
+    __shared__ __attribute__((aligned(16))) double smem[UPD_LDS_DOUBLES];
+    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
+    double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem + NRING * KC2 * LDP);
+    static_assert(GRAM_FUSE_MAX_D * TB <= NRING * KC2 * LDP, "coordinate image of a fused-Gram tile must fit the ring");
+    static_assert(UPD_LDS_DOUBLES * sizeof(double) >= (size_t)DIAGP_LDS_BYTES, "a diagonal-block task must fit the launch's LDS");
+    unsigned long long r0 = 0;
+    if (STAMP) r0 = __builtin_amdgcn_s_memrealtime();
+    int b = blockIdx.x;
+    if (!STAMP && ndfin > 0 && b >= dpos) {      // workgroup-uniform
+        if (b < dpos + ndfin) {
+            diag_finish_body(dfin[b - dpos], smem);
+            return;
+        }
+        b -= ndfin;
+    }
+    const TileTask tk = tasks[b];
+    if (tk.sym) {       // diagonal tile of the factorisation: lower blocks only (workgroup-uniform branch)
+        tile_syrk_body(tk, sA, kp, D);
+    } else if (PAD && !STAMP && tk.update == 1 && tk.mrows != 0 && tk.mrows <= 96 && tk.wi == nullptr && tk.rev == 0) {
+        // short tile (rows mrows.. are padding): the waves split the columns, every SIMD does mrows/128 of a tile's work
+        if (tk.mrows <= 32) tile_rows_body<2>(tk, sA, sB, kp, D);
+        else if (tk.mrows <= 64) tile_rows_body<4>(tk, sA, sB, kp, D);
+        else tile_rows_body<6>(tk, sA, sB, kp, D);
+    } else {
+        d4 acc[4][4];
+        gemm_mainloop_v2<STAMP>(tk, acc, sA, sB, stamps);
+        tile_epilogue(tk, acc, &sA[0][0], kp, D, &sB[0][0]);
+        if (STAMP && (threadIdx.x & 63) == 0) {
+            unsigned long long* s = stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+            s[6] = r0;                                    // kernel entry / exit of this wave (100 MHz wall ticks)
+            s[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 }
 
 }  // namespace dsmgp

@@ -30,33 +30,69 @@ class Shard:
         self.exchange = "none" if self.world == 1 else "torch"
 
     # ---- exchange through the library (RCCL on the context's stream) ----------------------------
+    @staticmethod
+    def device_exchange_requested():
+        """The in-library RCCL exchange is OPT-IN (`DSMGP_EXCHANGE=rccl-device` in the environment of every rank, read
+        before the first GPU call): no run with more than one rank has exercised it on hardware yet (no multi-GPU box has
+        been available to any round), so `torch.distributed` -- the path every world-2 test covers -- is the default."""
+        import os
+        return os.environ.get("DSMGP_EXCHANGE", "torch").strip().lower() == "rccl-device"
+
+    def _all_min(self, ok):
+        """MIN over ranks of a per-rank verdict, on whatever device the process group moves (gloo: host, nccl: GPU)."""
+        import torch
+        td = _pg()
+        dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
+        td.all_reduce(flag, op=td.ReduceOp.MIN)
+        return int(flag.item())
+
     def device_comm(self, ctx, force=False):
-        """Set up the library's own RCCL communicator on `ctx` (one per rank) when the process group is `nccl`: rank 0
-        draws the 128-byte id, torch.distributed carries it to the others, every rank calls dsmgp_comm_init and proves
-        the communicator with one tiny all-gather.  All ranks take the device path or none does (a MIN all-reduce of
-        the per-rank verdicts); on any failure the exchanges stay on torch.distributed.  Returns the path in use."""
+        """Set up the library's own RCCL communicator on `ctx` (one per rank): rank 0 draws the 128-byte id,
+        torch.distributed carries it to the others, every rank calls dsmgp_comm_init and proves the communicator with one
+        tiny all-gather.  Taken when asked for (`device_exchange_requested`) under the `nccl` process group, or with
+        `force` (tests: a one-rank communicator on the GPU box, stub contexts over gloo).
+
+        Every rank runs the SAME torch.distributed collectives in the SAME order whatever fails where: (1) each rank
+        probes that it can reach RCCL at all (draws an id of its own and drops it) and the verdicts are MIN-reduced --
+        nobody enters the blocking dsmgp_comm_init unless everybody can; (2) rank 0's id is broadcast; (3) init, verdicts
+        MIN-reduced; (4) the proof all-gather, verdicts MIN-reduced: all ranks take the device path or none does, and on any
+        failure the exchanges stay on torch.distributed.  Returns the path in use."""
         td = _pg()
         if self.world == 1 and force:          # one-rank communicator: the GPU box's test of this path
             uid = ctx.comm_unique_id()
             ctx.comm_init(0, 1, uid)
             self.comm_ctx, self.exchange = ctx, "rccl-device"
             return self.exchange
-        if self.world == 1 or td is None or td.get_backend() != "nccl" or self.comm_ctx is not None:
+        if self.world == 1 or td is None or self.comm_ctx is not None:
             return self.exchange
-        import torch
+        if not force and not (td.get_backend() == "nccl" and self.device_exchange_requested()):
+            return self.exchange
+        uid = None
+        try:
+            uid = ctx.comm_unique_id()          # loads librccl: the probe of THIS rank (only rank 0's id is used)
+        except Exception:
+            uid = None
+        if self._all_min(uid is not None) != 1:
+            return self.exchange
+        box = [uid if self.rank == 0 else None]
+        td.broadcast_object_list(box, src=0)
         ok = 1
         try:
-            box = [ctx.comm_unique_id() if self.rank == 0 else None]
-            td.broadcast_object_list(box, src=0)
             ctx.comm_init(self.rank, self.world, box[0])
-            got = ctx.allgather(np.array([float(self.rank)]))
-            ok = int(np.array_equal(got.ravel(), np.arange(self.world, dtype=np.float64)))
         except Exception:
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-        td.all_reduce(flag, op=td.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        ok = self._all_min(ok)                 # nobody enters the proof collective unless every rank holds a communicator
+        if ok == 1:
+            try:
+                got = ctx.allgather(np.array([float(self.rank)]))
+                ok = int(np.array_equal(np.asarray(got).ravel(), np.arange(self.world, dtype=np.float64)))
+            except Exception:
+                ok = 0
+            ok = self._all_min(ok)
+        if ok == 1:
             self.comm_ctx, self.exchange = ctx, "rccl-device"
+            self.verified = False
         else:
             try:
                 ctx.comm_destroy()
@@ -64,14 +100,32 @@ class Shard:
                 pass
         return self.exchange
 
-    def fit_exchange(self, ctx):
-        """(mll, info) of every leaf after this rank's fit: one device-to-device all-gather (dsmgp_fit_exchange)."""
+    def drop_device_comm(self):
+        """Back to torch.distributed for good (a cross-check of the device exchange failed)."""
+        try:
+            self.comm_ctx.comm_destroy()
+        except Exception:
+            pass
+        self.comm_ctx, self.exchange = None, "torch"
+
+    def fit_exchange(self, ctx, local_cols=None):
+        """(mll, info) of every leaf after this rank's fit: one device-to-device all-gather (dsmgp_fit_exchange) of
+        `count` = max leaves per rank slots of (mll, info) per rank; rank r's leaves, in leaf order, fill its first slots.
+        With more than one rank the FIRST exchange of a communicator is cross-checked against the torch.distributed
+        gather of `local_cols` (this rank's (n_local, 2) results); a mismatch on any rank drops the device path on all."""
         counts = np.bincount(self.owner, minlength=self.world)
-        both = ctx.fit_exchange(int(max(1, counts.max())))
+        both = np.asarray(ctx.fit_exchange(int(max(1, counts.max()))))
         out = np.empty((self.owner.size, 2))
         for r in range(self.world):
             idx = np.flatnonzero(self.owner == r)
             out[idx] = both[r, : idx.size]
+        if self.world > 1 and not getattr(self, "verified", True) and local_cols is not None:
+            ref = self.gather_leaf_columns(local_cols)
+            same = int(np.array_equal(ref, out))
+            if self._all_min(same) != 1:
+                self.drop_device_comm()
+                return ref
+            self.verified = True
         return out
 
     @staticmethod

@@ -15,7 +15,7 @@ AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h 
 OPT_ARD_LENGTHSCALE_GRADIENT = 1
 OPT_FUSED_GRAM = 2
 OPT_FUSED_STEPS = 3
-OPT_LOOKAHEAD = 4
+OPT_DIAG_IN_UPDATE = 4
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
 

@@ -177,8 +177,8 @@ class Model:
                 self._ctx = hipabi.MultiContext(self._device, self._n_sub)
             else:
                 self._ctx = hipabi.Context(self._device)
-                if self.shard.world > 1:      # nccl process group: the exchanges run through the library's communicator
-                    self.shard.device_comm(self._ctx)
+                if self.shard.world > 1:      # opt-in (DSMGP_EXCHANGE=rccl-device): the exchanges run through the library's
+                    self.shard.device_comm(self._ctx)     # communicator; a collective every rank enters, or none
         return self._ctx
 
     # ---- kernel ids -> shared hyper-parameters --------------------------------------------------
@@ -372,10 +372,11 @@ def _fit(model, tau):
     else:
         model._push_hyper()
         mll_loc, info_loc, sec = model.ctx.fit()
+    cols = np.stack([mll_loc, info_loc.astype(np.float64)], axis=1)
     if model.shard.comm_ctx is not None:
-        both = model.shard.fit_exchange(model.ctx)     # device to device over RCCL, then one copy to the host
+        both = model.shard.fit_exchange(model.ctx, cols)     # device to device over RCCL, then one copy to the host
     else:
-        both = model.shard.gather_leaf_columns(np.stack([mll_loc, info_loc.astype(np.float64)], axis=1))   # one collective
+        both = model.shard.gather_leaf_columns(cols)         # one collective
     model.leaf_mll = np.ascontiguousarray(both[:, 0])
     model.leaf_info = both[:, 1].astype(np.int32)
     model.last_fit_seconds = sec

@@ -157,13 +157,15 @@ int dsmgp_gradients(dsmgp_ctx* ctx, double* grad_out, int32_t stride);
  * product from k(row, col)).  Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing it discards the leaf plan and a registered
  * test set. */
 #define DSMGP_OPT_FUSED_STEPS 3
-/* DSMGP_OPT_LOOKAHEAD: 1 = the block steps that are not fused (few leaves, deep K: the headline regime) run on a
- * lookahead schedule (default 0: measured slower on one GPU): the update of step k is cut at its
- * last block column; the bulk runs on the context's stream as soon as step k - 2 is final, the rest -- rank-128 update + factorisation of the diagonal block, rank-128 update + solve
- * of the tiles below -- on a second stream beside the bulk of step k + 1, so the dependent chain diagonal block ->
- * panel solve no longer sits between two update launches.  0 = update / reduce / diagonal block / panel solve launches
- * one after the other.  Results agree to rounding (one addition per entry changes place).  Needs DSMGP_OPT_FUSED_GRAM. */
-#define DSMGP_OPT_LOOKAHEAD 4
+/* DSMGP_OPT_DIAG_IN_UPDATE: 1 (default) = where two consecutive block steps are classic, the diagonal block runs one step
+ * ahead of the panel below it (the lookahead of a blocked factorisation, src/AdvancedCholeskey.jl:161-171 per step): the update
+ * launch of step k - 1 also updates tile (k, k) over the columns it covers, and the update launch of step k carries a task
+ * per leaf that applies the last block column, factorises the block and inverts it beside the updates of the tiles below,
+ * so the panel-solve launch finds L_kk, Dinv_k and z_k ready and the per-step chain loses a dependent launch (35 us x every
+ * block step of the deepest leaf); 0 = update / reduce / diagonal block / panel solve launches one after the other.
+ * Results agree to rounding (the diagonal tile's update is summed in two parts); a fit is bit-reproducible either way.
+ * Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing it discards the leaf plan and a registered test set. */
+#define DSMGP_OPT_DIAG_IN_UPDATE 4
 int dsmgp_set_option(dsmgp_ctx* ctx, int32_t option, int32_t value);
 
 /* ---- inspection ------------------------------------------------------------------------------- */
@@ -232,7 +234,8 @@ int dsmgp_allgather(dsmgp_ctx* ctx, const double* send, int64_t count, double* r
  *        table and contributes zeros): out[(r * count + l) * 2 + {0, 1}] = mll / info of rank r's leaf l.
  *      dsmgp_aggregate_exchange: after dsmgp_aggregate_partial on every rank, all-gathers the W x n_t partial sums and
  *        adds them in rank order on the device (the same bits on every rank); dsmgp_aggregate_finish(ctx, NULL, ...)
- *        then finishes from the total.  A rank without leaves calls dsmgp_aggregate_exchange_empty(ctx, W, n_t) instead
+ *        then finishes from the total (a second exchange of the same partial sums returns DSMGP_E_STATE: they already hold
+ *        the total).  A rank without leaves calls dsmgp_aggregate_exchange_empty(ctx, W, n_t) instead
  *        (it contributes zeros and receives the total in `total_out`, W x n_t doubles, may be NULL). */
 int dsmgp_fit_exchange(dsmgp_ctx* ctx, int64_t count, double* out /* world x count x 2 */);
 int dsmgp_aggregate_exchange(dsmgp_ctx* ctx, double* total_out /* W x n_t, may be NULL */);

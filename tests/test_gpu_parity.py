@@ -1329,7 +1329,6 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
         b = run(False)
     finally:
         ctx.set_option(hipabi.OPT_FUSED_STEPS, 1)
-        ctx.set_option(hipabi.OPT_LOOKAHEAD, 0)
         ctx.set_profile(0)
     assert a[4]["gram"] < 0.25 * b[4]["gram"]          # no Gram launch: the tasks of block column 0 start from the kernel function
     assert np.allclose(a[0], b[0], rtol=1e-12, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
@@ -1467,6 +1466,9 @@ def test_shard_exchange_through_the_library_communicator():
         assert np.array_equal(m.leaf_mll, ref.leaf_mll) and np.array_equal(m.leaf_info, ref.leaf_info) and z == zr
         assert np.array_equal(mu, mr) and np.array_equal(var, vr)
         assert dsm.scores(m, np.zeros(Xt.shape[0])) == dsm.scores(ref, np.zeros(Xt.shape[0]))      # finish ran on the device
+        # a second exchange of the same partial sums would add the total to itself `world` times: refused
+        with pytest.raises(hipabi.DsmgpError):
+            m.ctx.aggregate_exchange(3)
         # the rank-without-leaves form of the predict exchange: zeros in, the total out
         tot = m.ctx.aggregate_exchange_empty(3, Xt.shape[0])
         assert tot.shape == (3, Xt.shape[0]) and np.all(tot == 0.0)
@@ -1534,19 +1536,19 @@ def test_config5_full_size_factor_and_discard():
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_lookahead_schedule_agrees_with_the_classic_steps(ctx, kind):
-    """Few leaves, many block steps (the headline regime; opt-in: it measured slower):
-    with DSMGP_OPT_LOOKAHEAD the update of step k is
-    cut at its last block column -- the bulk launch (split along K where the step has few tiles: its reduce then leaves
-    product - K) runs on the context's stream, the finish (rank-128 update + factorisation of the diagonal block, rank-128
-    update + solve of the tiles below, both starting from the bulk's tile) on a second stream beside the next bulk.  Twelve
-    leaves of 200..1900 rows with a COPY and a PREFIX leaf and routed test rows, against the same table with the option off
-    (update / reduce / diagonal block / panel solve launches in sequence): log-marginals 1e-12, factors 1e-11, moments 1e-9;
-    two leaves against the oracle; and the same fit twice gives the same bits (two streams, one order of arithmetic)."""
-    N, D, L = 20_000, 3, 12
-    X, y, Xt = regression_data(N, D, n_test=200, seed=6200 + kind)
-    rng = np.random.default_rng(21 + kind)
-    sizes = [200, 333, 512, 640, 777, 900, 1100, 1290, 1500, 1900, 333, 700]
+def test_diagonal_block_inside_the_update_launch_agrees_with_separate_launches(ctx, kind):
+    """Round 4 (shorten the chain): where two consecutive block steps are classic the diagonal block runs one
+    step ahead (DSMGP_OPT_DIAG_IN_UPDATE): the update launch of step k - 1 also updates tile (k, k) over its columns, and the
+    update launch of step k carries one task per leaf that applies the last block column, factorises and inverts -- no
+    diagonal-block launch on the chain.  Thirteen leaves of 200..4100 rows (33 block steps: launches with fewer tiles than
+    CUs, where every tile is split along K, and fuller ones) with a COPY and a PREFIX leaf and routed test rows, every step
+    classic and then the default mix with the fused shallow steps, against the same table with the option off:
+    log-marginals 1e-12, factors 1e-11, moments 1e-9; two leaves against the oracle; the same fit three times gives the
+    same bits."""
+    N, D, L = 20_000, 3, 13
+    X, y, Xt = regression_data(N, D, n_test=200, seed=6300 + kind)
+    rng = np.random.default_rng(31 + kind)
+    sizes = [200, 333, 512, 640, 777, 900, 1100, 1290, 1500, 1900, 333, 700, 4100]
     obs = [np.sort(rng.choice(N, size=int(n), replace=False)) for n in sizes]
     obs[10] = obs[1].copy()                                               # COPY of leaf 1
     tail = np.arange(obs[3][-1] + 1, min(N, obs[3][-1] + 1 + 200))
@@ -1565,8 +1567,9 @@ def test_lookahead_schedule_agrees_with_the_classic_steps(ctx, kind):
     means = [float(np.mean(y[o])) for o in obs]
     means[10] = means[1]
 
-    def run(look):
-        ctx.set_option(hipabi.OPT_LOOKAHEAD, 1 if look else 0)
+    def run(inside, fused_steps):
+        ctx.set_option(hipabi.OPT_FUSED_STEPS, 1 if fused_steps else 0)
+        ctx.set_option(hipabi.OPT_DIAG_IN_UPDATE, 1 if inside else 0)
         ctx.set_train(X, y)
         ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, dtype=np.int32), means)
         ctx.set_sharing(op, src, plen)
@@ -1576,29 +1579,30 @@ def test_lookahead_schedule_agrees_with_the_classic_steps(ctx, kind):
         assert np.all(info == 0)
         ctx.predict_run()
         mu, var = ctx.predict_fetch()
-        fa = [ctx.download_factor(j, obs[j].size) for j in (0, 9, 11)]
-        mll2, _, _ = ctx.fit()                       # again: same launches, same order of arithmetic
-        ctx.predict_run()
-        mu2, var2 = ctx.predict_fetch()
-        assert np.array_equal(mll, mll2) and np.array_equal(mu, mu2) and np.array_equal(var, var2)
+        fa = [ctx.download_factor(j, obs[j].size) for j in (0, 9, 11, 12)]
+        for _ in range(2):                           # again: same launches, same order of arithmetic
+            mll2, _, _ = ctx.fit()
+            ctx.predict_run()
+            mu2, var2 = ctx.predict_fetch()
+            assert np.array_equal(mll, mll2) and np.array_equal(mu, mu2) and np.array_equal(var, var2)
         return mll, mu, var, fa
 
     try:
-        ctx.set_option(hipabi.OPT_FUSED_STEPS, 0)     # every step of the table on the schedule under test
-        a = run(True)
-        b = run(False)
+        runs = [(run(True, fs), run(False, fs)) for fs in (False, True)]
     finally:
-        ctx.set_option(hipabi.OPT_LOOKAHEAD, 0)
+        ctx.set_option(hipabi.OPT_DIAG_IN_UPDATE, 1)
         ctx.set_option(hipabi.OPT_FUSED_STEPS, 1)
-    assert np.allclose(a[0], b[0], rtol=1e-12, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
-    emu = float(np.max(np.abs(a[1] - b[1])) / max(1.0, float(np.max(np.abs(b[1])))))
-    evar = float(np.max(np.abs(a[2] - b[2]) / np.abs(b[2])))
-    assert emu <= 1e-9 and evar <= 1e-9, (emu, evar)
-    for (Fa, aa), (Fb, ab) in zip(a[3], b[3]):
-        assert np.max(np.abs(Fa - Fb)) <= 1e-11 * np.max(np.abs(Fb)), float(np.max(np.abs(Fa - Fb)) / np.max(np.abs(Fb)))
-        assert np.max(np.abs(aa - ab)) <= 1e-8 * np.max(np.abs(ab))
+    for a, b in runs:
+        assert np.allclose(a[0], b[0], rtol=1e-12, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
+        emu = float(np.max(np.abs(a[1] - b[1])) / max(1.0, float(np.max(np.abs(b[1])))))
+        evar = float(np.max(np.abs(a[2] - b[2]) / np.abs(b[2])))
+        assert emu <= 1e-9 and evar <= 1e-9, (emu, evar)
+        for (Fa, aa), (Fb, ab) in zip(a[3], b[3]):
+            assert np.max(np.abs(Fa - Fb)) <= 1e-11 * np.max(np.abs(Fb)), float(np.max(np.abs(Fa - Fb)) / np.max(np.abs(Fb)))
+            assert np.max(np.abs(aa - ab)) <= 1e-8 * np.max(np.abs(ab))
+    a = runs[1][0]
     mk = {0: lambda: ogp.IsoSE(hyp[0], hyp[1]), 1: lambda: ogp.ArdSE(np.array(hyp[:3]), hyp[3]), 2: lambda: ogp.IsoLinear(hyp[0])}[kind]
-    for j in (9, 11):
+    for j in (11, 12):
         g = ogp.GaussianProcess(X[obs[j]], y[obs[j]], means[j], mk(), hyp[-1], True).update_cholesky()
         assert abs(a[0][j] - g.mll()) <= RTOL * abs(g.mll())
         mo, vo = g.prediction(Xt[ridx[rptr[j]:rptr[j + 1]]])

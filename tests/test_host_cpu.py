@@ -244,6 +244,22 @@ def test_lpt_sharding_balances_and_colocates():
     assert np.array_equal(s1.gather_leaf_values(np.arange(5.0)), np.arange(5.0))
 
 
+def _run_two_ranks(script, port):
+    """Two gloo ranks of `script`; both are reaped whatever happens (a hung pair would keep the port for the next run)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert " ok" in o
+
+
 _WORKER = r"""
 import os, sys
 import numpy as np
@@ -271,13 +287,7 @@ print("rank", rank, "ok", len(m.shard.local))
 def test_two_rank_gloo_sharding_reproduces_the_single_process_result(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
-        assert " ok " in o
+    _run_two_ranks(script, 29731)
 
 
 _EMPTY_RANK_WORKER = r"""
@@ -314,13 +324,102 @@ def test_rank_without_leaves_joins_the_collectives(tmp_path):
     """Fewer leaf groups than ranks: the idle rank makes no device call and contributes empty parts."""
     script = tmp_path / "worker.py"
     script.write_text(_EMPTY_RANK_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", WORLD_SIZE="2", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
-        assert " ok " in o
+    _run_two_ranks(script, 29733)
+
+
+_DEVICE_COMM_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as td
+sys.path.insert(0, {root!r})
+from deepstructuredmixtures_amd import dist as pdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+td.init_process_group("gloo", rank=rank, world_size=world)
+
+
+class StubCtx:
+    # the communicator entries of hipabi.Context, moving data over the gloo group instead of RCCL
+    def __init__(self, fail_id_on=None, fail_init_on=None, corrupt_on=None):
+        self.fail_id_on, self.fail_init_on, self.corrupt_on = fail_id_on, fail_init_on, corrupt_on
+        self.inited = self.destroyed = False
+        self.local = None
+
+    def comm_unique_id(self):
+        if rank == self.fail_id_on:
+            raise RuntimeError("librccl.so: cannot open shared object file")
+        return bytes([rank]) * 128
+
+    def comm_init(self, r, w, uid):
+        assert uid == bytes([0]) * 128 and (r, w) == (rank, world)      # rank 0's id reached everybody
+        if rank == self.fail_init_on:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.inited = True
+
+    def allgather(self, v):
+        out = [None] * world
+        td.all_gather_object(out, np.asarray(v, dtype=np.float64))
+        return np.stack(out)
+
+    def comm_destroy(self):
+        self.destroyed = True
+
+    def fit_exchange(self, count):
+        # what dsmgp_fit_exchange hands back: (world, count, 2), rank r's leaves in its first slots, the rest padding
+        mine = np.full((count, 2), -777.0)
+        mine[: self.local.shape[0]] = self.local
+        if rank == self.corrupt_on:
+            mine[0, 0] += 1.0
+        out = [None] * world
+        td.all_gather_object(out, mine)
+        return np.stack(out)
+
+
+owner = np.array([0, 1, 1, 0, 1])          # ragged: rank 0 owns 2 leaves, rank 1 owns 3 -> count = 3
+vals = np.stack([np.arange(5.0) * 1.5 - 2.0, np.array([0.0, 0.0, 7.0, 0.0, 0.0])], axis=1)
+
+# (1) without the opt-in and without force nothing collective happens and the path stays torch.distributed
+os.environ.pop("DSMGP_EXCHANGE", None)
+sh = pdist.Shard(owner, rank, world)
+assert sh.device_comm(StubCtx()) == "torch" and sh.comm_ctx is None
+
+# (2) the likeliest failure (ADVICE r3): rank 0 cannot load RCCL.  Nobody hangs, everybody ends on torch.distributed
+sh = pdist.Shard(owner, rank, world)
+c = StubCtx(fail_id_on=0)
+assert sh.device_comm(c, force=True) == "torch" and sh.comm_ctx is None and not c.inited
+
+# (3) one rank fails inside comm_init: the MIN of the verdicts takes all ranks back, the survivor destroys its communicator
+sh = pdist.Shard(owner, rank, world)
+c = StubCtx(fail_init_on=1)
+assert sh.device_comm(c, force=True) == "torch" and sh.comm_ctx is None
+assert c.destroyed
+
+# (4) all good: device path on every rank; slot padding to `count` and per-rank unpacking; first exchange cross-checked
+sh = pdist.Shard(owner, rank, world)
+c = StubCtx()
+assert sh.device_comm(c, force=True) == "rccl-device" and sh.comm_ctx is c and sh.verified is False
+c.local = vals[sh.local]
+got = sh.fit_exchange(c, vals[sh.local])
+assert np.array_equal(got, vals) and sh.verified is True and sh.exchange == "rccl-device"
+
+# (5) a device exchange that returns something else than torch.distributed on ONE rank: every rank drops the device path
+sh = pdist.Shard(owner, rank, world)
+c = StubCtx(corrupt_on=1)
+assert sh.device_comm(c, force=True) == "rccl-device"
+c.local = vals[sh.local]
+got = sh.fit_exchange(c, vals[sh.local])
+assert np.array_equal(got, vals) and sh.exchange == "torch" and sh.comm_ctx is None and c.destroyed
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_device_comm_setup_takes_every_rank_down_the_same_path(tmp_path):
+    """ADVICE r3 / VERDICT r3 #7: the world > 1 control flow of Shard.device_comm and Shard.fit_exchange over gloo with stub
+    contexts -- a rank that cannot reach RCCL, a rank whose init fails, the slot layout of the gathered (mll, info), and the
+    cross-check of the first device exchange against torch.distributed.  Every case must END (no mismatched collectives)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_DEVICE_COMM_WORKER.format(root=ROOT))
+    _run_two_ranks(script, 29735)
 
 
 def test_product_library_has_no_diagnostic_code():
