@@ -67,6 +67,9 @@ struct HostLog {
 
 enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 constexpr int FUSED_SHALLOW_STEPS = 4;   // block steps 0..4 (K <= 512) always run fused
+#ifndef DSMGP_SOLO_FACTOR
+#define DSMGP_SOLO_FACTOR 1.56             // time of one workgroup alone on a CU relative to its share of a co-resident pair
+#endif
 #ifndef DSMGP_DFIN_BACK
 #define DSMGP_DFIN_BACK (-1)             // < 0: the diagonal-block tasks of a full update launch go last; >= 0: that many rounds of
                                          // whole tiles before its tail pieces (diagnostic builds: A/B of the placement)
@@ -90,6 +93,9 @@ struct StepLists {
     // there has no `diag` task in that step
     std::vector<int> dpos, dfin_off;                         // size nsteps / nsteps+1
     DevBuf<DiagFinishTask> dfin;
+    // the diagonal blocks of the fused steps: factorised WITHOUT their inverse (only L_kk and the 16x16 diagonal inverses exist
+    // after a fit); dinv_complete_kernel over this list produces the rest of Dinv_k for whoever needs it (ensure_dinv)
+    DevBuf<DiagTask> dinvc;
     int nsteps = 0;
 };
 
@@ -173,14 +179,23 @@ struct UpdateSplitter {
     size_t tail_begin = 0;                     // add_step: index in `upd` where the tail pieces of the last step begin (its end if none)
     size_t max_slabs = 0;
 
+    // Cost model in units of one K column at the matrix pipe's full rate on one CU.  A CU holds two workgroups: two co-resident
+    // pieces of depth d share the pipe and are both done after 2 d; ONE piece alone on a CU cannot saturate it (a wave issues an
+    // f64 MFMA every ~100 cycles where the pipe takes one every 64: kernels.hpp, chol_diag_packed_body) and takes 1.56 d.
+    // (Until round 4 the model counted rounds over `ncu` slots at d per round: right for pairs, but it left a step of 129..255
+    // tiles unsplit -- one workgroup per CU at 64 % of the pipe -- where two half-depth pieces per CU take 36 % less time.)
     static int choose_split(int T, int K, int ncu) {
         if (T <= 0 || K < 512) return 1;
         const double C0 = 96.0, CRED = 64.0;
         const int chunks = K / KC;
         auto cost = [&](int S) {
             const double depth = (double)((chunks + S - 1) / S) * KC;
-            const double rounds = std::ceil((double)T * S / ncu);
-            return rounds * (depth + C0) + (S > 1 ? CRED : 0.0);
+            const long P = (long)T * S, slots = 2L * ncu;
+            const long full = P / slots, rem = P % slots;
+            double t = (double)full * 2.0 * (depth + C0);
+            if (rem > ncu) t += 2.0 * (depth + C0);
+            else if (rem > 0) t += DSMGP_SOLO_FACTOR * depth + C0;
+            return t + (S > 1 ? CRED : 0.0);
         };
         int best = 1;
         double bc = cost(1);
@@ -381,6 +396,11 @@ struct dsmgp_ctx {
     int solve_steps = 0;
     bool fitted = false;
     bool alpha_valid = false;       // alpha = L^-T z has been computed for the current factors (ensure_alpha)
+    bool dinv_complete = false;     // every Dinv_k holds the whole inverse for the current factors (ensure_dinv); a fit leaves the
+                                    // blocks of its fused steps with their 16x16 diagonal inverses only
+    DevBuf<DiagTask> dinvc_prefix;  // copied blocks of PREFIX leaves whose source factorised them in a fused step: completed right
+                                    // after the copy (the classic steps of the PREFIX phase solve against Dinv_k)
+    DevBuf<DiagTask> dinvc_fwd;     // blocks of the leaves whose z comes from the forward sweep (COPY, PREFIX): completed before it
 
     // prediction
     double* dXt = nullptr;
@@ -419,9 +439,11 @@ struct dsmgp_ctx {
 
     // gradients (built on first use)
     bool grad_ready = false;
+    std::vector<char> grad_active;  // dsmgp_set_gradient_leaves: leaves whose gradients are wanted (empty = all)
     double* arenaX = nullptr;       // Xt = L^-T per factor owner, npad x npad
     size_t arenaX_count = 0;
     double* slabG = nullptr;
+    size_t slabG_count = 0;
     DevBuf<TransTask> gtrans;
     std::vector<int> gupd_off, gred_off, gtrsm_off;
     DevBuf<TileTask> gupd, gtrsm;
@@ -510,9 +532,22 @@ void arena_put(dsmgp_ctx* c, double*& p) {
     p = nullptr;
 }
 
+// the task lists of the gradient pass (they depend on the set of active leaves); the L^-T arena stays
+void free_grad_lists(dsmgp_ctx* c) {
+    dev_free(c->gtrans.p);
+    dev_free(c->gupd.p);
+    dev_free(c->gtrsm.p);
+    dev_free(c->gred.p);
+    dev_free(c->gfrob.p);
+    dev_free(c->gdot.p);
+    dev_free(c->d_gpart);
+    c->grad_ready = false;
+}
+
 void free_grad(dsmgp_ctx* c) {
-    arena_put(c, c->arenaX);
     arena_put(c, c->slabG);
+    c->slabG_count = 0;
+    arena_put(c, c->arenaX);
     dev_free(c->gtrans.p);
     dev_free(c->gupd.p);
     dev_free(c->gtrsm.p);
@@ -547,10 +582,13 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.fdiag.p);
         dev_free(ph.ftile.p);
         dev_free(ph.dfin.p);
+        dev_free(ph.dinvc.p);
     }
     arena_put(c, c->slabF);
     dev_free(c->fwd.p);
     dev_free(c->bwd.p);
+    dev_free(c->dinvc_prefix.p);
+    dev_free(c->dinvc_fwd.p);
     free_grad(c);
     c->plan_ready = false;
     c->phase_ready = false;
@@ -594,6 +632,7 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.fdiag.p);
         dev_free(ph.ftile.p);
         dev_free(ph.dfin.p);
+        dev_free(ph.dinvc.p);
     }
     arena_put(c, c->slabJ);
     c->joint_ready = false;
@@ -738,6 +777,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         std::vector<FusedTask> ftile;
         std::vector<DiagFusedTask> fdiag;
         std::vector<DiagFinishTask> dfin;
+        std::vector<DiagTask> dinvc;
         S.dpos.assign(nsteps, 0);
         S.dfin_off.assign(nsteps + 1, 0);
         S.upd_off.assign(nsteps + 1, 0);
@@ -890,6 +930,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             fg.glda = ld;
                             fg.kid = lf.kid;
                             fdiag.push_back(fg);
+                            dinvc.push_back(g);
                         } else if (fin) {
                             DiagFinishTask ft{};
                             ft.d = g;
@@ -1023,6 +1064,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.ftile_off[nsteps] = (int)ftile.size();
         S.dfin_off[nsteps] = (int)dfin.size();
         if (int rc = dev_upload(c, S.dfin, dfin)) return rc;
+        if (int rc = dev_upload(c, S.dinvc, dinvc)) return rc;
         if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
         if (int rc = dev_upload(c, S.fdiag, fdiag)) return rc;
@@ -1223,6 +1265,40 @@ int build_plan(dsmgp_ctx* c) {
     }
     if (int rc = dev_upload(c, c->gram, gram)) return rc;
 
+    // Selective completions of Dinv_k inside fit! (the fused steps leave the 16x16 diagonal inverses only, kernels.hpp):
+    {
+        auto fused_in = [&](int ph, int k) { return k < (int)c->fused_step[ph].size() && c->fused_step[ph][k] == STEP_FUSED; };
+        auto block_task = [&](int l, int k) {
+            const LeafHost& lf = c->leaves[l];
+            const LeafDev& d = c->h_leaves[l];
+            DiagTask g{};
+            g.T = d.F + (size_t)k * TB + (size_t)k * TB * lf.npad;
+            g.Dinv = d.Dinv + (size_t)k * TB * TB;
+            g.info = d.info;
+            g.ld = lf.npad;
+            g.nvalid = std::max(0, std::min(TB, lf.n - k * TB));
+            g.row0 = k * TB;
+            return g;
+        };
+        std::vector<DiagTask> pre, fw;
+        std::vector<char> done(L, 0);
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.op == DSMGP_SHARE_PREFIX)      // its copied blocks: produced by the source's phase-0 steps
+                for (int k = 0; k < lf.kb; ++k)
+                    if (fused_in(0, k)) pre.push_back(block_task(l, k));
+            if (lf.op == DSMGP_SHARE_FULL) continue;
+            const int o = lf.owner;               // COPY: the source's buffers; PREFIX: its own
+            if (done[o]) continue;
+            done[o] = 1;
+            const LeafHost& lo = c->leaves[o];
+            const int pho = (int)c->leaf_group[o];
+            for (int k = lo.kb; k < lo.nb; ++k)
+                if (fused_in(pho, k)) fw.push_back(block_task(o, k));
+        }
+        if (int rc = dev_upload(c, c->dinvc_prefix, pre)) return rc;
+        if (int rc = dev_upload(c, c->dinvc_fwd, fw)) return rc;
+    }
     // The step lists of the factorisation are built on first use: those for the train rows alone by the first fit! without a
     // resident test set (ensure_phase), those with the test rows riding along by dsmgp_set_test -- a context that only ever
     // fits with its test set resident (the streaming mode: 20 million tile tasks over the groups of config 5) builds one set.
@@ -1455,9 +1531,23 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
     return 0;
 }
 
+// The whole inverse of every diagonal block (the fused steps of a fit leave L_kk and its 16x16 diagonal inverses only): what the
+// standalone prediction sweep, the gradients and the sweeps for alpha multiply with.  Queued on the context's stream.
+int ensure_dinv(dsmgp_ctx* c) {
+    if (c->dinv_complete) return 0;
+    StepLists* phases = c->last_fit_joint ? c->phaseJ : c->phase;
+    for (int ph = 0; ph < 2; ++ph)
+        if (phases[ph].dinvc.count)
+            dinv_complete_kernel<<<(int)phases[ph].dinvc.count, 256, DIAGP_LDS_BYTES, c->stream>>>(phases[ph].dinvc.p);
+    HIPCHK(c, hipGetLastError());
+    c->dinv_complete = true;
+    return 0;
+}
+
 // alpha = L^-T z by the backward block sweep on w = copy of z (z stays: the predictive mean is m + V^T z).
 int ensure_alpha(dsmgp_ctx* c) {
     if (c->alpha_valid) return 0;
+    if (int rc = ensure_dinv(c)) return rc;
     EventPair ev;
     HIPCHK(c, ev.init());
     HIPCHK(c, hipEventRecord(ev.a, c->stream));
@@ -1499,6 +1589,8 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(diag_fused_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dinv_complete_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     {
         hipDeviceProp_t prop;
@@ -1629,6 +1721,7 @@ int dsmgp_set_leaves(dsmgp_ctx* c, int32_t L, const int64_t* obs_ptr, const int6
     free_test(c);
     if (obs_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "obs_ptr[0] must be 0");
     c->leaves.assign(L, LeafHost{});
+    c->grad_active.clear();         // a new leaf table: gradients of every leaf again
     for (int l = 0; l < L; ++l) {
         const int64_t a = obs_ptr[l], b = obs_ptr[l + 1];
         if (b <= a) return fail(c, DSMGP_E_ARG, "leaf " + std::to_string(l) + " has no observations");
@@ -1775,14 +1868,19 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
                                    rows * sizeof(double), rows, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d.Dinv, s.Dinv, rows * TB * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
-    if (any_prefix)
+    if (any_prefix) {
+        if (c->dinvc_prefix.count)      // copied blocks that a fused step factorised: their whole inverse, for the classic steps below
+            dinv_complete_kernel<<<(int)c->dinvc_prefix.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_prefix.p);
         if (int rc = run_phase(c, phases[1], pt, true)) return rc;
+    }
     // 4. z = L^-1 (y - m) for the leaves whose factor came from another leaf (COPY, PREFIX); leaves factorised in
     //    full produced z during the factorisation.  alpha = L^-T z (src/gaussianprocess.jl:105) is NOT computed here:
     //    neither the log-marginal (z.z) nor the prediction (V^T z) needs it -- ensure_alpha() runs the backward sweep
     //    on first use (gradients, dsmgp_download_factor).
     {
         pt.begin(4);
+        if (c->dinvc_fwd.count)
+            dinv_complete_kernel<<<(int)c->dinvc_fwd.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_fwd.p);
         for (int k = 0; k < c->solve_steps; ++k) {
             const int n = c->fwd_off[k + 1] - c->fwd_off[k];
             if (n > 0) solve_fwd_kernel<<<n, 256, 0, c->stream>>>(c->fwd.p + c->fwd_off[k]);
@@ -1813,6 +1911,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     c->predicted = false;
     c->vt_valid = joint;
     c->last_fit_joint = joint;
+    c->dinv_complete = phases[0].dinvc.count == 0 && phases[1].dinvc.count == 0;
     return 0;
 }
 
@@ -2056,6 +2155,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     if (c->pgram.count) {
         const bool standalone = !c->vt_valid;
         if (standalone) {
+            if (int rc = ensure_dinv(c)) return rc;       // the panel solves of the sweep multiply with Dinv_k
             HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
             // K_tn tiles                                  (src/gaussianprocess.jl:133)
             pt.begin(6);
@@ -2263,9 +2363,29 @@ int build_grad_plan(dsmgp_ctx* c) {
     if (!c->pool_base && xTot * sizeof(double) + (size_t(2) << 30) > freeB)
         return fail(c, DSMGP_E_NOMEM, "gradients need " + std::to_string((xTot * 8) >> 20) + " MiB for L^-1, device has " +
                                           std::to_string(freeB >> 20) + " MiB free");
-    if (int rc = arena_get(c, c->arenaX, xTot)) return rc;
-    c->arenaX_count = xTot;
+    if (!c->arenaX || c->arenaX_count != xTot) {      // kept across changes of the active set (dsmgp_set_gradient_leaves)
+        arena_put(c, c->arenaX);
+        if (int rc = arena_get(c, c->arenaX, xTot)) return rc;
+        c->arenaX_count = xTot;
+    }
     auto Xt = [&](int l) { return c->arenaX + xoff[c->leaves[l].owner]; };
+    // Active leaves (dsmgp_set_gradient_leaves; default all).  A leaf's gradient needs tr K_y^-1 = |L^-1|_F^2 of its factor
+    // owner and, for the kernels with a length-scale term, the contraction tiles -- its own, or its source's where a COPY leaf
+    // shares them (grad_src): needC = leaves whose contraction is computed, needX = owners whose L^-T is built.
+    auto active = [&](int l) { return c->grad_active.empty() || c->grad_active[l] != 0; };
+    c->grad_src.assign(L, -1);
+    for (int l = 0; l < L; ++l) {
+        const LeafHost& lf = c->leaves[l];
+        if (lf.op == DSMGP_SHARE_COPY && lf.mean == c->leaves[lf.src].mean) c->grad_src[l] = lf.src;
+    }
+    std::vector<char> needC(L, 0), needX(L, 0);
+    for (int l = 0; l < L; ++l)
+        if (active(l)) {
+            needC[c->grad_src[l] >= 0 ? c->grad_src[l] : l] = 1;
+            needX[c->leaves[l].owner] = 1;
+        }
+    for (int l = 0; l < L; ++l)
+        if (needC[l]) needX[c->leaves[l].owner] = 1;
 
     std::vector<TransTask> trans;
     std::vector<FrobTask> frob;
@@ -2273,7 +2393,7 @@ int build_grad_plan(dsmgp_ctx* c) {
     int nsteps = 0;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
-        if (lf.owner != l) continue;
+        if (lf.owner != l || !needX[l]) continue;
         nsteps = std::max(nsteps, lf.nb);
         const LeafDev& d = c->h_leaves[l];
         for (int t = 0; t < lf.nb; ++t) {
@@ -2313,7 +2433,7 @@ int build_grad_plan(dsmgp_ctx* c) {
         double depth = 0.0;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
-            if (lf.owner != l || lf.nb <= k) continue;
+            if (lf.owner != l || lf.nb <= k || !needX[l]) continue;
             const LeafDev& d = c->h_leaves[l];
             for (int t = 0; t < k; ++t) {
                 double* tile = Xt(l) + (size_t)t * TB + (size_t)k * TB * lf.npad;
@@ -2350,8 +2470,11 @@ int build_grad_plan(dsmgp_ctx* c) {
         c->gred_off[nsteps] = (int)U.red.size();
         c->gtrsm_off[nsteps] = (int)trsm.size();
     }
-    if (U.max_slabs)
+    if (U.max_slabs * TB * TB > c->slabG_count) {
+        arena_put(c, c->slabG);
         if (int rc = arena_get(c, c->slabG, U.max_slabs * TB * TB)) return rc;
+        c->slabG_count = U.max_slabs * TB * TB;
+    }
     U.bind(c->slabG);
 
     // contraction tiles: every IsoSE leaf (COPY leaves too: their alpha is their own)
@@ -2364,7 +2487,6 @@ int build_grad_plan(dsmgp_ctx* c) {
     std::vector<GradTask> gd;
     std::vector<size_t> gblock;
     c->gdot_leaf.clear();
-    c->grad_src.assign(L, -1);
     bool any_ard = false;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
@@ -2375,10 +2497,7 @@ int build_grad_plan(dsmgp_ctx* c) {
         // Shared gradients (the idea of src/fit.jl:313-395: a leaf whose observation set equals its main leaf's takes
         // that leaf's gradients, `copygradients`): a COPY leaf has its source's factor and kernel id; with the same
         // ConstMean its alpha is the source's too, so its contraction is the source's and is not computed again.
-        if (lf.op == DSMGP_SHARE_COPY && lf.mean == c->leaves[lf.src].mean) {
-            c->grad_src[l] = lf.src;
-            continue;
-        }
+        if (c->grad_src[l] >= 0 || !needC[l]) continue;
         const LeafDev& d = c->h_leaves[l];
         for (int ib = 0; ib < lf.nb; ib += GS) {
             gblock.push_back(gd.size());           // one block per (leaf, GS tile rows): these tasks share their A panels
@@ -2432,6 +2551,27 @@ int build_grad_plan(dsmgp_ctx* c) {
 
 }  // namespace
 
+int dsmgp_set_gradient_leaves(dsmgp_ctx* c, const int32_t* active) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_gradient_leaves before set_leaves");
+    std::vector<char> m;
+    if (active) {
+        m.resize(c->L);
+        bool all = true;
+        for (int l = 0; l < c->L; ++l) {
+            m[l] = active[l] != 0;
+            all = all && m[l];
+        }
+        if (all) m.clear();
+    }
+    if (m != c->grad_active) {
+        HIPCHK(c, hipSetDevice(c->device));
+        free_grad_lists(c);
+        c->grad_active = std::move(m);
+    }
+    return 0;
+}
+
 int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     if (!c) return DSMGP_E_ARG;
     if (!c->fitted) return fail(c, DSMGP_E_STATE, "gradients before fit");
@@ -2444,6 +2584,7 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     }
     if (!c->grad_ready)
         if (int rc = build_grad_plan(c)) return rc;
+    if (int rc = ensure_dinv(c)) return rc;
     if (int rc = ensure_alpha(c)) return rc;
     c->timings[10] = 0.0;
     EventPair ev;
@@ -2525,6 +2666,7 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
         const double trPK = (ya - cc * aa) - (n - cc * trK[l]);
         double* g = grad_out + (size_t)l * stride;
         for (int j = 0; j < stride; ++j) g[j] = 0.0;
+        if (!c->grad_active.empty() && !c->grad_active[l]) continue;      // not asked for (dsmgp_set_gradient_leaves): zeros
         if (h.kind == DSMGP_KIND_ISO_SE) {
             const double sigma = std::exp(h.loghyp[1]);
             const double ell2 = std::exp(2.0 * h.loghyp[0]);

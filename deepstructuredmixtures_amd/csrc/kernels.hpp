@@ -1594,11 +1594,81 @@ struct PackedMap {
 };
 __constant__ const PackedMap PACKED{};
 
+// Phase 2 of the diagonal-block kernel (see chol_diag_packed_body): L^-1 from the packed image, whose off-diagonal slots hold
+// the blocks of L and whose diagonal slots hold L_JJ^-1; finished blocks go straight to Dinv.  No barrier, no image write.
+__device__ __forceinline__ void packed_inverse_phase(const DiagTask& tk, const double* S, int mytab, int JN) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    auto off = [&](int I, int K) { return __builtin_amdgcn_readlane(mytab, I * 8 + K); };
+    auto frag = [&](const double* blk, double (&f)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = blk[(4 * q + l4) * PLD + l15];
+    };
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    auto mma4 = [&](const double (&fa)[4], const double (&fb)[4]) {
+        d4 u = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0], fb[0], zero4, 0, 0, 0);
+        d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1], fb[1], zero4, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[2], fb[2], u, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[3], fb[3], v, 0, 0, 0);
+        return u + v;
+    };
+    // L^-1 = X, block column by block column WITHOUT barriers: X(K,K) = L_KK^-1 is in the image, and
+    //      X(I,K) = -L_II^-1 sum_{J=K..I-1} L(I,J) X(J,K) depends on the same column's earlier blocks only.  Wave w takes the
+    //      columns K = w and 7 - w and keeps its X blocks in registers: a 16x16 result in accumulator layout is the B operand
+    //      of the next product as it stands (register q = k-slab q), so the image is only read (blocks of L as A operands)
+    //      and every finished block goes straight to Dinv.  The sum runs on two accumulators (even and odd J): a dependent
+    //      f64 MFMA waits ~100 cycles for its predecessor where an independent one issues after 64.
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int K = half ? 7 - w : w;
+        if (K >= JN) continue;      // identity padding: the diagonal block is written above, everything below it is zero
+        const int m = (JN < 8 ? JN - 1 : 7) - K;     // rows I >= JN of the column are zero (and stay so in the zeroed arena)
+        d4 xr[8];
+        {   // X(K,K) = L_KK^-1 into accumulator layout: a product with the identity (reading it lane-per-column
+            // from the image would be a 8-way bank conflict)
+            double lk[4], id[4];
+            frag(S + off(K, K), lk);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) id[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
+            xr[0] = mma4(lk, id);
+        }
+#pragma unroll
+        for (int i = 1; i <= 7; ++i) {
+            if (i > m) break;
+            const int I = K + i;
+            d4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+            for (int s2 = 0; s2 < i; ++s2) {     // sum_J L(I,J) X(J,K)
+                double lb[4];
+                frag(S + off(I, K + s2), lb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (s2 & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[q], xr[s2][q], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[q], xr[s2][q], acc0, 0, 0, 0);
+                }
+            }
+            const d4 acc = acc0 + acc1;
+            double li[4], ta[4] = {acc[0], acc[1], acc[2], acc[3]};
+            frag(S + off(I, I), li);
+            xr[i] = -mma4(li, ta);
+            // register r holds X(row 16 I + l4 + 4 r, column 16 K + l15)
+            const gf64_ptr gD = AS_GLOBAL_F64(tk.Dinv + (size_t)(16 * I + l4) + (size_t)(16 * K + l15) * TB);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gD[4 * r] = xr[i][r];
+        }
+    }
+}
+
 // have_image: the caller has already put the lower blocks of the tile into the image (diag_fused_kernel: straight from
 // the accumulators of the tile's update); the barrier below makes them visible
 // (Rotating the wave roles with the workgroup index, so that the pivot chains of the two workgroups of a CU run on different
 // SIMDs, measured no difference: depth 4 0.0604 / 0.0593 / 0.0594 s without, 0.0596 / 0.0597 / 0.0586 s with, same box.)
-template <bool STAMP = false>
+// INVERSE = false (fused block steps since round 4): phase 2 is left out -- the tile tasks of a fused step solve by block
+// substitution against L_kk and the eight 16x16 inverses L_JJ^-1 this phase-1 leaves on the diagonal of Dinv_k
+// (tile_fused_body), and whoever needs the whole inverse later (standalone prediction, gradients, alpha, forward solves of
+// COPY / PREFIX leaves) gets it from dinv_complete_kernel: the same phase 2 on an image re-loaded from the tile and Dinv_k.
+template <bool STAMP = false, bool INVERSE = true>
 __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double* S, bool have_image,
                                                       unsigned long long* st = nullptr) {
     const int t = threadIdx.x, lane = t & 63;
@@ -1867,51 +1937,7 @@ __device__ __forceinline__ void chol_diag_packed_body(const DiagTask& tk, double
         }
     }
     stamp(19);
-    // ---- phase 2: L^-1 = X, block column by block column WITHOUT barriers: X(K,K) = L_KK^-1 is in the image, and
-    //      X(I,K) = -L_II^-1 sum_{J=K..I-1} L(I,J) X(J,K) depends on the same column's earlier blocks only.  Wave w takes the
-    //      columns K = w and 7 - w and keeps its X blocks in registers: a 16x16 result in accumulator layout is the B operand
-    //      of the next product as it stands (register q = k-slab q), so the image is only read (blocks of L as A operands)
-    //      and every finished block goes straight to Dinv.  The sum runs on two accumulators (even and odd J): a dependent
-    //      f64 MFMA waits ~100 cycles for its predecessor where an independent one issues after 64.
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int K = half ? 7 - w : w;
-        if (K >= JN) continue;      // identity padding: the diagonal block is written above, everything below it is zero
-        const int m = (JN < 8 ? JN - 1 : 7) - K;     // rows I >= JN of the column are zero (and stay so in the zeroed arena)
-        d4 xr[8];
-        {   // X(K,K) = L_KK^-1 into accumulator layout: a product with the identity (reading it lane-per-column
-            // from the image would be a 8-way bank conflict)
-            double lk[4], id[4];
-            frag(S + off(K, K), lk);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) id[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
-            xr[0] = mma4(lk, id);
-        }
-#pragma unroll
-        for (int i = 1; i <= 7; ++i) {
-            if (i > m) break;
-            const int I = K + i;
-            d4 acc0 = zero4, acc1 = zero4;
-#pragma unroll
-            for (int s2 = 0; s2 < i; ++s2) {     // sum_J L(I,J) X(J,K)
-                double lb[4];
-                frag(S + off(I, K + s2), lb);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (s2 & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[q], xr[s2][q], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[q], xr[s2][q], acc0, 0, 0, 0);
-                }
-            }
-            const d4 acc = acc0 + acc1;
-            double li[4], ta[4] = {acc[0], acc[1], acc[2], acc[3]};
-            frag(S + off(I, I), li);
-            xr[i] = -mma4(li, ta);
-            // register r holds X(row 16 I + l4 + 4 r, column 16 K + l15)
-            const gf64_ptr gD = AS_GLOBAL_F64(tk.Dinv + (size_t)(16 * I + l4) + (size_t)(16 * K + l15) * TB);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gD[4 * r] = xr[i][r];
-        }
-    }
+    if constexpr (INVERSE) packed_inverse_phase(tk, S, mytab, JN);
     stamp(20);
     if (w == 0 && lane == 0 && bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
 }
@@ -1921,6 +1947,38 @@ __global__ __launch_bounds__(256, 2) void chol_diag_packed_kernel(const DiagTask
     const DiagTask tk = tasks[blockIdx.x];
     chol_diag_packed_body(tk, S, false);
 }
+// The whole inverse of diagonal blocks that were factorised without it (fused block steps): the image is re-loaded -- blocks
+// of L from the tile, L_JJ^-1 from the diagonal of Dinv_k, exactly what phase 1 leaves behind -- and phase 2 runs on it.
+__global__ __launch_bounds__(256, 2) void dinv_complete_kernel(const DiagTask* __restrict__ tasks) {
+    extern __shared__ __attribute__((aligned(16))) double S[];
+    const DiagTask tk = tasks[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int mytab = PACKED.off[lane];
+    const int myblk = PACKED.lower[lane < 36 ? lane : 0];
+    const int mc = lane >> 3, mr = 2 * (lane & 7);
+    d2 v[9][2];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
+        const int I = e >> 4, K = e & 15;
+        const double* src = (I == K) ? tk.Dinv + (size_t)(16 * I + mr) + (size_t)(16 * K + mc) * TB
+                                     : tk.T + (size_t)(16 * I + mr) + (size_t)(16 * K + mc) * tk.ld;
+        const size_t ld = (I == K) ? (size_t)TB : (size_t)tk.ld;
+        v[q][0] = *AS_GLOBAL_D2(src);
+        v[q][1] = *AS_GLOBAL_D2(src + 8 * ld);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int e = __builtin_amdgcn_readlane(myblk, w + 4 * q);
+        double* dst = S + __builtin_amdgcn_readlane(mytab, (e >> 4) * 8 + (e & 15)) + mc * PLD + mr;
+        *reinterpret_cast<d2*>(dst) = v[q][0];
+        *reinterpret_cast<d2*>(dst + 8 * PLD) = v[q][1];
+    }
+    __syncthreads();
+    packed_inverse_phase(tk, S, mytab, (tk.nvalid + 15) >> 4);
+}
+
 #ifdef DSMGP_DIAG
 __global__ __launch_bounds__(256, 2) void chol_diag_packed_stamp_kernel(const DiagTask* __restrict__ tasks, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double S[];

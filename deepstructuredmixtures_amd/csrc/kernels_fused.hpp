@@ -27,6 +27,10 @@
 
 namespace dsmgp {
 
+#ifndef DSMGP_SOLVE_DUAL
+#define DSMGP_SOLVE_DUAL 1
+#endif
+
 struct FusedTask {
     const double* A;      // row panel F[i, 0:K] (or the rows of K_tn L^-T so far), ld lda
     const double* B;      // column panel F[k, 0:K], ld ldb
@@ -194,17 +198,22 @@ __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda,
 #undef FGLOAD
 }
 
-// The 36 lower 16x16 blocks of Dinv_k in LDS, compact, block rows from the LAST one up -- block (cb, jb), jb <= cb, at
-// 256 (lower_block_base(cb) + jb) -- each column-major with leading dimension 16: the MFMA operand read (16 rows per k
-// column, four k columns per lane group) touches 64 consecutive doubles, conflict-free.  36 x 256 doubles = the ring's
-// 73,728 bytes exactly.  The solve runs from the last block column to the first, so the first half of this order (18
-// blocks: block rows 7, 6 and three blocks of row 5) is all it needs to start.
-__host__ __device__ constexpr int lower_block_base(int cb) { return (7 - cb) * (10 + cb) / 2; }   // sum_{c > cb} (c + 1)
+// The solve of a fused tile task (round 4): block forward substitution against L_kk instead of a product with Dinv_k, so that
+// the diagonal-block task of a fused step can leave its whole inverse phase out (40 % of its MFMAs):
+//     X(:, cb) = ( C(:, cb) - sum_{jb < cb} X(:, jb) L(cb, jb)^T ) L(cb, cb)^-T ,      cb = 0 .. 7
+// with the 28 blocks L(cb, jb), jb < cb, of the factorised diagonal tile and the eight 16x16 inverses L(cb, cb)^-1 that phase
+// 1 of the diagonal-block kernel leaves on the diagonal of Dinv_k: the same 36 block products (144 MFMAs per 16 rows) as the
+// product with the inverse, and one rounding-error source fewer.  The 36 blocks sit in LDS, compact, block rows from the FIRST
+// one down -- block (cb, jb), jb <= cb, at 256 (lower_block_base(cb) + jb) -- each column-major with leading dimension 16: the
+// MFMA operand read (16 rows per k column, four k columns per lane group) touches 64 consecutive doubles, conflict-free.
+// 36 x 256 doubles = the ring's 73,728 bytes exactly.  The substitution runs from the first block column to the last, so the
+// first half of this order (18 blocks: block rows 0..4 and three blocks of row 5) is all it needs to start.
+__host__ __device__ constexpr int lower_block_base(int cb) { return cb * (cb + 1) / 2; }   // sum_{c < cb} (c + 1)
 struct LowerBlocks {
     unsigned char cb[36], jb[36];
     constexpr LowerBlocks() : cb{}, jb{} {
         int n = 0;
-        for (int c = 7; c >= 0; --c)
+        for (int c = 0; c < 8; ++c)
             for (int j = 0; j <= c; ++j) {
                 cb[n] = (unsigned char)c;
                 jb[n] = (unsigned char)j;
@@ -213,7 +222,7 @@ struct LowerBlocks {
     }
 };
 __constant__ const LowerBlocks LOWER_BLOCKS{};
-static_assert(lower_block_base(7) == 0 && lower_block_base(6) == 8 && lower_block_base(5) == 15 && lower_block_base(0) == 35, "block order");
+static_assert(lower_block_base(0) == 0 && lower_block_base(5) == 15 && lower_block_base(7) == 28, "block order");
 
 // acc <- -k(row, col) in the accumulator layout of gemm_mainloop_rowsplit (register q of acc[cb][rn] is the entry
 // (row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q)); the operations of gram_half_tile in its order (gram_accumulate /
@@ -270,18 +279,20 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    // Dinv_k's lower blocks of the block rows < NCB (all 36 for NCB = 8) go global (L2: the diagonal-block launch of this
-    // step wrote them) -> registers -> LDS; for NCB = 8 in two halves of 9 loads per thread, both issued when the product
-    // is done: the second lands under the first two block columns of the solve.  (Issuing the first half before the
-    // product, held in registers across it, measured the same: depth 4 0.0584 / 0.0598 / 0.0589 without against 0.0625 /
-    // 0.0596 / 0.0586 s with, same box, alternating.)  Thread t moves the doubles 2 (t & 127), + 1 of block B0 + 2 e + (t >> 7).
-    constexpr int B0 = lower_block_base(NCB - 1);         // LOWER_BLOCKS lists the block rows from the last one up
-    constexpr int NBLK = 36 - B0, NE = (NBLK + 1) / 2;
+    // The lower blocks of the block rows < NCB (all 36 for NCB = 8) go global (L2: the diagonal-block launch of this step wrote
+    // them) -> registers -> LDS: off-diagonal blocks from the factorised diagonal tile L_kk (it sits behind the B panel: column
+    // k1 of block row k), diagonal ones -- the inverses L(cb, cb)^-1 -- from Dinv_k.  For NCB = 8 in two halves of 9 loads per
+    // thread, both issued when the product is done: the second lands under the first five block columns of the solve.
+    // Thread t moves the doubles 2 (t & 127), + 1 of block 2 e + (t >> 7).
+    constexpr int NBLK = lower_block_base(NCB), NE = (NBLK + 1) / 2;
     const int dj = (t & 127) >> 3, di = 2 * (t & 7), dhalf = __builtin_amdgcn_readfirstlane(t >> 7);
+    const double* Lkk = tk.B + (size_t)tk.k1 * (size_t)tk.ldb;
     auto dinv_load = [&](int e) {
-        const int b = min(B0 + 2 * e + dhalf, 35);
+        const int b = min(2 * e + dhalf, NBLK - 1);
         const int cb = LOWER_BLOCKS.cb[b], jb = LOWER_BLOCKS.jb[b];
-        return *AS_GLOBAL_D2(tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB);
+        const double* src = (cb == jb) ? tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB
+                                       : Lkk + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * (size_t)tk.ldb;
+        return *AS_GLOBAL_D2(src);
     };
     RowsplitPrefetch pf;
     rowsplit_prefetch<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, pf);
@@ -303,7 +314,7 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
     }
     gemm_mainloop_rowsplit<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB, pf);   // acc = -C; ends on a barrier: the ring is free
     double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256; block b sits at 256 b
-    constexpr int NE1 = (NCB == 8) ? 9 : NE;            // first stage (NCB = 8: block rows 7, 6 and three blocks of row 5)
+    constexpr int NE1 = (NCB == 8) ? 9 : NE;            // first stage (NCB = 8: block rows 0..4 and three blocks of row 5)
     d2 dv[NE1];
 #pragma unroll
     for (int e = 0; e < NE1; ++e) dv[e] = dinv_load(e);
@@ -314,45 +325,67 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
     }
 #pragma unroll
     for (int e = 0; e < NE1; ++e)
-        if (B0 + 2 * e + dhalf < 36) *reinterpret_cast<d2*>(sD + (size_t)(B0 + 2 * e + dhalf) * 256 + 2 * (t & 127)) = dv[e];
+        if (2 * e + dhalf < NBLK) *reinterpret_cast<d2*>(sD + (size_t)(2 * e + dhalf) * 256 + 2 * (t & 127)) = dv[e];
     __syncthreads();
-    // -X = (-C) Dinv_k^T, column blocks from the right: X(:, cb) = sum_{jb <= cb} C(:, jb) Dinv(cb, jb)^T reads the blocks of
-    // C up to cb and is the last to read C(:, cb), whose registers it takes over.  The accumulators are the second operand
-    // as they stand: register q of C(:, jb) holds the columns 16 jb + l4 + 4 q = the k-slab q of the product.
+    // Block forward substitution on -C (the accumulators hold -C): block column cb reads the solved columns before it -- the
+    // accumulators ARE the second operand as they stand: register q of X(:, jb) holds the columns 16 jb + l4 + 4 q = the
+    // k-slab q of the product -- and takes over the registers of C(:, cb):
+    //     t = -C(:, cb) + sum_{jb < cb} X(:, jb) L(cb, jb)^T = -T ;   -X(:, cb) = t L(cb, cb)^-T
+    // The sum runs on two accumulators per row block (even and odd jb): a dependent f64 MFMA waits ~100 cycles for its
+    // predecessor where an independent one issues after 64.
     auto solve_block_column = [&](auto cbc) {
         constexpr int cb = decltype(cbc)::value;
         if constexpr (cb < NCB) {
-            d4 x[NRW];
+            d4 x0[NRW], x1[NRW];
 #pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) x[rn] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int rn = 0; rn < NRW; ++rn) {
+                x0[rn] = acc[cb][rn];
+                x1[rn] = (d4){0.0, 0.0, 0.0, 0.0};
+            }
 #pragma unroll
-            for (int jb = 0; jb <= cb; ++jb) {
+            for (int jb = 0; jb < cb; ++jb) {
                 const double* blk = sD + (lower_block_base(cb) + jb) * 256 + l15;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double a = blk[(4 * q + l4) * 16];
 #pragma unroll
-                    for (int rn = 0; rn < NRW; ++rn) x[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x[rn], 0, 0, 0);
+                    for (int rn = 0; rn < NRW; ++rn) {
+                        if (DSMGP_SOLVE_DUAL && (jb & 1)) x1[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x1[rn], 0, 0, 0);
+                        else x0[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x0[rn], 0, 0, 0);
+                    }
                 }
             }
+            d4 tt[NRW], y[NRW];
 #pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = -x[rn];     // X itself from here on
+            for (int rn = 0; rn < NRW; ++rn) {
+                tt[rn] = (DSMGP_SOLVE_DUAL && cb > 1) ? x0[rn] + x1[rn] : x0[rn];
+                y[rn] = (d4){0.0, 0.0, 0.0, 0.0};
+            }
+            const double* dblk = sD + (lower_block_base(cb) + cb) * 256 + l15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a = dblk[(4 * q + l4) * 16];
+#pragma unroll
+                for (int rn = 0; rn < NRW; ++rn) y[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt[rn][q], y[rn], 0, 0, 0);
+            }
+#pragma unroll
+            for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = -y[rn];     // X itself from here on
             __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later column blocks from piling up in registers
         }
     };
-    solve_block_column(std::integral_constant<int, 7>{});
-    solve_block_column(std::integral_constant<int, 6>{});
+    solve_block_column(std::integral_constant<int, 0>{});
+    solve_block_column(std::integral_constant<int, 1>{});
+    solve_block_column(std::integral_constant<int, 2>{});
+    solve_block_column(std::integral_constant<int, 3>{});
+    solve_block_column(std::integral_constant<int, 4>{});
     if (NCB == 8) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) *reinterpret_cast<d2*>(sD + (size_t)(2 * (9 + e) + dhalf) * 256 + 2 * (t & 127)) = dw[e];
         __syncthreads();
     }
     solve_block_column(std::integral_constant<int, 5>{});
-    solve_block_column(std::integral_constant<int, 4>{});
-    solve_block_column(std::integral_constant<int, 3>{});
-    solve_block_column(std::integral_constant<int, 2>{});
-    solve_block_column(std::integral_constant<int, 1>{});
-    solve_block_column(std::integral_constant<int, 0>{});
+    solve_block_column(std::integral_constant<int, 6>{});
+    solve_block_column(std::integral_constant<int, 7>{});
     // store: register q of acc[cb][rn] is X(row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q); zeros beyond NCB
     const unsigned lofs = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
     const size_t ldc = (size_t)tk.ldc;
@@ -553,7 +586,8 @@ __global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask*
         const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
         diag_fused_front<0>(tt, kp, D, S, blk);
     }
-    chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
+    chol_diag_packed_body<false, false>(ft.d, S, true);      // its first barrier publishes the image; no inverse phase: the
+                                                             // step's tile tasks substitute against L_kk (tile_fused_body)
 }
 
 // ---------------------------------------------------------------------------------------------

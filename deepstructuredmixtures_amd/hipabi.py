@@ -47,6 +47,7 @@ SIGNATURES = {
     "dsmgp_predict_fetch": (C.c_int, [_ctx, _dp, _dp]),
     "dsmgp_predict_leaves": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp, _dp, _dp]),
     "dsmgp_gradients": (C.c_int, [_ctx, _dp, C.c_int32]),
+    "dsmgp_set_gradient_leaves": (C.c_int, [_ctx, _ip]),
     "dsmgp_set_option": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "dsmgp_aggregate": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "dsmgp_aggregate_partial": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, _dp]),
@@ -252,6 +253,15 @@ class Context:
     def set_option(self, option, value):
         """include/dsmgp_hip.h DSMGP_OPT_*: OPT_ARD_LENGTHSCALE_GRADIENT = 1, OPT_FUSED_GRAM = 2, OPT_FUSED_STEPS = 3."""
         self._chk(self.lib.dsmgp_set_option(self.h, int(option), int(value)))
+
+    def set_gradient_leaves(self, active=None):
+        """Restrict `gradients` to the leaves with a true flag (None: all): the other rows come back as zeros."""
+        if active is None:
+            self._chk(self.lib.dsmgp_set_gradient_leaves(self.h, None))
+            return
+        a = np.ascontiguousarray(np.asarray(active) != 0, dtype=np.int32)
+        assert a.size == self.L
+        self._chk(self.lib.dsmgp_set_gradient_leaves(self.h, a.ctypes.data_as(_ip)))
 
     def gradients(self, stride):
         g = np.zeros((self.L, stride))
@@ -613,6 +623,12 @@ class MultiContext:
             tot = p if tot is None else tot + p
         return tot
 
+    def set_gradient_leaves(self, active=None):
+        self._upload()
+        a = None if active is None else np.asarray(active) != 0
+        for s, loc in zip(self.act, self.part):
+            s.set_gradient_leaves(None if a is None else a[loc])
+
     def gradients(self, stride):
         self._upload()
         res = self._each(lambda s: s.gradients(stride))
@@ -921,6 +937,10 @@ class StreamingContext:
         self.set_test(Xt, route_ptr, route_idx)
         self.predict_run()
         return self.predict_fetch()
+
+    def set_gradient_leaves(self, active=None):
+        """Streaming passes compute the gradients of every leaf of a group while its factors are resident: no mask."""
+        return None
 
     def gradients(self, stride):
         if self._res is None or self._res["grads"] is None or self._res["grads"].shape[1] < stride:

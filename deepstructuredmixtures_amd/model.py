@@ -513,12 +513,17 @@ def setparams(model, hyp):
 
 # ------------------------------------------------------------------------------------ gradients / training
 
-def updategradients(model):
+def updategradients(model, active=None):
     """`updategradients!(spn)` (`src/fit.jl:306-311`): per-leaf gradient vectors in the reference's order
     [dl..., ds, dnoise] (`src/gaussianprocess.jl:212-214`), computed on the device for the local leaves and
-    gathered.  Also stored on the leaves (kernel.dl / kernel.ds / dnoise) like the reference does."""
+    gathered.  Also stored on the leaves (kernel.dl / kernel.ds / dnoise) like the reference does.
+    `active` (one flag per leaf, default all): only those leaves' gradients are computed, the other rows are zero --
+    what `finetune!` needs, whose pass for leaf j weights leaf l's gradient by the overlap D[j, l] (`src/optimize.jl:101`)."""
     target = model.model if isinstance(model, GaussianProcess) else model
     stride = max(lf.kernel.nparams() + 1 for lf in target.leaves)
+    if len(target.shard.local) and (active is not None or getattr(target, "_grad_masked", False)):
+        target.ctx.set_gradient_leaves(None if active is None else np.asarray(active)[target.shard.local])
+        target._grad_masked = active is not None
     g_loc = target.ctx.gradients(stride) if len(target.shard.local) else np.zeros((0, stride))
     g = target.shard.gather_leaf_columns(g_loc[:, :stride])
     for lf, row in zip(target.leaves, g):
@@ -733,7 +738,7 @@ def finetune(model, optim=None, *, iterations=1000, lam=0.5, tau=0.05, verbose=F
             for j, lf in enumerate(model.leaves):
                 setparams(model, hyp[j])
                 fit(model, tau=tau)
-                updategradients(model)
+                updategradients(model, active=rows[j] != 0)       # every other leaf's term is multiplied by D[j, l] = 0
                 ell += float(model.leaf_mll[lf.leaf])                             # :51
                 hyp[j] = hyp[j] + optim.apply(hyp[j], grad_mll(model, leaf_weights=rows[j]))   # :54-56
             hist.append(ell)
@@ -745,6 +750,9 @@ def finetune(model, optim=None, *, iterations=1000, lam=0.5, tau=0.05, verbose=F
                 break
     finally:
         model.ctx.set_joint(True)
+        if getattr(model, "_grad_masked", False) and len(model.shard.local):
+            model.ctx.set_gradient_leaves(None)
+            model._grad_masked = False
     # every leaf keeps its own hyper-parameters: a kernel id per leaf, then one factorisation each (:74-77, :82-85)
     before = [(lf.kernelid, lf.logNoise, lf.kernel.loghyp().copy()) for lf in model.leaves]
     for j, lf in enumerate(model.leaves):

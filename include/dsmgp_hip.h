@@ -137,6 +137,12 @@ int dsmgp_scores(dsmgp_ctx* ctx, const double* y_test /* n_t */, double* out /* 
  *      grad_out[l*stride + j], j over [dl..., ds, dnoise] (reference order, src/gaussianprocess.jl:212-214),
  *      reproducing the reference's scaling and ArdSE dl == 0. */
 int dsmgp_gradients(dsmgp_ctx* ctx, double* grad_out, int32_t stride);
+/* Restricts dsmgp_gradients to the leaves with active[l] != 0 (NULL: every leaf again; a new leaf table resets it): the rows
+ * of the others come back as zeros, and neither L^-T nor the contraction tiles of leaves nobody asked for are computed (a
+ * COPY leaf's source and every active leaf's factor owner are included as needed).  finetune! weights leaf l's gradient by
+ * the overlap D[j, l] while it moves leaf j's vector (src/optimize.jl:101, src/finetuning.jl:34-57): all but the overlapping
+ * leaves are multiplied by zero there.  Changing the set rebuilds the task lists of the gradient pass (the L^-T arena stays). */
+int dsmgp_set_gradient_leaves(dsmgp_ctx* ctx, const int32_t* active /* L flags, or NULL */);
 /* Options.  DSMGP_OPT_ARD_LENGTHSCALE_GRADIENT: 0 (default) = ArdSE length-scale gradients exactly as the reference
  * computes them, i.e. identically zero (`precomp * K .* (p/ls[d])` parses as `(precomp*K) .* (p/ls[d])` and p has a zero
  * diagonal, src/kernels.jl:161: train!/finetune! never move ARD length-scales); 1 = the true derivative of the

@@ -70,11 +70,18 @@ class OracleContext:
         self.predict_run()
         return self.predict_fetch()
 
+    def set_gradient_leaves(self, active=None):
+        self._grad_active = None if active is None else np.asarray(active) != 0
+
     def gradients(self, stride):
         g = np.zeros((self.L, stride))
+        act = getattr(self, "_grad_active", None)
         for i, gp_ in enumerate(self.gps):
+            if act is not None and not act[i]:
+                continue                           # not asked for: zeros, and no work (the count below is what a test reads)
             v = gp_.grad()
             g[i, : v.size] = v
+            self.grad_evaluations = getattr(self, "grad_evaluations", 0) + 1
         return g
 
 

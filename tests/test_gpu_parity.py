@@ -415,6 +415,44 @@ def test_train_loop_follows_the_oracle_trajectory():
     assert hist[-1] > hist[0]
 
 
+def test_gradient_leaf_mask_computes_only_what_is_asked_for(ctx):
+    """dsmgp_set_gradient_leaves: the rows of the active leaves equal the unmasked gradients (to rounding: with
+    fewer tiles in a launch the K ranges are cut differently, so sums change order in the last bits), the others are zero,
+    and the pass does proportionally less -- also for an active COPY leaf whose source is inactive (its
+    source's contraction and factor are pulled in) and for an active PREFIX leaf."""
+    N, D, L = 6000, 3, 6
+    X, y, _ = regression_data(N, D, n_test=10, seed=915)
+    rng = np.random.default_rng(5)
+    sizes = [700, 900, 1300, 500, 900, 800]
+    obs = [np.sort(rng.choice(N, size=n, replace=False)) for n in sizes]
+    obs[4] = obs[1].copy()                                                  # COPY of leaf 1
+    tail = np.arange(obs[3][-1] + 1, min(N, obs[3][-1] + 301))
+    obs[5] = np.concatenate([obs[3], tail])                                 # leaf 3 is a prefix of leaf 5
+    op = np.array([0, 0, 0, 0, 1, 2], dtype=np.int32)
+    src = np.array([-1, -1, -1, -1, 1, 3], dtype=np.int32)
+    plen = np.array([0, 0, 0, 0, 0, obs[3].size], dtype=np.int64)
+    means = [float(np.mean(y[o])) for o in obs]
+    means[4] = means[1]
+    ctx.set_train(X, y)
+    ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, dtype=np.int32), means)
+    ctx.set_sharing(op, src, plen)
+    ctx.set_hyper(0, 0, [np.log(0.3), 0.1, np.log(0.2)])
+    ctx.fit()
+    full = ctx.gradients(3)
+    t_full = ctx.timings()["gradients"]
+    assert np.all(full != 0)
+    for active in ([0, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 1], [1, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0]):
+        ctx.set_gradient_leaves(active)
+        g = ctx.gradients(3)
+        a = np.array(active, dtype=bool)
+        assert np.allclose(g[a], full[a], rtol=1e-11, atol=0) and np.all(g[~a] == 0)
+    ctx.set_gradient_leaves([0, 0, 0, 1, 0, 0])                             # the smallest leaf alone: a fraction of the pass
+    ctx.gradients(3)
+    assert ctx.timings()["gradients"] < 0.6 * t_full
+    ctx.set_gradient_leaves(None)
+    assert np.array_equal(ctx.gradients(3), full)
+
+
 def test_finetune_follows_the_oracle_loop():
     """finetune! (src/finetuning.jl:8-87): L whole-tree fit! + updategradients! passes per iteration on the device,
     per-leaf hyper-vectors at the end (a kernel id per leaf); same history and vectors as the oracle's loop."""
@@ -631,7 +669,8 @@ def test_config4_headline_size_sampled_against_oracle_and_properties():
     # refit is idempotent (bit-reproducible schedule, no atomics); the test set is resident now, so both fits
     # below take the joint path (a different split-K schedule than the first fit: last-bit differences only)
     dsm.fit(model)
-    assert np.allclose(m1 := model.leaf_mll.copy(), model.leaf_mll, rtol=0) and np.allclose(m1, m0, rtol=1e-12)
+    m1 = model.leaf_mll.copy()
+    assert np.allclose(m1, m0, rtol=1e-12)                                # joint path against the first (plain) fit
     dsm.fit(model)
     assert np.array_equal(m1, model.leaf_mll)
     mu2, var2 = dsm.predict(model, Xt)
@@ -1374,7 +1413,9 @@ def test_set_sharing_after_set_test_drops_the_test_set(ctx):
     ctx.set_test(Xt, rptr, ridx)
     ctx.set_sharing([0, 1, 0], [-1, 0, -1], [0, 0, 0])          # leaf 1 = COPY of leaf 0: new plan, new addresses
     mll, info, _ = ctx.fit()
-    assert np.all(info == 0) and mll[0] == mll[1]
+    # (the COPY leaf's z comes from the forward sweep against Dinv_k, its source's from the substitution that rides in the
+    # factorisation: the same value to rounding, not to the bit)
+    assert np.all(info == 0) and abs(mll[0] - mll[1]) <= 1e-13 * abs(mll[0])
     with pytest.raises(hipabi.DsmgpError) as e:
         ctx.predict_run()
     assert "set_test" in str(e.value)
@@ -1420,15 +1461,15 @@ def test_mpmath_golden_across_a_tile_edge(ctx, golden_dir):
 def test_c_host_calls_the_abi(golden_dir, tmp_path):
     """tests/c_abi_smoke.c -- plain C99 against include/dsmgp_hip.h, no Python in the process -- runs create / set_train /
     set_leaves / set_hyper / fit / predict_leaves / download_factor / destroy on the mpmath-pinned n = 160 cases and
-    compares with their numbers itself (exit code 0).  Built by __graft_entry__.build(); a child process, so its HIP
-    context is its own."""
+    compares with their numbers itself (exit code 0).  Built by __graft_entry__.build() (or here, when that could not); a
+    child process, so its HIP context is its own."""
     import struct
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tests", "c_abi_smoke")
-    if not os.path.exists(exe):
+    if not os.path.exists(exe):       # build() tries, and does not fail the product build when it cannot: the failure belongs here
         import __graft_entry__
-        __graft_entry__.build()
+        __graft_entry__.build_c_host()
     for name, c in _edge_cases(golden_dir).items():
         n, D = c["X"].shape
         nt = c["Xt"].shape[0]

@@ -422,6 +422,190 @@ def test_device_comm_setup_takes_every_rank_down_the_same_path(tmp_path):
     _run_two_ranks(script, 29735)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# julia/DSMGPHip.jl cannot be executed here (no Julia in the image): what CAN be checked mechanically is that every ccall site
+# agrees with the prototype of include/dsmgp_hip.h, and that every reference symbol the file imports, extends or reads exists
+# in the reference's sources with the arity used.
+
+def _strip_c_comments(text):
+    import re
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def _header_prototypes():
+    """name -> (return type, [argument types]) of every function declared in include/dsmgp_hip.h, types normalised
+    (`const` and parameter names dropped: `const double* X` -> `double*`)."""
+    import re
+    text = _strip_c_comments(open(os.path.join(ROOT, "include", "dsmgp_hip.h")).read())
+    protos = {}
+    for m in re.finditer(r"\b((?:const\s+)?(?:int64_t|int|char|void|double)\s*\**)\s*(dsmgp_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+
+        def norm(t):
+            t = re.sub(r"\bconst\b", " ", t)
+            mm = re.match(r"\s*([A-Za-z_]\w*)\s*((?:\*\s*)*)", t)
+            return mm.group(1) + "*" * mm.group(2).count("*")
+        argl = [norm(a) for a in args.split(",")] if args.strip() not in ("", "void") else []
+        protos[name] = (norm(ret), argl)
+    return protos
+
+
+def _split_top(text):
+    """Split at top-level commas (parentheses, brackets and braces balanced)."""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _julia_ccalls(src):
+    """(name, return type, [argument types], number of values passed, line) of every `ccall(sym(:name), ret, (types...), values...)`."""
+    import re
+    calls = []
+    for m in re.finditer(r"ccall\(", src):
+        i = m.end()
+        depth, j = 1, i
+        while depth:                     # the matching parenthesis of ccall(
+            ch = src[j]
+            depth += ch == "("
+            depth -= ch == ")"
+            j += 1
+        parts = _split_top(src[i:j - 1])
+        mm = re.match(r"sym\(:(\w+)\)$", parts[0])
+        assert mm, f"ccall does not go through sym(:name): {parts[0]!r}"
+        assert parts[2].startswith("(") and parts[2].endswith(")"), parts[2]
+        types = _split_top(parts[2][1:-1])
+        calls.append((mm.group(1), parts[1], types, len(parts) - 3, src.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+_JL_TO_C = {"Int32": {"int32_t"}, "Int64": {"int64_t"}, "Cint": {"int"}, "Ptr{Float64}": {"double*"}, "Ref{Float64}": {"double*"},
+            "Ptr{Int32}": {"int32_t*"}, "Ptr{Int64}": {"int64_t*"}, "Ptr{Cvoid}": {"dsmgp_ctx*"}, "Ref{Ptr{Cvoid}}": {"dsmgp_ctx**"},
+            "Cstring": {"char*"}, "Ptr{UInt8}": {"char*"}}
+
+
+def test_julia_binding_matches_the_header():
+    """Every ccall site of julia/DSMGPHip.jl against include/dsmgp_hip.h: the symbol exists, the return type and every
+    argument type map onto the prototype's C types, and as many values are passed as types are listed."""
+    protos = _header_prototypes()
+    assert len(protos) >= 40 and "dsmgp_fit" in protos and protos["dsmgp_fit"] == ("int", ["dsmgp_ctx*", "double*", "int32_t*", "double*"])
+    src = open(os.path.join(ROOT, "julia", "DSMGPHip.jl")).read()
+    calls = _julia_ccalls(src)
+    assert len(calls) >= 15 and len({c[0] for c in calls}) >= 13
+    for name, ret, types, nvals, line in calls:
+        assert name in protos, f"julia/DSMGPHip.jl:{line}: {name} is not declared in include/dsmgp_hip.h"
+        cret, cargs = protos[name]
+        assert cret in _JL_TO_C[ret], f"line {line}: {name} returns {cret}, ccall says {ret}"
+        assert len(types) == len(cargs), f"line {line}: {name} takes {len(cargs)} arguments, ccall lists {len(types)}"
+        assert nvals == len(types), f"line {line}: {name}: {len(types)} types but {nvals} values"
+        for k, (jt, ct) in enumerate(zip(types, cargs)):
+            assert jt in _JL_TO_C, f"line {line}: {name} argument {k}: unknown Julia type {jt}"
+            assert ct in _JL_TO_C[jt], f"line {line}: {name} argument {k}: header has {ct}, ccall has {jt}"
+    # the constants the file hard-codes are the header's
+    hdr = open(os.path.join(ROOT, "include", "dsmgp_hip.h")).read()
+    import re
+    for cname, jval in (("DSMGP_SHARE_FULL", 0), ("DSMGP_SHARE_COPY", 1), ("DSMGP_SHARE_PREFIX", 2), ("DSMGP_AGG_MIXTURE", 0),
+                        ("DSMGP_AGG_POE", 1), ("DSMGP_AGG_GPOE", 2), ("DSMGP_AGG_RBCM", 3), ("DSMGP_KIND_ISO_SE", 0),
+                        ("DSMGP_KIND_ARD_SE", 1), ("DSMGP_KIND_ISO_LINEAR", 2)):
+        m = re.search(rf"#define\s+{cname}\s+(-?\d+)", hdr) or re.search(rf"\b{cname}\s*=\s*(-?\d+)", hdr)
+        assert m and int(m.group(1)) == jval, cname
+    assert re.search(r"SHARE_FULL, SHARE_COPY, SHARE_PREFIX = Int32\(0\), Int32\(1\), Int32\(2\)", src)
+    assert re.search(r"AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = Int32\(0\), Int32\(1\), Int32\(2\), Int32\(3\)", src)
+    assert "kind(::IsoSE) = Int32(0)" in src and "kind(::ArdSE) = Int32(1)" in src and "kind(::IsoLinear) = Int32(2)" in src
+
+
+def test_julia_binding_names_exist_in_the_reference():
+    """Build container only (the reference does not travel): every name the binding imports from DeepStructuredMixtures is
+    defined there, every method it extends exists with that many positional arguments, and every field it reads off a
+    reference struct is declared in one (`src/fit.jl:71,294,306`, `src/gaussianprocess.jl:82,131,163,185`,
+    `src/common.jl:304-307`)."""
+    import glob
+    import re
+    refdir = "/root/reference/src"
+    if not os.path.isdir(refdir):
+        pytest.skip("reference sources are not on this machine")
+    ref = "\n".join(open(f, encoding="utf-8").read() for f in sorted(glob.glob(os.path.join(refdir, "*.jl"))))
+    src = open(os.path.join(ROOT, "julia", "DSMGPHip.jl"), encoding="utf-8").read()
+    ident = r"[A-Za-z_∇∂ℓσϵμ][\w!∇∂ℓσϵμ²]*"
+
+    def defined(name):
+        n = re.escape(name)
+        return bool(re.search(rf"(?m)^\s*(?:@inline\s+)?function\s+(?:\w+\.)?{n}\s*[({{]", ref) or re.search(rf"(?m)^\s*(?:@inline\s+)?(?:\w+\.)?{n}\([^)\n]*\)\s*(?:where[^=\n]*)?=", ref)
+                    or re.search(rf"(?m)^\s*(?:mutable\s+)?struct\s+{n}\b", ref) or re.search(rf"(?m)^\s*abstract\s+type\s+{n}\b", ref)
+                    or re.search(rf"(?m)^\s*const\s+{n}\b", ref))
+
+    imported = []
+    for m in re.finditer(r"(?m)^(?:import|using) DeepStructuredMixtures: ((?:[^\n]*,\s*\n)*[^\n]*)", src):
+        imported += [t.strip() for t in m.group(1).replace("\n", " ").split(",") if t.strip()]
+    assert len(imported) >= 20
+    third_party = {"children", "logweights", "BiDict"}        # SumProductNetworks.jl / the package's own re-exports (SURVEY section 2)
+    for name in imported:
+        assert defined(name) or name in third_party, f"{name} is imported from DeepStructuredMixtures but not defined in /root/reference/src"
+    assert re.search(r"BiDict", ref) and re.search(r"\bchildren\(", ref) and re.search(r"\blogweights\b", ref)
+
+    def positional_arity(sig):
+        args = sig.split(";")[0]
+        return len([a for a in _split_top(args) if a])
+
+    def ref_arities(name):
+        out = set()
+        for m in re.finditer(rf"(?m)^\s*(?:@inline\s+)?function\s+(?:\w+\.)?{re.escape(name)}\s*\(", ref):
+            i = m.end()
+            depth, j = 1, i
+            while depth:
+                depth += ref[j] == "("
+                depth -= ref[j] == ")"
+                j += 1
+            out.add(positional_arity(ref[i:j - 1]))
+        for m in re.finditer(rf"(?m)^\s*(?:@inline\s+)?(?:\w+\.)?{re.escape(name)}\(([^)\n]*)\)\s*(?:where[^=\n]*)?=", ref):
+            out.add(positional_arity(m.group(1)))
+        return out
+
+    extended = re.search(r"(?m)^import DeepStructuredMixtures: ([^\n]*)", src).group(1)
+    extended = [t.strip() for t in extended.split(",")]
+    assert set(extended) >= {"fit!", "fit_naive!", "update_cholesky!", "prediction", "mll", "predict", "updategradients!", "∇mll"}
+    for name in extended:
+        mine = set()
+        for m in re.finditer(rf"(?m)^(?:function\s+)?{re.escape(name)}\(", src):
+            i = m.end()
+            depth, j = 1, i
+            while depth:
+                depth += src[j] == "("
+                depth -= src[j] == ")"
+                j += 1
+            mine.add(positional_arity(src[i:j - 1]))
+        assert mine, f"{name} is imported for extension but never defined"
+        theirs = ref_arities(name)
+        assert mine <= theirs, f"{name}: the binding defines methods of {sorted(mine)} positional arguments, the reference has {sorted(theirs)}"
+
+    # fields read off reference structs: declared as a field of some struct of the reference
+    fields = set()
+    for m in re.finditer(r"(?ms)^\s*(?:mutable\s+)?struct\s+[^\n]*\n(.*?)^\s*end", ref):
+        for line in m.group(1).splitlines():
+            mm = re.match(rf"\s*({ident})\s*(?:::|$)", line)
+            if mm:
+                fields.add(mm.group(1))
+    own = set(re.findall(r"(?m)^\s+(\w+)::", src[src.index("mutable struct Session"):src.index("const SESSIONS")]))
+    base = {"jl", "so", "py", "md", "e", "c", "attach!", "DSMGPHip", "value"}     # file suffixes / doc text / Ref().value-like wrappers
+    qualified = set(re.findall(rf"\bDeepStructuredMixtures\.({ident})", src))      # module-qualified calls: functions, not fields
+    for name in qualified:
+        assert defined(name), f"DeepStructuredMixtures.{name} is called but not defined in /root/reference/src"
+    used = set(re.findall(rf"(?<![\w)])(?:{ident})\.({ident})", src)) - qualified
+    assert {"value"} <= fields or re.search(r"\.value\b", ref)                     # the reference's own parameter wrapper
+    unknown = sorted(f for f in used if f not in fields and f not in own and f not in base)
+    assert not unknown, f"fields the binding reads that no struct of the reference declares: {unknown}"
+
+
 def test_product_library_has_no_diagnostic_code():
     """ablation / stamp / probe variants live only in the -DDSMGP_DIAG build; the product library
     exports none of their symbols and reads no tuning variables from the environment."""
@@ -543,6 +727,11 @@ def test_finetune_follows_the_reference_loop():
     assert len({lf.kernelid for lf in m.leaves}) == m.L                     # every leaf keeps its own vector
     assert np.std(got[:, 0]) > 0                                            # and they did move apart
     assert np.allclose(m.leaf_mll, [g.mll() for g in gps], rtol=1e-9)       # final per-leaf factorisations
+    # pass j asks only for the gradients of the leaves that overlap leaf j (D[j, l] != 0) -- the same history
+    # as above with a fraction of the per-leaf gradient evaluations of L passes x L leaves per iteration
+    nnz = sum(int(np.count_nonzero(np.asarray(m.D[j, :]))) for j in range(m.L))
+    assert m.ctx.grad_evaluations == 3 * nnz and nnz < m.L * m.L // 2
+    assert getattr(m.ctx, "_grad_active", None) is None                     # the mask does not outlive finetune!
     with pytest.raises(NotImplementedError):
         kv = dsm.buildDSMGP(X, y, 2, 3, M=40, kernel=[dsm.IsoSE(0.0, 0.0), dsm.IsoLinear(0.0)], fit_now=False,
                             ctx=OracleContext(), seed=6)

@@ -14,6 +14,7 @@ ap.add_argument("--N", type=int, default=500_000)
 ap.add_argument("--D", type=int, default=16)
 ap.add_argument("--M", type=int, default=500)
 ap.add_argument("--train", action="store_true")
+ap.add_argument("--iterations", type=int, default=1, help="train! iterations to time (with --train)")
 ap.add_argument("--host-only", action="store_true", help="build the tree and schedule only (no GPU)")
 args = ap.parse_args()
 
@@ -28,11 +29,23 @@ print(f"# built in {time.perf_counter() - t0:.1f} s: {model.L} leaves, n = {int(
 if args.host_only:
     sys.exit(0)
 out = {"config": f"N={args.N} D={args.D} M={args.M} depth 2, [IsoSE, IsoLinear], {model.L} leaves, n max {int(n.max())}"}
-if args.train:                        # one train! iteration: fit + gradients per leaf group, ADAM step, final fit
+if args.train:                        # train! iterations (src/optimisers.jl:40-80): fit + gradients per leaf group, ADAM step; then the final fit
+    class TimedADAM(dsm.ADAM):        # the optimiser is applied once per iteration: its calls are the iteration boundaries
+        stamps = []
+
+        def apply(self, hyp, g):
+            TimedADAM.stamps.append(time.perf_counter())
+            print(f"# iteration {len(TimedADAM.stamps)} done at {TimedADAM.stamps[-1] - t0:.1f} s", flush=True)
+            return super().apply(hyp, g)
     t0 = time.perf_counter()
-    dsm.train(model, dsm.ADAM(), iterations=1)
-    out["train_1_iteration_plus_final_fit_s"] = time.perf_counter() - t0
-    print(f"# train: {out['train_1_iteration_plus_final_fit_s']:.1f} s", flush=True)
+    _, hist = dsm.train(model, TimedADAM(), iterations=args.iterations, earlystop=10 ** 9)
+    t_end = time.perf_counter()
+    st = [t0] + TimedADAM.stamps
+    out["train_iteration_s"] = [round(b - a, 2) for a, b in zip(st[:-1], st[1:])]
+    out["final_fit_s"] = round(t_end - st[-1], 2)
+    out["train_total_s"] = round(t_end - t0, 2)
+    out["mll_history"] = [float(v) for v in hist]
+    print(f"# train: iterations {out['train_iteration_s']} s, final fit {out['final_fit_s']} s", flush=True)
     out["passes"] = getattr(model.ctx, "passes", None)
     g_ = getattr(model.ctx, "groups", None)     # (train() restores the plain streaming context when it is done)
     out["groups"] = [int(len(g)) for g in g_] if g_ is not None else None

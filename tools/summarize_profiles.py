@@ -30,8 +30,10 @@ def newest(pattern):
     return max(m, key=os.path.getmtime)
 
 
-base = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_round"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+base = args[0] if len(args) > 0 else "gpurun_out/prof_round"
+tag = args[1] if len(args) > 1 else "r04"
+TRAFFIC_ONLY = "--traffic-only" in sys.argv      # on the GPU box, between the PMC passes and the stats pass (tools/profile_round.sh)
 os.makedirs("profiles", exist_ok=True)
 
 
@@ -51,6 +53,44 @@ def bench_line(log):
 
 def short(name):
     return name.split("(")[0]
+
+
+def write_traffic(per_step):
+    """HBM bytes per update launch of the last fit from the FETCH_SIZE / WRITE_SIZE passes of the headline run."""
+    def update_launches(d, counter):
+        """tile_gemm dispatches of the last TIMED-kind step: the update launches run as tile_gemm_kernel_v2<false, 0, *>
+        while per-launch timing is on (warm-up, timed steps, the breakdown step) and as <false, 2, *> in bench.py's untimed
+        standalone fit/predict extra, so the last dispatches of that name are one whole joint fit (the shallow block steps
+        run as tile_fused_kernel: counted in launches_per_step, not in this kernel's dispatches)."""
+        rows = [r for r in rows_of(d) if r["Counter_Name"] == counter and "tile_gemm_kernel_v2<false, 0," in r["Kernel_Name"]]
+        per_fit = len(rows) // max(1, int(round(len(rows) / per_step)))
+        return rows[-per_fit:]
+
+    fu, wu = update_launches("n100k_pmc2", "FETCH_SIZE"), update_launches("n100k_pmc3", "WRITE_SIZE")
+    fetch = sum(float(r["Counter_Value"]) for r in fu) * 1024 * 2
+    write = sum(float(r["Counter_Value"]) for r in wu) * 1024
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "bench.py", "include", "deepstructuredmixtures_amd/csrc"],
+                               capture_output=True, text=True).stdout.strip()
+        commit = (commit or "?") + ("+uncommitted" if dirty else "")
+    except Exception:
+        commit = "?"
+    res = {"source_stamp": bench.source_stamp(), "commit": commit,
+           "kernel": "tile_gemm_kernel_v2<false, 0, false>: update launches of the last fit (test rows riding along)",
+           "launches": len(fu), "fetch_bytes_total": fetch, "write_bytes_total": write,
+           "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)),
+           "note": "FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024 over the update launches of one fit; separate --pmc "
+                   "passes of `python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline`, taken BEFORE the stats pass of the same "
+                   "profile round (tools/profile_round.sh), whose bench line quotes this figure"}
+    json.dump(res, open(f"profiles/{tag}_update_kernel_traffic.json", "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if TRAFFIC_ONLY:
+    pl = bench_line(f"{base}/n100k_pmc2/bench.log")
+    write_traffic(int(pl["roofline"]["launches_per_step"]))
+    sys.exit(0)
 
 
 for run in ("n100k", "depth4", "train"):
@@ -101,32 +141,4 @@ for run in ("n100k", "depth4", "train"):
             print("  ", k[:70], {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()})
 
     if run == "n100k" and line is not None:
-        per_step = int(line["roofline"]["launches_per_step"])
-
-        def update_launches(d, counter):
-            """tile_gemm dispatches of the last TIMED-kind step: the update launches run as tile_gemm_kernel_v2<false, 0, *>
-            while per-launch timing is on (warm-up, timed steps, the breakdown step) and as <false, 2, *> in bench.py's untimed
-            standalone fit/predict extra, so the last dispatches of that name are one whole joint fit (the shallow block steps
-            run as tile_fused_kernel: counted in launches_per_step, not in this kernel's dispatches)."""
-            rows = [r for r in rows_of(d) if r["Counter_Name"] == counter and "tile_gemm_kernel_v2<false, 0," in r["Kernel_Name"]]
-            per_fit = len(rows) // max(1, int(round(len(rows) / per_step)))
-            return rows[-per_fit:]
-
-        fu, wu = update_launches("n100k_pmc2", "FETCH_SIZE"), update_launches("n100k_pmc3", "WRITE_SIZE")
-        fetch = sum(float(r["Counter_Value"]) for r in fu) * 1024 * 2
-        write = sum(float(r["Counter_Value"]) for r in wu) * 1024
-        try:
-            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-            dirty = subprocess.run(["git", "status", "--porcelain", "--", "bench.py", "include", "deepstructuredmixtures_amd/csrc"],
-                                   capture_output=True, text=True).stdout.strip()
-            commit = commit + ("+uncommitted" if dirty else "")
-        except Exception:
-            commit = "?"
-        res = {"source_stamp": bench.source_stamp(), "commit": commit,
-               "kernel": "tile_gemm_kernel_v2<false, 0, false>: update launches of the last fit (test rows riding along)",
-               "launches": len(fu), "fetch_bytes_total": fetch, "write_bytes_total": write,
-               "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)),
-               "note": "FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024 over the update launches of one fit; separate --pmc "
-                       "passes of `python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline` (tools/profile_round.sh)"}
-        json.dump(res, open(f"profiles/{tag}_update_kernel_traffic.json", "w"), indent=1)
-        print(json.dumps(res, indent=1))
+        write_traffic(int(line["roofline"]["launches_per_step"]))
