@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of library builds inside ONE gpurun call, alternating over ROUNDS rounds (default 2):
-#   WHAT="h s8 s4 d4 c23" tools/ab_libs.sh TAG:lib.so [TAG:lib.so ...]
+#   WHAT="h s8 s4 d4 c23" tools/ab_libs.sh TAG:lib.so[:bench args] [TAG:lib.so[:bench args] ...]
 # h = headline, s8 = shards 0/8 and 5/8 of an 8-rank job, s4 = shard 0/4, d4 = depth 4, c23 = configs 2 and 3.
 # One line per run on stdout; the product library is restored at the end.
 set -e
@@ -15,15 +15,15 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('$2', round(d['value'],4), {k: round(v*1e3,2) for k, v in d['device_seconds_per_step'].items() if v > 0.0005})"; }
 for round in $(seq 1 ${ROUNDS:-2}); do
   for spec in "$@"; do
-    tag="${spec%%:*}"; lib="${spec#*:}"
+    tag="${spec%%:*}"; rest="${spec#*:}"; lib="${rest%%:*}"; xa=""; if [ "$rest" != "$lib" ]; then xa="${rest#*:}"; fi
     cp "$lib" /tmp/lib_cur.so && cp /tmp/lib_cur.so $pk/libdsmgp_hip.so
     for w in $WHAT; do
       case $w in
-        h) python bench.py --steps 3 --warmup 2 --no-cpu-baseline > $o/h_${tag}_$round.json 2> $o/err.txt; line $o/h_${tag}_$round.json "$tag headline";;
-        s8) for sh in 0/8 5/8; do python bench.py --steps 3 --warmup 2 --no-cpu-baseline --simulate-shard $sh > $o/s_${tag}_$round.json 2> $o/err.txt; line $o/s_${tag}_$round.json "$tag shard $sh"; done;;
-        s4) python bench.py --steps 3 --warmup 2 --no-cpu-baseline --simulate-shard 0/4 > $o/s_${tag}_$round.json 2> $o/err.txt; line $o/s_${tag}_$round.json "$tag shard 0/4";;
-        d4) python bench.py --config dsmgp_n100k_d8_depth4 --steps 3 --warmup 2 --no-cpu-baseline > $o/d4_${tag}_$round.json 2> $o/err.txt; line $o/d4_${tag}_$round.json "$tag depth4";;
-        c23) python tools/run_config3.py 2>&1 | sed "s/^/$tag /";;
+        h) python bench.py --steps 3 --warmup 2 --no-cpu-baseline $xa > $o/h_${tag}_$round.json 2> $o/err.txt; line $o/h_${tag}_$round.json "$tag headline";;
+        s8) for sh in 0/8 5/8; do python bench.py --steps 3 --warmup 2 --no-cpu-baseline $xa --simulate-shard $sh > $o/s_${tag}_$round.json 2> $o/err.txt; line $o/s_${tag}_$round.json "$tag shard $sh"; done;;
+        s4) python bench.py --steps 3 --warmup 2 --no-cpu-baseline $xa --simulate-shard 0/4 > $o/s_${tag}_$round.json 2> $o/err.txt; line $o/s_${tag}_$round.json "$tag shard 0/4";;
+        d4) python bench.py --config dsmgp_n100k_d8_depth4 --steps 3 --warmup 2 --no-cpu-baseline $xa > $o/d4_${tag}_$round.json 2> $o/err.txt; line $o/d4_${tag}_$round.json "$tag depth4";;
+        c23) DSMGP_RUN_ARGS="$xa" python tools/run_config3.py 2>&1 | sed "s/^/$tag /";;
       esac
     done
   done

@@ -14,6 +14,13 @@ def timeit(f, n=5):
 
 X, y, Xt = dsm.regression_data(4096, 4, seed=20202)
 gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1))
+xa = os.environ.get("DSMGP_RUN_ARGS", "")      # A/B runs (tools/ab_libs.sh): the same switches as bench.py
+def options(ctx):
+    if "--no-one-launch" in xa:
+        ctx.set_option(dsm.hipabi.OPT_ONE_LAUNCH, 0)
+    if "--no-diag-ahead" in xa:
+        ctx.set_option(dsm.hipabi.OPT_DIAG_IN_UPDATE, 0)
+options(gp.model.ctx)
 def step2():
     dsm.update_cholesky(gp); return dsm.prediction(gp, Xt)
 print(f"config 2 (single GP n=4096, n_t={Xt.shape[0]}): {timeit(step2) * 1e3:.2f} ms per update_cholesky! + prediction")
@@ -22,6 +29,7 @@ X, y, Xt = dsm.regression_data(50_000, 8, seed=20203)
 m = dsm.buildPoE(X, y, 8, M=200, kernel=dsm.ArdSE(np.log(np.full(8, 0.3)), 0.0), logNoise=np.log(0.1),
                  meanFun=dsm.ConstMean(float(np.mean(y))), seed=20203)
 n = np.array([lf.nobs for lf in m.leaves])
+options(m.ctx)
 def step3():
     dsm.fit(m); return dsm.predict(m, Xt)
 t = timeit(step3)
