@@ -293,10 +293,8 @@ def main():
     ap.add_argument("--unfused-gram", action="store_true",
                     help="diagnostic: every Gram tile through memory first (DSMGP_OPT_FUSED_GRAM = 0), for A/B runs")
     ap.add_argument("--no-fused-steps", action="store_true", help="diagnostic: DSMGP_OPT_FUSED_STEPS = 0, for A/B runs")
-    ap.add_argument("--no-one-launch", action="store_true",
-                    help="diagnostic: DSMGP_OPT_ONE_LAUNCH = 0 (update / reduce / panel solve launches per step), for A/B runs")
     ap.add_argument("--no-diag-ahead", action="store_true",
-                    help="diagnostic: DSMGP_OPT_DIAG_IN_UPDATE = 0 (with --no-one-launch: a diagonal-block launch per step)")
+                    help="diagnostic: DSMGP_OPT_DIAG_IN_UPDATE = 0 (a diagonal-block launch per classic step), for A/B runs")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
@@ -383,8 +381,6 @@ def main():
         ctx.set_option(dsm.hipabi.OPT_FUSED_GRAM, 0)
     if args.no_fused_steps:
         ctx.set_option(dsm.hipabi.OPT_FUSED_STEPS, 0)
-    if args.no_one_launch:
-        ctx.set_option(dsm.hipabi.OPT_ONE_LAUNCH, 0)
     if args.no_diag_ahead:
         ctx.set_option(dsm.hipabi.OPT_DIAG_IN_UPDATE, 0)
     if args.mode == "train":

@@ -65,7 +65,7 @@ struct HostLog {
     }
 };
 
-enum { STEP_CLASSIC = 0, STEP_FUSED = 1, STEP_ONE = 2 };
+enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 #ifndef DSMGP_FUSED_SHALLOW
 #define DSMGP_FUSED_SHALLOW 4
 #endif
@@ -99,11 +99,6 @@ struct StepLists {
     // the diagonal blocks of the fused steps: factorised WITHOUT their inverse (only L_kk and the 16x16 diagonal inverses exist
     // after a fit); dinv_complete_kernel over this list produces the rest of Dinv_k for whoever needs it (ensure_dinv)
     DevBuf<DiagTask> dinvc;
-    // one-launch steps (STEP_ONE): step k runs stask[stask_off[k] .. stask_off[k+1]) behind its DiagFinishTasks (dfin) in one
-    // grid; leaves without a finished bulk tile from the step before get their diagonal block from fdiag first
-    std::vector<int> stask_off;
-    DevBuf<StepTask> stask;
-    DevBuf<unsigned> sync;                                   // flags of the DiagFinishTasks and tickets of the split tiles: zeroed per phase
     int nsteps = 0;
 };
 
@@ -368,20 +363,22 @@ struct dsmgp_ctx {
     DevBuf<GramTask> gram;          // Gram launch of fit!: every lower tile, or (fused) the tiles no update task writes
     bool fuse_gram = true;          // update tasks of fit! evaluate the Gram values of their tile themselves (TileTask.gram)
     bool fuse_steps = true;         // block steps with more diagonal blocks than CUs run as two fused launches (kernels_fused.hpp)
-    bool one_launch = false;        // classic-eligible steps run as ONE launch each (STEP_ONE, step_kernel): measured slower, opt-in
     bool diag_in_update = true;     // classic steps: the diagonal tile's update runs one step ahead and its factorisation rides in
                                     // the update launch (DiagFinishTask, kernels_fused.hpp)
     // per phase and block step (decided by build_plan):
     //   STEP_CLASSIC    update (all tiles, split-K) / reduce / diagonal block / panel solve launches, one after the other
     //   STEP_FUSED      many leaves: diag_fused_kernel, then tile_fused_kernel, from the kernel function (kernels_fused.hpp)
-    //   STEP_ONE        few leaves: ONE launch (step_kernel, kernels_fused.hpp) -- the diagonal blocks run one step ahead and sit at
-    //                   the front of the grid, every tile below is updated, solved and written once by one task (or by the last
-    //                   of its K-pieces to arrive), which waits inside the launch for its leaf's diagonal block
     // (A third, lookahead schedule -- the update of step k cut at its last block column, the bulk on this stream, the rank-128
     // finish + diagonal block + solve on a second, high-priority stream beside the bulk of step k + 1 -- was built in round 3
     // and measured in every regime it was meant for: headline 0.4037 / 0.4055 s against 0.3906 / 0.3992, config 2 3.51 against
     // 3.35 ms, 8-rank shards 0.0571 / 0.0569 / 0.0568 / 0.0572 against 0.0577 / 0.0575 / 0.0574 / 0.0575, a 4-rank shard 0.1089 /
     // 0.1082 against 0.1054 / 0.1053.  Removed in round 4; the numbers are in DESIGN.md section 8d.)
+    // (Round 4 also built the whole classic step as ONE launch -- diagonal blocks ahead and first in the grid, tile tasks that
+    // update from the kernel function, wait inside the launch for their leaf's flag, solve from their registers and write once,
+    // K-pieces of split tiles meeting at a ticket -- commit 9fc7be2, parity-green, and measured slower everywhere: headline
+    // 0.3947 -> 0.4096 s, 8-rank shard 0.0562 -> 0.0645, config 2 2.51 -> 4.40 ms (profiles/r04_one_launch_ab.log): the last
+    // piece to arrive sums up to 46 slabs alone where the reduce launch spreads a tile over 8 workgroups, and the row-split
+    // main loop the in-register solve needs runs 5-10 % behind the 2 x 2 one at K >= 2000.  Removed again.)
     std::vector<char> fused_step[2];
     StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
     std::vector<char> leaf_group;   // per leaf: the phase it belongs to (COPY leaves ride with their source)
@@ -595,8 +592,6 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.ftile.p);
         dev_free(ph.dfin.p);
         dev_free(ph.dinvc.p);
-        dev_free(ph.stask.p);
-        dev_free(ph.sync.p);
     }
     arena_put(c, c->slabF);
     dev_free(c->fwd.p);
@@ -647,8 +642,6 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.ftile.p);
         dev_free(ph.dfin.p);
         dev_free(ph.dinvc.p);
-        dev_free(ph.stask.p);
-        dev_free(ph.sync.p);
     }
     arena_put(c, c->slabJ);
     c->joint_ready = false;
@@ -773,11 +766,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
     alg_flops = 0.0;
     const bool fused = gram_fused(c);
     UpdateSplitter split[2];
-    // (bound to the split-K workspace and the sync words once both phases are listed)
-    std::vector<StepTask> stask_h[2];
-    std::vector<int64_t> stask_slab_h[2], stask_sync_h[2], dfin_sync_h[2];
-    std::vector<DiagFinishTask> dfin_h[2];
-    size_t nsync_h[2] = {0, 0};
     for (int ph = 0; ph < 2; ++ph) {
         StepLists& S = phase[ph];
         UpdateSplitter& U = split[ph];
@@ -797,13 +785,8 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         std::vector<DiagTask> diag;
         std::vector<FusedTask> ftile;
         std::vector<DiagFusedTask> fdiag;
-        std::vector<DiagFinishTask>& dfin = dfin_h[ph];
+        std::vector<DiagFinishTask> dfin;
         std::vector<DiagTask> dinvc;
-        std::vector<StepTask>& stask = stask_h[ph];
-        // per task: first slab (pieces) / sync word: a whole tile's flag, a piece's ticket with its flag + 1 in the high half
-        std::vector<int64_t>&stask_slab = stask_slab_h[ph], &stask_sync = stask_sync_h[ph], &dfin_sync = dfin_sync_h[ph];
-        size_t& nsync = nsync_h[ph];
-        S.stask_off.assign(nsteps + 1, 0);
         S.dpos.assign(nsteps, 0);
         S.dfin_off.assign(nsteps + 1, 0);
         S.upd_off.assign(nsteps + 1, 0);
@@ -823,198 +806,8 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             S.fdiag_off[k] = (int)fdiag.size();
             S.ftile_off[k] = (int)ftile.size();
             S.dfin_off[k] = (int)dfin.size();
-            S.stask_off[k] = (int)stask.size();
             const int mode = k < (int)c->fused_step[ph].size() ? c->fused_step[ph][k] : STEP_CLASSIC;
             S.mode[k] = (char)mode;
-            auto mode_at = [&](int q) { return (q >= 0 && q < (int)c->fused_step[ph].size()) ? (int)c->fused_step[ph][q] : (int)STEP_CLASSIC; };
-            if (mode == STEP_ONE) {
-                // ---- one launch for the whole step (step_kernel)
-                std::vector<StepTask> tiles;
-                auto base_task = [&](const LeafHost& lf, const LeafDev& d) {
-                    StepTask tsk{};
-                    tsk.f.B = d.F + (size_t)k * TB;
-                    tsk.f.ldb = lf.npad;
-                    tsk.f.Dinv = d.Dinv + (size_t)k * TB * TB;
-                    tsk.f.k1 = k * TB;
-                    tsk.f.gxb = d.Xg + (size_t)k * TB;
-                    tsk.f.gldb = lf.npad;
-                    tsk.f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
-                    tsk.f.kid = lf.kid;
-                    tsk.x.L = d.F + (size_t)k * TB + (size_t)k * TB * lf.npad;
-                    tsk.x.ldl = lf.npad;
-                    tsk.x.nsplit = 1;
-                    tsk.x.info = d.info;
-                    return tsk;
-                };
-                std::vector<int64_t> tile_flag;       // per tile: index of the flag it waits for, -1 = none
-                std::vector<int64_t> owner_flag(L, -1);
-                for (int l = 0; l < L; ++l) {
-                    const LeafHost& lf = c->leaves[l];
-                    if (lf.nb <= k || !in_phase(lf)) continue;
-                    const LeafDev& d = c->h_leaves[l];
-                    const int ld = lf.npad;
-                    int64_t flag_idx = -1;
-                    if (lf.owner == l) {
-                        const int i_first = (k < lf.kb) ? lf.kb : k;
-                        const bool own_diag = (k >= lf.kb);
-                        const bool fin = own_diag && k >= 1 && mode_at(k - 1) == STEP_ONE;   // the step before left tile (k,k) all but done
-                        if (own_diag) {
-                            DiagTask g{};
-                            g.T = d.F + (size_t)k * TB + (size_t)k * TB * ld;
-                            g.Dinv = d.Dinv + (size_t)k * TB * TB;
-                            if (ph != 1) {
-                                g.wk = d.w + (size_t)k * TB;
-                                g.zk = d.z + (size_t)k * TB;
-                            }
-                            g.info = d.info;
-                            g.ld = ld;
-                            g.nvalid = std::max(0, std::min(TB, lf.n - k * TB));
-                            g.row0 = k * TB;
-                            dinvc.push_back(g);       // factorised without its inverse either way
-                            if (fin) {
-                                DiagFinishTask ft{};
-                                ft.d = g;
-                                ft.A = d.F + (size_t)k * TB + (size_t)(k - 1) * TB * ld;
-                                flag_idx = (int64_t)nsync++;
-                                owner_flag[l] = flag_idx;
-                                dfin.push_back(ft);
-                                dfin_sync.push_back(flag_idx);
-                            } else {                  // first one-launch step of this leaf: its whole diagonal block in a launch before
-                                DiagFusedTask fg{};
-                                fg.d = g;
-                                fg.A = d.F + (size_t)k * TB;
-                                fg.gx = d.Xg + (size_t)k * TB;
-                                fg.k1 = k * TB;
-                                fg.glda = ld;
-                                fg.kid = lf.kid;
-                                fdiag.push_back(fg);
-                            }
-                        }
-                        for (int i = std::max(i_first, k + 1); i < lf.nb; ++i) {
-                            StepTask tsk = base_task(lf, d);
-                            tsk.f.A = d.F + (size_t)i * TB;
-                            tsk.f.lda = ld;
-                            tsk.f.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
-                            tsk.f.ldc = ld;
-                            tsk.f.gxa = d.Xg + (size_t)i * TB;
-                            tsk.f.glda = ld;
-                            tsk.f.gna = std::max(0, std::min(TB, lf.n - i * TB));
-                            tsk.f.mrows = tile_mrows(lf.n - i * TB);
-                            tsk.f.zpad = 1;
-                            if (ph != 1) {
-                                tsk.f.zk = d.z + (size_t)k * TB;
-                                tsk.f.wi = d.w + (size_t)i * TB;
-                            }
-                            tiles.push_back(tsk);
-                            tile_flag.push_back(flag_idx);
-                        }
-                        if (lf.nb > k + 1 && k + 1 >= lf.kb && mode_at(k + 1) == STEP_ONE) {
-                            // the next step's diagonal tile over this step's columns (bulk): K - product, unsolved
-                            const int i = k + 1;
-                            StepTask tsk = base_task(lf, d);
-                            tsk.f.A = tsk.f.B = d.F + (size_t)i * TB;
-                            tsk.f.lda = ld;
-                            tsk.f.C = d.F + (size_t)i * TB + (size_t)i * TB * ld;
-                            tsk.f.ldc = ld;
-                            tsk.f.gxa = tsk.f.gxb = d.Xg + (size_t)i * TB;
-                            tsk.f.glda = ld;
-                            tsk.f.gna = tsk.f.gnb = std::max(0, std::min(TB, lf.n - i * TB));
-                            tsk.f.mrows = tile_mrows(lf.n - i * TB);
-                            tsk.x.bulk = 1;
-                            tiles.push_back(tsk);
-                            tile_flag.push_back(-1);
-                        }
-                    } else if (with_test && lf.nt > 0) {
-                        // a COPY leaf's test rows wait for its SOURCE's diagonal block of this launch: find that flag
-                        const int o = lf.owner;
-                        const LeafHost& lo = c->leaves[o];
-                        if (k >= lo.kb && k >= 1 && mode_at(k - 1) == STEP_ONE && lo.nb > k)
-                            flag_idx = -2;            // resolved below (the owner's DiagFinishTask may come later in the leaf order)
-                    }
-                    if (with_test && lf.nt > 0) {
-                        for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
-                            StepTask tsk = base_task(lf, d);
-                            tsk.f.A = d.Vt + (size_t)ti * TB;
-                            tsk.f.lda = lf.ntpad;
-                            tsk.f.C = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
-                            tsk.f.ldc = lf.ntpad;
-                            tsk.f.gxa = d.Xtg + (size_t)ti * TB;
-                            tsk.f.glda = lf.ntpad;
-                            tsk.f.gna = std::max(0, std::min(TB, lf.nt - ti * TB));
-                            tsk.f.mrows = tile_mrows(lf.nt - ti * TB);
-                            if (d.zfused) {
-                                tsk.f.zk = d.z + (size_t)k * TB;
-                                tsk.f.wi = d.macc + (size_t)ti * TB;
-                                tsk.f.sq = d.sacc + (size_t)ti * TB;
-                            }
-                            tiles.push_back(tsk);
-                            tile_flag.push_back(flag_idx == -2 ? -(int64_t)(3 + lf.owner) : flag_idx);
-                        }
-                    }
-                }
-                for (auto& f : tile_flag)       // test rows of COPY leaves: the flag of their owner's DiagFinishTask in this launch
-                    if (f <= -3) f = owner_flag[(size_t)(-f - 3)];
-                // Cut along K where the step cannot fill the chip's workgroup slots with whole tiles (same rules as the classic
-                // update launches: all tiles when there are fewer than CUs, else the tail of the launch)
-                const size_t T = tiles.size();
-                const int K = k * TB;
-                size_t slab = 0;
-                auto emit_whole = [&](size_t from, size_t to) {
-                    const size_t begin = stask.size();
-                    for (size_t i = from; i < to; ++i) {
-                        stask.push_back(tiles[i]);
-                        stask_slab.push_back(-1);
-                        stask_sync.push_back(tile_flag[i]);       // whole tile: sync word = its flag (or none)
-                    }
-                    std::vector<std::pair<int64_t, int64_t>> aux(stask.size());
-                    for (size_t i = 0; i < aux.size(); ++i) aux[i] = {stask_slab[i], stask_sync[i]};
-                    xcd_permute(stask, aux, begin, stask.size(), c->xcd_order);
-                    for (size_t i = begin; i < aux.size(); ++i) {
-                        stask_slab[i] = aux[i].first;
-                        stask_sync[i] = aux[i].second;
-                    }
-                };
-                std::vector<int64_t> stask_ticket_local;
-                auto emit_split = [&](size_t from, size_t to, int Sp) {
-                    if (Sp <= 1) {
-                        emit_whole(from, to);
-                        return;
-                    }
-                    for (int sidx = 0; sidx < Sp; ++sidx)
-                        for (size_t i = from; i < to; ++i) {
-                            StepTask p = tiles[i];
-                            const long chunks = K / KC;
-                            const int k0 = (int)(chunks * sidx / Sp) * KC, k1 = (int)(chunks * (sidx + 1) / Sp) * KC;
-                            p.f.A += (size_t)k0 * p.f.lda;
-                            p.f.B += (size_t)k0 * p.f.ldb;
-                            p.f.k1 = k1 - k0;
-                            p.x.nsplit = Sp;
-                            p.x.piece = sidx;
-                            stask.push_back(p);
-                            stask_slab.push_back((int64_t)(slab + (i - from) * Sp));
-                            // sync word of a piece = its tile's ticket; its flag rides in the high part (resolved at bind time)
-                            stask_sync.push_back((int64_t)(nsync + (i - from)) | ((tile_flag[i] + 1) << 32));
-                        }
-                    nsync += to - from;
-                    slab += (to - from) * (size_t)Sp;
-                };
-                if ((int)T < c->ncu) {
-                    emit_split(0, T, UpdateSplitter::choose_split((int)T, K, c->ncu));
-                } else {
-                    const size_t r = T % (size_t)c->ncu;
-                    size_t ntail = r + (T < (size_t)(2 * c->ncu) ? (size_t)c->tail_rounds * c->ncu : 0);
-                    if (ntail > T) ntail = T;
-                    int Sp = std::min(c->tail_split, std::max(1, K / 256));
-                    if (r > 0 && r * 4 < (size_t)c->ncu) Sp = std::max(Sp, (int)std::min<size_t>((size_t)c->ncu / r, 16));
-                    Sp = std::min(Sp, std::max(1, K / 256));
-                    if (Sp <= 1 || r == 0) ntail = 0;
-                    emit_whole(0, T - ntail);
-                    if (ntail) emit_split(T - ntail, T, Sp);
-                }
-                U.max_slabs = std::max(U.max_slabs, slab);
-                S.step_tiles[k] = (int)T;
-                continue;
-            }
             const bool fstep = mode != STEP_CLASSIC;               // diagonal blocks and tiles below go through the fused kernels
             std::vector<TileTask> tiles;
             // One-step lookahead of the diagonal blocks (DiagFinishTask): where steps k-1 and k are both classic, the update
@@ -1152,7 +945,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             ft.d = g;
                             ft.A = d.F + (size_t)k * TB + (size_t)(k - 1) * TB * ld;
                             dfin.push_back(ft);
-                            dfin_sync.push_back(-1);
                         } else {
                             diag.push_back(g);
                         }
@@ -1280,7 +1072,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.fdiag_off[nsteps] = (int)fdiag.size();
         S.ftile_off[nsteps] = (int)ftile.size();
         S.dfin_off[nsteps] = (int)dfin.size();
-        S.stask_off[nsteps] = (int)stask.size();
+        if (int rc = dev_upload(c, S.dfin, dfin)) return rc;
         if (int rc = dev_upload(c, S.dinvc, dinvc)) return rc;
         if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
@@ -1296,29 +1088,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         }
         for (int ph = 0; ph < 2; ++ph) {
             split[ph].bind(slab_ws);
-            dev_free(phase[ph].sync.p);
-            phase[ph].sync = DevBuf<unsigned>{};
-            if (nsync_h[ph]) {
-                HIPCHK(c, hipMalloc(&phase[ph].sync.p, nsync_h[ph] * sizeof(unsigned)));
-                phase[ph].sync.count = nsync_h[ph];
-            }
-            unsigned* sy = phase[ph].sync.p;
-            for (size_t q = 0; q < stask_h[ph].size(); ++q) {
-                StepExtra& x = stask_h[ph][q].x;
-                const int64_t sl = stask_slab_h[ph][q], sn = stask_sync_h[ph][q];
-                if (sl >= 0) {          // a K-piece: ticket in the low half, flag + 1 in the high half
-                    x.slabs = slab_ws + (size_t)sl * TB * TB;
-                    x.ticket = sy + (size_t)(sn & 0xffffffffLL);
-                    const int64_t fl = (sn >> 32) - 1;
-                    x.flag = fl >= 0 ? sy + (size_t)fl : nullptr;
-                } else {
-                    x.flag = sn >= 0 ? sy + (size_t)sn : nullptr;
-                }
-            }
-            for (size_t q = 0; q < dfin_h[ph].size(); ++q)
-                dfin_h[ph][q].flag = dfin_sync_h[ph][q] >= 0 ? sy + (size_t)dfin_sync_h[ph][q] : nullptr;
-            if (int rc = dev_upload(c, phase[ph].stask, stask_h[ph])) return rc;
-            if (int rc = dev_upload(c, phase[ph].dfin, dfin_h[ph])) return rc;
             if (int rc = dev_upload(c, phase[ph].upd, split[ph].upd)) return rc;
             if (int rc = dev_upload(c, phase[ph].red, split[ph].red)) return rc;
         }
@@ -1473,7 +1242,6 @@ int build_plan(dsmgp_ctx* c) {
             // updates a diagonal tile before factorising it is done in a few microseconds; deeper, that update belongs in
             // the many-workgroup update launch, split along K)
             if (c->fuse_steps && (nd > c->ncu || k <= FUSED_SHALLOW_STEPS)) c->fused_step[ph][k] = STEP_FUSED;
-            else if (c->one_launch) c->fused_step[ph][k] = STEP_ONE;
         }
     }
     // Gram tasks: lower tiles of every owner; with the Gram fused into the update tasks only the tiles that have none --
@@ -1508,7 +1276,7 @@ int build_plan(dsmgp_ctx* c) {
 
     // Selective completions of Dinv_k inside fit! (the fused steps leave the 16x16 diagonal inverses only, kernels.hpp):
     {
-        auto fused_in = [&](int ph, int k) { return k < (int)c->fused_step[ph].size() && c->fused_step[ph][k] != STEP_CLASSIC; };
+        auto fused_in = [&](int ph, int k) { return k < (int)c->fused_step[ph].size() && c->fused_step[ph][k] == STEP_FUSED; };
         auto block_task = [&](int l, int k) {
             const LeafHost& lf = c->leaves[l];
             const LeafDev& d = c->h_leaves[l];
@@ -1720,27 +1488,9 @@ struct PhaseTimer {
 // One factorisation phase on the context's stream.  Classic step: update (-> split-K reduce) -> diagonal block -> panel solve.
 // Fused step (many leaves, or shallow): diag_fused_kernel -> tile_fused_kernel.
 int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
-    if (S.sync.count) HIPCHK(c, hipMemsetAsync(S.sync.p, 0, S.sync.count * sizeof(unsigned), c->stream));
     for (int k = 0; k < S.nsteps; ++k) {
         const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
-        if (S.mode[k] == STEP_ONE) {
-            if (nfd > 0) {      // leaves whose diagonal block could not run ahead (the first one-launch step): in a launch before
-                pt.begin(2);
-                diag_fused_kernel<<<nfd, 256, DIAGP_LDS_BYTES, c->stream>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
-                pt.note(k, nfd, 0);
-                pt.end();
-            }
-            const int nst = S.stask_off[k + 1] - S.stask_off[k], ndf1 = S.dfin_off[k + 1] - S.dfin_off[k];
-            if (nst + ndf1 > 0) {
-                pt.begin(1);
-                step_kernel<<<nst + ndf1, 256, 0, c->stream>>>(S.stask.p + S.stask_off[k], S.dfin.p + S.dfin_off[k], ndf1, c->d_kp, c->D);
-                pt.note(k, nst, S.step_tiles[k]);
-                pt.end();
-                if (count_launches) c->n_update_launches++;
-            }
-            continue;
-        }
         if (nfd > 0 || nft > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
             if (nfd > 0) {
                 pt.begin(2);
@@ -1931,15 +1681,6 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
             free_test(c);
         }
         c->fuse_steps = value != 0;
-        return 0;
-    }
-    if (option == DSMGP_OPT_ONE_LAUNCH) {
-        if ((value != 0) != c->one_launch) {
-            HIPCHK(c, hipSetDevice(c->device));
-            free_plan(c);
-            free_test(c);
-        }
-        c->one_launch = value != 0;
         return 0;
     }
     if (option == DSMGP_OPT_DIAG_IN_UPDATE) {
@@ -2169,15 +1910,11 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     c->timings[11] = ms * 1e-3;
     if (seconds) *seconds = ms * 1e-3;
     if (mll_out) HIPCHK(c, hipMemcpy(mll_out, c->d_mll, L * sizeof(double), hipMemcpyDeviceToHost));
-    {
+    if (info_out) {
         // info lives per factor owner
         std::vector<int> owner_info(L);
         HIPCHK(c, hipMemcpy(owner_info.data(), c->d_info, L * sizeof(int), hipMemcpyDeviceToHost));
-        for (int l = 0; l < L; ++l) {
-            if (owner_info[l] == INFO_HANDOFF_TIMEOUT)      // a tile task gave up waiting for its diagonal block inside a launch
-                return fail(c, DSMGP_E_HIP, "fit: in-launch hand-off of a diagonal block timed out (leaf " + std::to_string(l) + ")");
-            if (info_out) info_out[l] = owner_info[c->leaves[l].owner];
-        }
+        for (int l = 0; l < L; ++l) info_out[l] = owner_info[c->leaves[l].owner];
     }
     c->fitted = true;
     c->predicted = false;

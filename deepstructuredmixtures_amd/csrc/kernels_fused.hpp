@@ -50,30 +50,6 @@ struct FusedTask {
 };
 static_assert(sizeof(FusedTask) == 128, "FusedTask is read with scalar loads: keep it two cache lines");
 
-// A tile task of a ONE-LAUNCH block step (step_kernel below): a FusedTask plus what ties it to the other tasks of its launch.
-struct StepExtra {
-    const double* L;      // the step's factorised diagonal tile L_kk of this leaf (ld = ldl)
-    unsigned* flag;       // set by the leaf's DiagFinishTask of this launch once L_kk, the diagonal of Dinv_k and z_k are final;
-                          // NULL: they were final before the launch
-    unsigned* ticket;     // split tile: arrivals of its K-pieces; NULL: whole tile
-    double* slabs;        // split tile: nsplit slabs of 128 x 128 (ld 128), piece p writes slab p
-    int ldl;
-    int nsplit, piece;    // piece 0 starts from the kernel function, the others from zero; FusedTask.A / .B are offset to the
-                          // piece's first column and FusedTask.k1 is its depth
-    int bulk;             // 1: the tile (k+1, k+1) over this step's columns, K - product, stored unsolved (its last block column and
-                          //    its factorisation follow in the next launch's DiagFinishTask): diagonal-tile rules of the kernel
-                          //    function, no solve, no riders
-    int* info;            // the leaf's info word: INFO_HANDOFF_TIMEOUT if the wait for `flag` gives up (dsmgp_fit then fails)
-    int pad[2];
-};
-constexpr unsigned STEP_WAIT_SPINS = 1u << 22;         // x ~0.3 us of s_sleep: about a second
-constexpr int INFO_HANDOFF_TIMEOUT = 0x7fffff00;
-struct StepTask {
-    FusedTask f;
-    StepExtra x;
-};
-static_assert(sizeof(StepTask) == 192, "StepTask: three cache lines");
-
 struct DiagFusedTask {
     DiagTask d;           // the diagonal block: T (the tile of F), Dinv, wk / zk, info, ld, nvalid, row0
     const double* A;      // F[k, 0:K]: the block row left of the tile, ld = d.ld
@@ -255,7 +231,7 @@ static_assert(lower_block_base(0) == 0 && lower_block_base(5) == 15 && lower_blo
 // yet live -- and the accumulators end as -(K - A B^T) = -C.
 template <int KIND, int NRW, int NCB = 8>
 __device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KParam& p, int D, d4 (&acc)[NCB][NRW], const double* sa,
-                                                      const double* sb, bool diag_tile = false) {
+                                                      const double* sb) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -284,7 +260,7 @@ __device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KP
             const int cidx = 16 * CG * cp + 16 * (j >> 2) + l4 + 4 * (j & 3);
 #pragma unroll
             for (int rn = 0; rn < NRW; ++rn) {
-                acc[CG * cp + (j >> 2)][rn][j & 3] = -gram_finish<KIND, true>(z[rn][j], p, rowbase + 16 * rn, cidx, tk.gna, tk.gnb, diag_tile);
+                acc[CG * cp + (j >> 2)][rn][j & 3] = -gram_finish<KIND, true>(z[rn][j], p, rowbase + 16 * rn, cidx, tk.gna, tk.gnb, false);
             }
         }
     }
@@ -295,13 +271,9 @@ __device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KP
 // 391-row experts).  Columns beyond are padding -- K is zero there, the padding rows of the B panel are zero, Dinv_k is the
 // identity there -- so X is exactly zero in them: they are neither accumulated, nor evaluated, nor solved, only stored as zeros;
 // rows 64.. of the B panel are not staged and only the block rows of Dinv_k below NCB are fetched.
-// STEP: the task belongs to a one-launch block step (step_kernel): `x` says where L_kk is, which flag announces it, and whether
-// the task is one K-piece of its tile (the last piece to arrive sums the slabs and goes on) or the unsolved tile of the next
-// step's diagonal block; `sflag` = two ints of LDS outside the ring.
-template <int NRW, int NCB, bool STEP = false>
+template <int NRW, int NCB>
 __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
-                                                const KParam* __restrict__ kp, int D, const StepExtra* x = nullptr,
-                                                int* sflag = nullptr) {
+                                                const KParam* __restrict__ kp, int D) {
     static_assert(NCB == 8 || NCB == 4 || NCB == 2 || NCB == 1, "column-block classes");
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -314,24 +286,18 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
     // Thread t moves the doubles 2 (t & 127), + 1 of block 2 e + (t >> 7).
     constexpr int NBLK = lower_block_base(NCB), NE = (NBLK + 1) / 2;
     const int dj = (t & 127) >> 3, di = 2 * (t & 7), dhalf = __builtin_amdgcn_readfirstlane(t >> 7);
-    const double* Lkk = STEP ? x->L : tk.B + (size_t)tk.k1 * (size_t)tk.ldb;
-    const size_t ldl = STEP ? (size_t)x->ldl : (size_t)tk.ldb;
+    const double* Lkk = tk.B + (size_t)tk.k1 * (size_t)tk.ldb;
     auto dinv_load = [&](int e) {
         const int b = min(2 * e + dhalf, NBLK - 1);
         const int cb = LOWER_BLOCKS.cb[b], jb = LOWER_BLOCKS.jb[b];
         const double* src = (cb == jb) ? tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB
-                                       : Lkk + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * ldl;
+                                       : Lkk + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * (size_t)tk.ldb;
         return *AS_GLOBAL_D2(src);
     };
     RowsplitPrefetch pf;
     rowsplit_prefetch<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, pf);
     d4 acc[NCB][NRW];
-    if (STEP && x->piece != 0) {        // a later K-piece of a split tile: the product alone
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = (d4){0.0, 0.0, 0.0, 0.0};
-    } else {        // acc = -k(row, col): coordinates through the (still unused) ring
+    {               // acc = -k(row, col): coordinates through the (still unused) ring
         const KParam p = kp[tk.kid];
         double* sa = &sA[0][0];
         double* sb = &sB[0][0];
@@ -341,93 +307,12 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
             sb[e] = (r < tk.gnb) ? tk.gxb[r + (size_t)d * tk.gldb] : 0.0;
         }
         __syncthreads();
-        const bool dt = STEP && x->bulk != 0;
-        if (p.kind == 0) rowsplit_gram_init<0, NRW, NCB>(tk, p, D, acc, sa, sb, dt);
-        else if (p.kind == 1) rowsplit_gram_init<1, NRW, NCB>(tk, p, D, acc, sa, sb, dt);
-        else rowsplit_gram_init<2, NRW, NCB>(tk, p, D, acc, sa, sb, dt);
+        if (p.kind == 0) rowsplit_gram_init<0, NRW, NCB>(tk, p, D, acc, sa, sb);
+        else if (p.kind == 1) rowsplit_gram_init<1, NRW, NCB>(tk, p, D, acc, sa, sb);
+        else rowsplit_gram_init<2, NRW, NCB>(tk, p, D, acc, sa, sb);
         __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
     }
     gemm_mainloop_rowsplit<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB, pf);   // acc = -C; ends on a barrier: the ring is free
-    if constexpr (STEP) {
-        const unsigned lofs_s = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)TB;
-        if (x->nsplit > 1) {
-            // Split tile: this piece's part of -C goes to its slab; the piece that arrives last adds the slabs up in piece
-            // order (whichever it is: the same bits) and carries on with the whole tile.  Agent-scope hand-off, counter form:
-            // plain stores -> every wave drains -> barrier -> one lane: release fence, drain, ticket | last arriver: acquire
-            // fence, drain, barrier, plain loads.
-            double* slab = x->slabs + (size_t)x->piece * TB * TB;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const gf64_ptr col = AS_GLOBAL_F64(slab + (size_t)(16 * cb + 4 * q) * TB);
-#pragma unroll
-                    for (int rn = 0; rn < NRW; ++rn) col[lofs_s + 16 * rn] = acc[cb][rn][q];
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned old = __hip_atomic_fetch_add(x->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = (old + 1u == (unsigned)x->nsplit) ? 1 : 0;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                sflag[0] = last;
-            }
-            __syncthreads();
-            if (sflag[0] == 0) return;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = (d4){0.0, 0.0, 0.0, 0.0};
-            for (int p = 0; p < x->nsplit; ++p) {
-                const double* sl = x->slabs + (size_t)p * TB * TB;
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const gf64_ptr col = AS_GLOBAL_F64(sl + (size_t)(16 * cb + 4 * q) * TB);
-#pragma unroll
-                        for (int rn = 0; rn < NRW; ++rn) acc[cb][rn][q] += col[lofs_s + 16 * rn];
-                    }
-            }
-        }
-        if (x->bulk) {      // K(k+1,k+1) - product, unsolved: C = -acc (padding rows and columns come out of the kernel function's rules)
-            const unsigned lofs_b = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * q) * (size_t)tk.ldc);
-                    const int cidx = 16 * cb + l4 + 4 * q;
-#pragma unroll
-                    for (int rn = 0; rn < NRW; ++rn) {
-                        const int row = 16 * NRW * w + 16 * rn + l15;
-                        col[lofs_b + 16 * rn] = (cb < NCB) ? -acc[cb < NCB ? cb : 0][rn][q] : (row == cidx ? 1.0 : 0.0);
-                    }
-                    if (NRW == 1) col[lofs_b + 64] = (64 + 16 * w + l15 == cidx) ? 1.0 : 0.0;     // rows 64..: identity padding
-                }
-            return;
-        }
-        if (x->flag != nullptr) {       // L_kk, the diagonal of Dinv_k and z_k come from a DiagFinishTask of THIS launch
-            if (t == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(x->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > STEP_WAIT_SPINS) {        // cannot happen (the producers precede every consumer in the grid and
-                        *x->info = INFO_HANDOFF_TIMEOUT;    // never wait); if it does, fail loudly instead of hanging the device
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-        }
-    }
     double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256; block b sits at 256 b
     constexpr int NE1 = (NCB == 8) ? 9 : NE;            // first stage (NCB = 8: block rows 0..4 and three blocks of row 5)
     d2 dv[NE1];
@@ -726,10 +611,8 @@ __global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask*
 struct DiagFinishTask {
     DiagTask d;
     const double* A;         // F[k, K - 128 .. K): the last finished block of the block row, ld = d.ld
-    unsigned* flag;          // one-launch steps: set (agent scope) when the block is done, for the tile tasks of the same launch
 };
 
-template <bool INVERSE = true>
 __device__ __forceinline__ void diag_finish_body(const DiagFinishTask& ft, double* S) {
     TileTask tt{};
     tt.A = ft.A;
@@ -747,7 +630,7 @@ __device__ __forceinline__ void diag_finish_body(const DiagFinishTask& ft, doubl
         const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
         diag_fused_front<0, true>(tt, nullptr, 0, S, blk);
     }
-    chol_diag_packed_body<false, INVERSE>(ft.d, S, true);    // its first barrier publishes the image
+    chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
 }
 
 // ROLE only names the instantiation (same code): 0 = update launches (whole tiles and split-K pieces), 1 = panel
@@ -774,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
     int b = blockIdx.x;
     if (!STAMP && ndfin > 0 && b >= dpos) {      // workgroup-uniform
         if (b < dpos + ndfin) {
-            diag_finish_body<true>(dfin[b - dpos], smem);
+            diag_finish_body(dfin[b - dpos], smem);
             return;
         }
         b -= ndfin;
@@ -796,60 +679,6 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel_v2(const TileTask* __
             s[6] = r0;                                    // kernel entry / exit of this wave (100 MHz wall ticks)
             s[7] = __builtin_amdgcn_s_memrealtime();
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ONE launch per block step (round 4).  With the diagonal block one step ahead (DiagFinishTask) nothing in a classic step
-// needs a launch boundary any more except the step itself:
-//   [0, ndfin)   the DiagFinishTasks of the step: rank-128 finish + factorisation of L_kk (no inverse phase: the tile tasks
-//                substitute), z_k; each ends by publishing a flag at agent scope (release fence, then a relaxed store);
-//   then         one StepTask per tile (i, k) below the diagonal blocks and per test-row tile: tile_fused_body -- the product
-//                over K on -k(x, x') in row-split accumulators, then (flag of its leaf: relaxed poll by one lane, ONE acquire)
-//                the solve against L_kk from the registers, the tile written once, riders.  Where a step has fewer tiles than
-//                the chip has workgroup slots the tiles are cut along K: pieces write slabs, take a ticket, and the LAST piece
-//                to arrive sums the slabs in piece order and carries on as the whole tile (no reduce launch);
-//                and per leaf the unsolved tile (k+1, k+1) over this step's columns, for the next launch's DiagFinishTask.
-// What used to be update -> reduce -> diagonal block -> panel solve (four dependent launches, every tile of the block column
-// through memory twice more than needed) is one launch that writes every tile once.  Deadlock-free by construction: only tile
-// tasks wait, only for DiagFinishTasks, which never wait and precede them in the grid (workgroups are dispatched in index
-// order); the poll is bounded all the same.
-__global__ __launch_bounds__(256, 2) void step_kernel(const StepTask* __restrict__ tasks, const DiagFinishTask* __restrict__ dfin,
-                                                      int ndfin, const KParam* __restrict__ kp, int D) {
-    __shared__ __attribute__((aligned(16))) double smem[UPD_LDS_DOUBLES];
-    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
-    double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem + NRING * KC2 * LDP);
-    int* sflag = reinterpret_cast<int*>(smem + 2 * NRING * KC2 * LDP);      // behind the ring
-    static_assert(UPD_LDS_DOUBLES >= 2 * NRING * KC2 * LDP + 2, "room for the hand-off words behind the ring");
-    if ((int)blockIdx.x < ndfin) {
-        const DiagFinishTask ft = dfin[blockIdx.x];
-        diag_finish_body<false>(ft, smem);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the fence's own wait)
-            __hip_atomic_store(ft.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-    const StepTask* tp = tasks + (blockIdx.x - ndfin);
-    const FusedTask tk = tp->f;
-    const StepExtra x = tp->x;
-    const bool half = tk.mrows != 0 && tk.mrows <= 64;
-    const int ncb = x.bulk ? 8 : (tk.gnb + 15) >> 4;
-    if (ncb <= 1) {
-        if (half) tile_fused_body<1, 1, true>(tk, sA, sB, kp, D, &x, sflag);
-        else tile_fused_body<2, 1, true>(tk, sA, sB, kp, D, &x, sflag);
-    } else if (ncb <= 2) {
-        if (half) tile_fused_body<1, 2, true>(tk, sA, sB, kp, D, &x, sflag);
-        else tile_fused_body<2, 2, true>(tk, sA, sB, kp, D, &x, sflag);
-    } else if (ncb <= 4) {
-        if (half) tile_fused_body<1, 4, true>(tk, sA, sB, kp, D, &x, sflag);
-        else tile_fused_body<2, 4, true>(tk, sA, sB, kp, D, &x, sflag);
-    } else {
-        if (half) tile_fused_body<1, 8, true>(tk, sA, sB, kp, D, &x, sflag);
-        else tile_fused_body<2, 8, true>(tk, sA, sB, kp, D, &x, sflag);
     }
 }
 

@@ -172,15 +172,6 @@ int dsmgp_set_gradient_leaves(dsmgp_ctx* ctx, const int32_t* active /* L flags, 
  * Results agree to rounding (the diagonal tile's update is summed in two parts); a fit is bit-reproducible either way.
  * Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing it discards the leaf plan and a registered test set. */
 #define DSMGP_OPT_DIAG_IN_UPDATE 4
-/* DSMGP_OPT_ONE_LAUNCH: 1 (default) = every block step that is not fused (few leaves, deep K: the headline regime, the shards of
- * a multi-GPU job, a single GP) runs as ONE launch: the diagonal blocks, one step ahead as above, at the front of the grid; one
- * task per tile below them that updates it over K from the kernel function, waits inside the launch for its leaf's diagonal
- * block (agent-scope release / acquire on a flag), solves against L_kk from its registers and writes the tile once; tiles of
- * steps that cannot fill the chip are cut along K, the last piece to arrive sums the slabs in piece order and carries on.
- * 0 = update / reduce / panel solve launches (with DSMGP_OPT_DIAG_IN_UPDATE) or update / reduce / diagonal block / panel
- * solve.  Results agree to rounding; a fit is bit-reproducible either way.  Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing
- * it discards the leaf plan and a registered test set. */
-#define DSMGP_OPT_ONE_LAUNCH 5
 int dsmgp_set_option(dsmgp_ctx* ctx, int32_t option, int32_t value);
 
 /* ---- inspection ------------------------------------------------------------------------------- */

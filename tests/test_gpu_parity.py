@@ -1349,7 +1349,6 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
 
     def run(fused):
         ctx.set_option(hipabi.OPT_FUSED_STEPS, 1 if fused else 0)
-        ctx.set_option(hipabi.OPT_ONE_LAUNCH, 1 if fused else 0)      # `classic` = update / diagonal block / panel solve launches
         ctx.set_train(X, y)
         ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, dtype=np.int32), means)
         ctx.set_sharing(op, src, plen)
@@ -1369,7 +1368,6 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
         b = run(False)
     finally:
         ctx.set_option(hipabi.OPT_FUSED_STEPS, 1)
-        ctx.set_option(hipabi.OPT_ONE_LAUNCH, 1)
         ctx.set_profile(0)
     assert a[4]["gram"] < 0.25 * b[4]["gram"]          # no Gram launch: the tasks of block column 0 start from the kernel function
     assert np.allclose(a[0], b[0], rtol=1e-12, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
@@ -1579,20 +1577,17 @@ def test_config5_full_size_factor_and_discard():
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_one_launch_steps_and_diagonal_blocks_ahead_agree_with_separate_launches(ctx, kind):
-    """Round 4 (shorten the chain).  Three schedules of the block steps that are not fused:
-      classic   update / reduce / diagonal block / panel solve launches (both options off);
-      ahead     DSMGP_OPT_DIAG_IN_UPDATE: the update launch of step k - 1 also updates tile (k, k) over its columns, the update
-                launch of step k carries one task per leaf that applies the last block column, factorises and inverts;
-      one       DSMGP_OPT_ONE_LAUNCH (the default): the whole step is ONE launch -- diagonal blocks ahead and first in the
-                grid, every tile below updated from the kernel function, solved from its registers after an in-launch wait
-                for its leaf's diagonal block, written once; K-pieces of split tiles meet at a ticket, the last one sums the
-                slabs in piece order.
+def test_diagonal_blocks_one_step_ahead_agree_with_separate_launches(ctx, kind):
+    """Round 4 (shorten the chain).  Two schedules of the block steps that are not fused:
+      classic   update / reduce / diagonal block / panel solve launches (DSMGP_OPT_DIAG_IN_UPDATE off);
+      ahead     the default: the update launch of step k - 1 also updates tile (k, k) over its columns, the update launch of
+                step k carries one task per leaf that applies the last block column, factorises and inverts -- no
+                diagonal-block launch on the chain.
     Thirteen leaves of 200..4100 rows (33 block steps: launches with fewer tiles than CUs, where every tile is split along K,
     and fuller ones) with a COPY and a PREFIX leaf and routed test rows, every step on the schedule under test and then the
-    default mix with the fused shallow steps, each against `classic`: log-marginals 1e-12, factors 1e-11, moments 1e-9; two
-    leaves against the oracle; the same fit three times gives the same bits (whatever order pieces and flags arrive in);
-    and the paths that need the WHOLE inverse afterwards (alpha, standalone prediction) agree too."""
+    default mix with the fused shallow steps, against `classic`: log-marginals 1e-12, factors 1e-11, moments 1e-9; two
+    leaves against the oracle; the same fit three times gives the same bits; and the paths that need the WHOLE inverse of
+    the fused steps' diagonal blocks afterwards (alpha, standalone prediction) agree too."""
     N, D, L = 20_000, 3, 13
     X, y, Xt = regression_data(N, D, n_test=200, seed=6300 + kind)
     rng = np.random.default_rng(31 + kind)
@@ -1614,13 +1609,11 @@ def test_one_launch_steps_and_diagonal_blocks_ahead_agree_with_separate_launches
            2: [np.log(1.5), 0.0, np.log(0.3)]}[kind]
     means = [float(np.mean(y[o])) for o in obs]
     means[10] = means[1]
-    schedules = {"classic": (0, 0), "ahead": (0, 1), "one": (1, 1)}
+    schedules = {"classic": 0, "ahead": 1}
 
     def run(schedule, fused_steps):
-        one, ahead = schedules[schedule]
         ctx.set_option(hipabi.OPT_FUSED_STEPS, 1 if fused_steps else 0)
-        ctx.set_option(hipabi.OPT_ONE_LAUNCH, one)
-        ctx.set_option(hipabi.OPT_DIAG_IN_UPDATE, ahead)
+        ctx.set_option(hipabi.OPT_DIAG_IN_UPDATE, schedules[schedule])
         ctx.set_train(X, y)
         ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, dtype=np.int32), means)
         ctx.set_sharing(op, src, plen)
@@ -1645,9 +1638,8 @@ def test_one_launch_steps_and_diagonal_blocks_ahead_agree_with_separate_launches
         return mll, mu, var, fa
 
     try:
-        runs = [(run(sch, fs), run("classic", fs), sch, fs) for fs in (False, True) for sch in ("one", "ahead")]
+        runs = [(run("ahead", fs), run("classic", fs), "ahead", fs) for fs in (False, True)]
     finally:
-        ctx.set_option(hipabi.OPT_ONE_LAUNCH, 1)
         ctx.set_option(hipabi.OPT_DIAG_IN_UPDATE, 1)
         ctx.set_option(hipabi.OPT_FUSED_STEPS, 1)
     for a, b, sch, fs in runs:
@@ -1658,7 +1650,7 @@ def test_one_launch_steps_and_diagonal_blocks_ahead_agree_with_separate_launches
         for (Fa, aa), (Fb, ab) in zip(a[3], b[3]):
             assert np.max(np.abs(Fa - Fb)) <= 1e-11 * np.max(np.abs(Fb)), (sch, fs, float(np.max(np.abs(Fa - Fb)) / np.max(np.abs(Fb))))
             assert np.max(np.abs(aa - ab)) <= 1e-8 * np.max(np.abs(ab)), (sch, fs)
-    a = runs[2][0]                                   # the default: one-launch steps behind the fused shallow ones
+    a = runs[1][0]                                   # the default: diagonal blocks ahead, behind the fused shallow steps
     mk = {0: lambda: ogp.IsoSE(hyp[0], hyp[1]), 1: lambda: ogp.ArdSE(np.array(hyp[:3]), hyp[3]), 2: lambda: ogp.IsoLinear(hyp[0])}[kind]
     for j in (11, 12):
         g = ogp.GaussianProcess(X[obs[j]], y[obs[j]], means[j], mk(), hyp[-1], True).update_cholesky()

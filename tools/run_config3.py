@@ -16,8 +16,6 @@ X, y, Xt = dsm.regression_data(4096, 4, seed=20202)
 gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1))
 xa = os.environ.get("DSMGP_RUN_ARGS", "")      # A/B runs (tools/ab_libs.sh): the same switches as bench.py
 def options(ctx):
-    if "--no-one-launch" in xa:
-        ctx.set_option(dsm.hipabi.OPT_ONE_LAUNCH, 0)
     if "--no-diag-ahead" in xa:
         ctx.set_option(dsm.hipabi.OPT_DIAG_IN_UPDATE, 0)
 options(gp.model.ctx)
