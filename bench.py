@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--unfused-gram", action="store_true",
                     help="diagnostic: every Gram tile through memory first (DSMGP_OPT_FUSED_GRAM = 0), for A/B runs")
     ap.add_argument("--no-fused-steps", action="store_true", help="diagnostic: DSMGP_OPT_FUSED_STEPS = 0, for A/B runs")
+    ap.add_argument("--graph", action="store_true", help="diagnostic: DSMGP_OPT_FIT_GRAPH = 1 (the untimed fits replay a captured hipGraph)")
     ap.add_argument("--no-diag-ahead", action="store_true",
                     help="diagnostic: DSMGP_OPT_DIAG_IN_UPDATE = 0 (a diagonal-block launch per classic step), for A/B runs")
     ap.add_argument("--sub", type=int, default=None,
@@ -383,6 +384,8 @@ def main():
         ctx.set_option(dsm.hipabi.OPT_FUSED_STEPS, 0)
     if args.no_diag_ahead:
         ctx.set_option(dsm.hipabi.OPT_DIAG_IN_UPDATE, 0)
+    if args.graph:
+        ctx.set_option(dsm.hipabi.OPT_FIT_GRAPH, 1)
     if args.mode == "train":
         return bench_train(args, model, X, y, rank, world, td, torch)
     ctx.set_profile(0 if args.no_profile else 1)   # timed region: events around the update launches only

@@ -404,6 +404,15 @@ struct dsmgp_ctx {
     DevBuf<SolveTask> fwd, bwd;
     int solve_steps = 0;
     bool fitted = false;
+    // The launch sequence of fit! as a captured hipGraph (one per variant: fit alone / with the resident test rows), replayed
+    // while per-launch timing is off (dsmgp_set_profile 0): every kernel argument is a pointer into the plan's task lists or
+    // arenas, which live as long as the plan, and the hyper-parameters go through d_kp's CONTENTS -- so a graph stays valid
+    // until the plan, the test set or the KParam table's allocation changes (drop_graphs).  What it buys is the host-side
+    // launch cost between dependent kernels of a latency-bound chain (config 2: 32 steps x 3 launches).
+    bool use_graph = false;         // opt-in (DSMGP_OPT_FIT_GRAPH): config 2 2.50 -> 2.47 ms, nothing elsewhere; capture does not mix with
+                                    // several contexts driven from concurrent host threads (hipabi.MultiContext)
+    hipGraphExec_t fit_graph[2] = {nullptr, nullptr};
+    int graph_launches[2][2] = {{0, 0}, {0, 0}};
     bool alpha_valid = false;       // alpha = L^-T z has been computed for the current factors (ensure_alpha)
     bool dinv_complete = false;     // every Dinv_k holds the whole inverse for the current factors (ensure_dinv); a fit leaves the
                                     // blocks of its fused steps with their 16x16 diagonal inverses only
@@ -541,6 +550,14 @@ void arena_put(dsmgp_ctx* c, double*& p) {
     p = nullptr;
 }
 
+void drop_graphs(dsmgp_ctx* c) {
+    for (auto& g : c->fit_graph)
+        if (g) {
+            (void)hipGraphExecDestroy(g);
+            g = nullptr;
+        }
+}
+
 // the task lists of the gradient pass (they depend on the set of active leaves); the L^-T arena stays
 void free_grad_lists(dsmgp_ctx* c) {
     dev_free(c->gtrans.p);
@@ -569,6 +586,7 @@ void free_grad(dsmgp_ctx* c) {
 
 void free_test(dsmgp_ctx* c);
 void free_plan(dsmgp_ctx* c) {
+    drop_graphs(c);
     if (c->pool_base) {      // stack order: everything above the plan goes with it
         free_test(c);
         c->pool_top = 0;
@@ -605,6 +623,7 @@ void free_plan(dsmgp_ctx* c) {
 }
 
 void free_test(dsmgp_ctx* c) {
+    drop_graphs(c);
     if (c->pool_base) {      // the gradient arenas sit above (or would be clobbered below) the test arenas
         free_grad(c);
         c->pool_top = c->pool_mark_plan;
@@ -687,11 +706,13 @@ int upload_hyper(dsmgp_ctx* c) {
     const size_t nslots = l2pool.size();
     for (size_t i = 0; i < nslots; ++i) l2pool.push_back(-0.5 / l2pool[i]);   // second half: the exponent's factor
     if (l2pool.size() > c->l2_cap || !c->d_l2) {   // (re)allocate only when the table grows: fit is called in loops
+        drop_graphs(c);
         dev_free(c->d_l2);
         c->l2_cap = std::max<size_t>(16, 2 * l2pool.size());
         HIPCHK(c, hipMalloc(&c->d_l2, c->l2_cap * sizeof(double)));
     }
     if ((size_t)nk > c->kp_cap || !c->d_kp) {
+        drop_graphs(c);
         dev_free(c->d_kp);
         c->kp_cap = std::max<size_t>(4, 2 * (size_t)nk);
         HIPCHK(c, hipMalloc(&c->d_kp, c->kp_cap * sizeof(KParam)));
@@ -1633,6 +1654,7 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->d_kp);
     dev_free(c->d_l2);
     (void)dsmgp_comm_destroy(c);
+    drop_graphs(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1681,6 +1703,11 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
             free_test(c);
         }
         c->fuse_steps = value != 0;
+        return 0;
+    }
+    if (option == DSMGP_OPT_FIT_GRAPH) {
+        if (value == 0) drop_graphs(c);
+        c->use_graph = value != 0;
         return 0;
     }
     if (option == DSMGP_OPT_DIAG_IN_UPDATE) {
@@ -1844,63 +1871,101 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
 
-    HIPCHK(c, hipMemsetAsync(c->d_info, 0, L * sizeof(int), c->stream));
     StepLists* phases = joint ? c->phaseJ : c->phase;
-    c->vt_valid = false;
-    if (joint && c->acc_count) HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
-    // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98) [+ K_tn tiles]
-    //    (fused into the update tasks: only the tiles of block column 0 are written here)
-    {
-        const DevBuf<GramTask>& tg = (joint && gram_fused(c)) ? c->pgram0 : c->pgram;
-        pt.begin(0);
-        if (c->gram.count) gram_tile_kernel<<<2 * (int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
-        if (joint && tg.count) gram_tile_kernel<<<2 * (int)tg.count, 256, 0, c->stream>>>(tg.p, c->d_kp, c->D);
-        pt.end();
-    }
-    // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101); w = y - m rides along
-    {
-        int maxpad = 0;
-        for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
-        copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
-    }
-    if (int rc = run_phase(c, phases[0], pt, true)) return rc;
-    // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
-    bool any_prefix = false;
-    for (int l = 0; l < L; ++l) {
-        const LeafHost& lf = c->leaves[l];
-        if (lf.op != DSMGP_SHARE_PREFIX) continue;
-        any_prefix = true;
-        const LeafDev& d = c->h_leaves[l];
-        const LeafDev& s = c->h_leaves[lf.src];
-        const size_t rows = (size_t)lf.kb * TB;
-        HIPCHK(c, hipMemcpy2DAsync(d.F, (size_t)d.npad * sizeof(double), s.F, (size_t)s.npad * sizeof(double),
-                                   rows * sizeof(double), rows, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d.Dinv, s.Dinv, rows * TB * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    }
-    if (any_prefix) {
-        if (c->dinvc_prefix.count)      // copied blocks that a fused step factorised: their whole inverse, for the classic steps below
-            dinv_complete_kernel<<<(int)c->dinvc_prefix.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_prefix.p);
-        if (int rc = run_phase(c, phases[1], pt, true)) return rc;
-    }
-    // 4. z = L^-1 (y - m) for the leaves whose factor came from another leaf (COPY, PREFIX); leaves factorised in
-    //    full produced z during the factorisation.  alpha = L^-T z (src/gaussianprocess.jl:105) is NOT computed here:
-    //    neither the log-marginal (z.z) nor the prediction (V^T z) needs it -- ensure_alpha() runs the backward sweep
-    //    on first use (gradients, dsmgp_download_factor).
-    {
-        pt.begin(4);
-        if (c->dinvc_fwd.count)
-            dinv_complete_kernel<<<(int)c->dinvc_fwd.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_fwd.p);
-        for (int k = 0; k < c->solve_steps; ++k) {
-            const int n = c->fwd_off[k + 1] - c->fwd_off[k];
-            if (n > 0) solve_fwd_kernel<<<n, 256, 0, c->stream>>>(c->fwd.p + c->fwd_off[k]);
+    auto enqueue = [&]() -> int {
+        HIPCHK(c, hipMemsetAsync(c->d_info, 0, L * sizeof(int), c->stream));
+        if (joint && c->acc_count) HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
+        // 1. kernel matrices K + (noise + eps) I, lower tiles   (src/gaussianprocess.jl:83-98) [+ K_tn tiles]
+        //    (fused into the update tasks: only the tiles of block column 0 are written here)
+        {
+            const DevBuf<GramTask>& tg = (joint && gram_fused(c)) ? c->pgram0 : c->pgram;
+            pt.begin(0);
+            if (c->gram.count) gram_tile_kernel<<<2 * (int)c->gram.count, 256, 0, c->stream>>>(c->gram.p, c->d_kp, c->D);
+            if (joint && tg.count) gram_tile_kernel<<<2 * (int)tg.count, 256, 0, c->stream>>>(tg.p, c->d_kp, c->D);
+            pt.end();
         }
+        // 2. factorisation, full leaves first                    (src/gaussianprocess.jl:101); w = y - m rides along
+        {
+            int maxpad = 0;
+            for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
+            copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
+        }
+        if (int rc = run_phase(c, phases[0], pt, true)) return rc;
+        // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
+        bool any_prefix = false;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.op != DSMGP_SHARE_PREFIX) continue;
+            any_prefix = true;
+            const LeafDev& d = c->h_leaves[l];
+            const LeafDev& s = c->h_leaves[lf.src];
+            const size_t rows = (size_t)lf.kb * TB;
+            HIPCHK(c, hipMemcpy2DAsync(d.F, (size_t)d.npad * sizeof(double), s.F, (size_t)s.npad * sizeof(double),
+                                       rows * sizeof(double), rows, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d.Dinv, s.Dinv, rows * TB * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (any_prefix) {
+            if (c->dinvc_prefix.count)      // copied blocks that a fused step factorised: their whole inverse, for the classic steps below
+                dinv_complete_kernel<<<(int)c->dinvc_prefix.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_prefix.p);
+            if (int rc = run_phase(c, phases[1], pt, true)) return rc;
+        }
+        // 4. z = L^-1 (y - m) for the leaves whose factor came from another leaf (COPY, PREFIX); leaves factorised in
+        //    full produced z during the factorisation.  alpha = L^-T z (src/gaussianprocess.jl:105) is NOT computed here:
+        //    neither the log-marginal (z.z) nor the prediction (V^T z) needs it -- ensure_alpha() runs the backward sweep
+        //    on first use (gradients, dsmgp_download_factor).
+        {
+            pt.begin(4);
+            if (c->dinvc_fwd.count)
+                dinv_complete_kernel<<<(int)c->dinvc_fwd.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_fwd.p);
+            for (int k = 0; k < c->solve_steps; ++k) {
+                const int n = c->fwd_off[k + 1] - c->fwd_off[k];
+                if (n > 0) solve_fwd_kernel<<<n, 256, 0, c->stream>>>(c->fwd.p + c->fwd_off[k]);
+            }
+            pt.end();
+        }
+        // 5. log marginal likelihood                              (src/gaussianprocess.jl:163)
+        pt.begin(5);
+        mll_kernel<<<L, 256, 0, c->stream>>>(c->d_leaves, c->d_mll);
         pt.end();
-        c->alpha_valid = false;
+        return 0;
+    };
+    c->vt_valid = false;
+    c->alpha_valid = false;
+    // Replay the sequence as a graph while nothing inside it records events (profile 0); capture it on first use
+    const int gk = joint ? 1 : 0;
+    if (c->use_graph && c->profile == 0) {
+        if (!c->fit_graph[gk]) {
+            hipGraph_t g = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue();
+            const hipError_t ce = hipStreamEndCapture(c->stream, &g);
+            if (rc != 0 || ce != hipSuccess || !g) {
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                c->use_graph = false;               // this runtime cannot capture the sequence: plain launches from here on
+                if (rc != 0) return rc;
+            } else {
+                const hipError_t ie = hipGraphInstantiate(&c->fit_graph[gk], g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (ie != hipSuccess) {
+                    c->fit_graph[gk] = nullptr;
+                    (void)hipGetLastError();
+                    c->use_graph = false;
+                }
+                c->graph_launches[gk][0] = c->n_update_launches;      // counted by the capture pass: the same on every replay
+                c->graph_launches[gk][1] = c->n_fused_launches;
+            }
+        }
+        if (c->fit_graph[gk]) {
+            HIPCHK(c, hipGraphLaunch(c->fit_graph[gk], c->stream));
+            c->n_update_launches = c->graph_launches[gk][0];
+            c->n_fused_launches = c->graph_launches[gk][1];
+        } else if (int rc = enqueue()) {
+            return rc;
+        }
+    } else {
+        if (int rc = enqueue()) return rc;
     }
-    // 5. log marginal likelihood                              (src/gaussianprocess.jl:163)
-    pt.begin(5);
-    mll_kernel<<<L, 256, 0, c->stream>>>(c->d_leaves, c->d_mll);
-    pt.end();
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

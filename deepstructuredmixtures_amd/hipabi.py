@@ -16,6 +16,7 @@ OPT_ARD_LENGTHSCALE_GRADIENT = 1
 OPT_FUSED_GRAM = 2
 OPT_FUSED_STEPS = 3
 OPT_DIAG_IN_UPDATE = 4
+OPT_FIT_GRAPH = 5
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
 

@@ -172,6 +172,13 @@ int dsmgp_set_gradient_leaves(dsmgp_ctx* ctx, const int32_t* active /* L flags, 
  * Results agree to rounding (the diagonal tile's update is summed in two parts); a fit is bit-reproducible either way.
  * Needs DSMGP_OPT_FUSED_GRAM (D <= 32); changing it discards the leaf plan and a registered test set. */
 #define DSMGP_OPT_DIAG_IN_UPDATE 4
+/* DSMGP_OPT_FIT_GRAPH: 1 = while per-launch timing is off (dsmgp_set_profile 0) dsmgp_fit replays its launch sequence as a
+ * captured hipGraph (captured on the first such fit of a plan, dropped with the plan, the test set or a re-allocated
+ * kernel-parameter table).  Same kernels, same arguments, same results to the bit.  0 (default) = plain launches: what the
+ * graph buys is the host-side cost between dependent launches, measured at 2 % of a single GP's 32-step chain (config 2: 2.50
+ * -> 2.47 ms) and nothing elsewhere, and a capture does not tolerate other contexts being driven from concurrent host threads
+ * in the same process. */
+#define DSMGP_OPT_FIT_GRAPH 5
 int dsmgp_set_option(dsmgp_ctx* ctx, int32_t option, int32_t value);
 
 /* ---- inspection ------------------------------------------------------------------------------- */

@@ -1660,6 +1660,61 @@ def test_diagonal_blocks_one_step_ahead_agree_with_separate_launches(ctx, kind):
         assert np.allclose(a[2][rptr[j]:rptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
 
 
+def test_fit_replayed_as_a_graph_equals_plain_launches(ctx):
+    """DSMGP_OPT_FIT_GRAPH (round 4; opt-in): with per-launch timing off dsmgp_fit replays its launch sequence as
+    a captured hipGraph.  Same kernels and arguments: the results equal those of plain launches BIT FOR BIT -- also after the
+    hyper-parameters change (they travel through the CONTENTS of the kernel-parameter table, which the graph only points at),
+    with and without resident test rows, with a COPY and a PREFIX leaf (the graph holds the device-to-device copies of the
+    prefix blocks), and after a new leaf table (the old graphs are dropped with their plan)."""
+    N, D, L = 8000, 3, 6
+    X, y, Xt = regression_data(N, D, n_test=120, seed=1234)
+    rng = np.random.default_rng(9)
+    sizes = [300, 700, 1500, 400, 700, 900]
+    obs = [np.sort(rng.choice(N, size=n, replace=False)) for n in sizes]
+    obs[4] = obs[1].copy()
+    tail = np.arange(obs[3][-1] + 1, min(N, obs[3][-1] + 401))
+    obs[5] = np.concatenate([obs[3], tail])
+    op = np.array([0, 0, 0, 0, 1, 2], dtype=np.int32)
+    src = np.array([-1, -1, -1, -1, 1, 3], dtype=np.int32)
+    plen = np.array([0, 0, 0, 0, 0, obs[3].size], dtype=np.int64)
+    means = [float(np.mean(y[o])) for o in obs]
+    means[4] = means[1]
+    ntest = rng.integers(10, 100, size=L)
+    rptr = np.concatenate([[0], np.cumsum(ntest)])
+    ridx = np.concatenate([np.sort(rng.choice(Xt.shape[0], size=int(k), replace=False)) for k in ntest])
+    hypers = [[np.log(0.3), 0.0, np.log(0.1)], [np.log(0.5), 0.2, np.log(0.2)], [np.log(0.3), 0.0, np.log(0.1)]]
+
+    def run(graph):
+        ctx.set_option(hipabi.OPT_FIT_GRAPH, 1 if graph else 0)
+        ctx.set_profile(0)
+        ctx.set_train(X, y)
+        ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, dtype=np.int32), means)
+        ctx.set_sharing(op, src, plen)
+        out = []
+        for h in hypers:                              # fit alone: the graph of the plain step lists
+            ctx.set_hyper(0, 0, h)
+            mll, info, _ = ctx.fit()
+            assert np.all(info == 0)
+            out.append(mll)
+        ctx.set_test(Xt, rptr, ridx)
+        for h in hypers[:2]:                          # with the rows riding along: the second graph
+            ctx.set_hyper(0, 0, h)
+            mll, info, _ = ctx.fit()
+            ctx.predict_run()
+            mu, var = ctx.predict_fetch()
+            out += [mll, mu, var]
+        out.append(ctx.download_factor(5, obs[5].size)[0])
+        return out
+
+    try:
+        a, b = run(True), run(False)
+    finally:
+        ctx.set_option(hipabi.OPT_FIT_GRAPH, 0)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    assert not np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])     # the replay follows the hyper-parameters
+
+
 @pytest.mark.parametrize("order", ["none", "import", "first"])
 def test_rccl_communicator_comes_up_in_every_import_order(order):
     """A PyTorch wheel bundles its own ROCm runtime; a process holds one or two runtimes depending on who came first, and

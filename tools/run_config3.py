@@ -18,6 +18,8 @@ xa = os.environ.get("DSMGP_RUN_ARGS", "")      # A/B runs (tools/ab_libs.sh): th
 def options(ctx):
     if "--no-diag-ahead" in xa:
         ctx.set_option(dsm.hipabi.OPT_DIAG_IN_UPDATE, 0)
+    if "--graph" in xa:
+        ctx.set_option(dsm.hipabi.OPT_FIT_GRAPH, 1)
 options(gp.model.ctx)
 def step2():
     dsm.update_cholesky(gp); return dsm.prediction(gp, Xt)
