@@ -453,7 +453,7 @@ def main():
             kname = ("tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along, each task "
                      "evaluating the kernel function of its own tile; <false, 0, true> in launches with >= 10 % short tiles; "
                      "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel, the shallow block steps "
-                     "(K <= 512) as diag_fused_kernel + tile_fused_kernel: all timed apart, device_seconds_per_step)")
+                     "(K <= 512) as diag_fused_reg_kernel + tile_fused_kernel: all timed apart, device_seconds_per_step; the diagonal blocks of the other steps ride in these launches as DiagFinishTasks)")
         avg_launch = t_cat / max(1, n_l)
         flops_per_launch = fl_step * args.steps / max(1, n_l)
         achieved = flops_per_launch / avg_launch / 1e12

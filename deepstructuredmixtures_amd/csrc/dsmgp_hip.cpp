@@ -86,7 +86,7 @@ struct StepLists {
     DevBuf<TileTask> upd, trsm;
     DevBuf<ReduceTask> red;
     DevBuf<DiagTask> diag;
-    // steps with more diagonal blocks than CUs run fused (kernels_fused.hpp): diag_fused_kernel, then tile_fused_kernel
+    // steps with more diagonal blocks than CUs run fused (kernels_fused.hpp): diag_fused_reg_kernel, then tile_fused_kernel
     std::vector<int> fdiag_off, ftile_off;                   // size nsteps+1; a fused step has no classic tasks and vice versa
     std::vector<char> mode;                                  // STEP_* per step
     DevBuf<DiagFusedTask> fdiag;
@@ -275,6 +275,10 @@ struct UpdateSplitter {
             if (r > 0 && r * 4 < (size_t)ncu) S = std::max(S, (int)std::min<size_t>((size_t)ncu / r, 16));   // tiny remainder: finer
             S = std::min(S, std::max(1, K / 256));
             if (S <= 1 || r == 0) ntail = 0;   // an exact multiple of the CU count already ends evenly
+            // (Round 4 tried cutting the last ncu whole tiles in two along K where the whole tiles make an odd number of ncu-rounds
+            // -- the reasoning: two workgroups per CU, so an odd round would run one workgroup per CU at 64 % of the pipe.  No
+            // effect: headline 0.3847 / 0.3848 / 0.3854 without, 0.3847 / 0.3860 / 0.3853 with; slots free up one by one, there
+            // is no such round.)
             emit(tiles, 0, T - ntail, 1, slab);
             tail_begin = upd.size();
             if (ntail) emit(tiles, T - ntail, T, S, slab);
@@ -367,7 +371,7 @@ struct dsmgp_ctx {
                                     // the update launch (DiagFinishTask, kernels_fused.hpp)
     // per phase and block step (decided by build_plan):
     //   STEP_CLASSIC    update (all tiles, split-K) / reduce / diagonal block / panel solve launches, one after the other
-    //   STEP_FUSED      many leaves: diag_fused_kernel, then tile_fused_kernel, from the kernel function (kernels_fused.hpp)
+    //   STEP_FUSED      many leaves: diag_fused_reg_kernel, then tile_fused_kernel, from the kernel function (kernels_fused.hpp)
     // (A third, lookahead schedule -- the update of step k cut at its last block column, the bulk on this stream, the rank-128
     // finish + diagonal block + solve on a second, high-priority stream beside the bulk of step k + 1 -- was built in round 3
     // and measured in every regime it was meant for: headline 0.4037 / 0.4055 s against 0.3906 / 0.3992, config 2 3.51 against
@@ -1507,7 +1511,7 @@ struct PhaseTimer {
 };
 
 // One factorisation phase on the context's stream.  Classic step: update (-> split-K reduce) -> diagonal block -> panel solve.
-// Fused step (many leaves, or shallow): diag_fused_kernel -> tile_fused_kernel.
+// Fused step (many leaves, or shallow): diag_fused_reg_kernel -> tile_fused_kernel.
 int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
     for (int k = 0; k < S.nsteps; ++k) {
         const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
@@ -1515,7 +1519,7 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
         if (nfd > 0 || nft > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
             if (nfd > 0) {
                 pt.begin(2);
-                diag_fused_kernel<<<nfd, 256, DIAGP_LDS_BYTES, c->stream>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
+                diag_fused_reg_kernel<<<nfd, 256, DIAGR_LDS_BYTES, c->stream>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
                 pt.note(k, nfd, 0);
                 pt.end();
             }
@@ -1617,8 +1621,6 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(diag_fused_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dinv_complete_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);

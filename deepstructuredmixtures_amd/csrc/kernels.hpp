@@ -1660,7 +1660,7 @@ __device__ __forceinline__ void packed_inverse_phase(const DiagTask& tk, const d
     }
 }
 
-// have_image: the caller has already put the lower blocks of the tile into the image (diag_fused_kernel: straight from
+// have_image: the caller has already put the lower blocks of the tile into the image (diag_finish_body: straight from
 // the accumulators of the tile's update); the barrier below makes them visible
 // (Rotating the wave roles with the workgroup index, so that the pivot chains of the two workgroups of a CU run on different
 // SIMDs, measured no difference: depth 4 0.0604 / 0.0593 / 0.0594 s without, 0.0596 / 0.0597 / 0.0586 s with, same box.)

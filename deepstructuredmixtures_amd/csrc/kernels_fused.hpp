@@ -8,11 +8,12 @@
 // chain of dependent launches kept as short as possible.  With thousands of leaves the diagonal tiles of a step fill the
 // chip by themselves, so the step is reordered (src/AdvancedCholeskey.jl:161-171 does the same per leaf: the diagonal
 // block first, then the panel below it):
-//     diag_fused_kernel   per leaf: S = K(k,k) - F[k,0:K] F[k,0:K]^T (lower blocks, straight into the LDS image),
+//     diag_fused_reg_kernel  per leaf: S = K(k,k) - F[k,0:K] F[k,0:K]^T (lower blocks; they STAY in the accumulators: round 4),
 //                         L_kk = chol(S), z_k, Dinv_k               -- the tile never exists unfactorised in memory
 //     tile_fused_kernel   per tile below: C = K(i,k) - F[i,0:K] F[k,0:K]^T stays in the accumulators, which ARE the
 //                         second operand of the solve (register r of a 16x16 result = k-slab r of the operand);
-//                         X = C Dinv_k^T with Dinv_k's 36 lower blocks staged once in LDS; the tile is written once
+//                         X L_kk^T = C by block forward substitution against L_kk's blocks staged once in LDS (round 4;
+//                         a product with Dinv_k before); the tile is written once
 // Two launches per step, no Gram launch for block column 0 (K = 0: the tasks start at the kernel function), and at depth 4
 // about 60 GB of the 210 GB a fit moves are not moved.  The arithmetic is that of the classic step -- the products sum over
 // K chunk by chunk, the Gram values come from gram_accumulate / gram_finish, the solve sums over j in groups of four
@@ -23,6 +24,7 @@
 // (test_fused_steps_agree_with_the_classic_steps).
 #pragma once
 #include <type_traits>
+#include <utility>
 #include "kernels.hpp"
 
 namespace dsmgp {
@@ -30,12 +32,15 @@ namespace dsmgp {
 #ifndef DSMGP_SOLVE_DUAL
 #define DSMGP_SOLVE_DUAL 1
 #endif
+#ifndef DSMGP_DIAGR_WGS
+#define DSMGP_DIAGR_WGS 3                 // workgroups per CU the register-resident diagonal-block task is compiled for
+#endif
 
 struct FusedTask {
     const double* A;      // row panel F[i, 0:K] (or the rows of K_tn L^-T so far), ld lda
     const double* B;      // column panel F[k, 0:K], ld ldb
     double* C;            // the tile, written once: (K(i,k) - A B^T) Dinv_k^T
-    const double* Dinv;   // inverse of the step's diagonal block (ld 128), from diag_fused_kernel of the same step
+    const double* Dinv;   // Dinv_k (ld 128) from the diagonal-block task of the same step: its diagonal 16x16 blocks are what is read
     const double* zk;     // riders, as in TileTask: z_k (128) ...
     double* wi;           // ... train rows: w_i -= X z_k; test rows (sq set): mu += X z_k.  NULL = none
     double* sq;           // test rows: sum of squares of the solved row
@@ -507,19 +512,17 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
     }
 }
 
-// MEM: S starts from the tile in memory -- which holds K(k,k) minus the product over the columns BEFORE this task's K range: an
-// earlier update launch wrote it (the diagonal-block tasks that ride in the update launches, DiagFinishTask) -- instead of from
-// the kernel function.
-template <int SHAPE, bool MEM = false>
-__device__ __forceinline__ void diag_fused_front(const TileTask& tt, const KParam* __restrict__ kp, int D, double* S,
-                                                 const int (&blk)[6]) {
+// Front of a DiagFinishTask (the diagonal-block tasks that ride in the update launches): the update of the diagonal tile over
+// the task's K range on the tile in memory -- which holds K(k,k) minus the product over the columns BEFORE that range: an earlier
+// update launch wrote it -- straight into the packed LDS image of chol_diag_packed_body.
+template <int SHAPE>
+__device__ __forceinline__ void diag_finish_front(const TileTask& tt, double* S, const int (&blk)[6]) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
     d4 acc[9];
     syrk_mainloop<SHAPE>(tt, acc, sA, blk);                 // ends on a barrier: the ring is free
-    if constexpr (MEM) {
-        // S = tile - product over this task's columns, block by block in the accumulator layout (36 loads in flight)
+    {   // S = tile - product over this task's columns, block by block in the accumulator layout (36 loads in flight)
         const size_t ldc = (size_t)tt.ldc;
         double cv[9][4];
 #pragma unroll
@@ -536,13 +539,6 @@ __device__ __forceinline__ void diag_fused_front(const TileTask& tt, const KPara
         for (int i = 0; i < 9; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][r] = cv[i][r] - acc[i][r];
-    } else {
-        const KParam p = kp[tt.kid];
-        gram_stage_coords(tt, D, S, nullptr, false);        // coordinates over the ring (barrier inside)
-        if (p.kind == 0) syrk_gram_inplace<SHAPE, 0>(tt, p, D, acc, blk, S);
-        else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1>(tt, p, D, acc, blk, S);
-        else syrk_gram_inplace<SHAPE, 2>(tt, p, D, acc, blk, S);
-        __syncthreads();                                    // the coordinates are no longer read: the image takes their place
     }
 #pragma unroll
     for (int g3 = 0; g3 < 3; ++g3)
@@ -562,9 +558,216 @@ __device__ __forceinline__ void diag_fused_front(const TileTask& tt, const KPara
         }
 }
 
-__global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask* __restrict__ tasks, const KParam* __restrict__ kp, int D) {
-    extern __shared__ __attribute__((aligned(16))) double S[];   // DIAGP_LDS_BYTES: ring / coordinates / image share the front
-    static_assert(NRING * KC2 * LDP <= PIMG && GRAM_FUSE_MAX_D * TB <= PIMG, "ring and coordinates must fit under the image");
+// ---------------------------------------------------------------------------------------------
+// Diagonal-block task of a fused step with the trailing matrix in REGISTERS (round 4).  chol_diag_packed_body keeps the 36
+// lower 16x16 blocks in a 75 KB LDS image: two workgroups per CU, i.e. two latency-bound pivot chains in flight, and every
+// trailing block read, updated and written back through LDS at every block step.  But the update of the tile leaves each wave
+// with nine of the 36 blocks in its accumulators (syrk_mainloop), and a block in accumulator layout is BOTH operands of the
+// f64 MFMA as it stands (register q as A operand: M(i = l15, k = 4q + l4); as B operand: M^T): the blocks can stay where they
+// are.  Per block step J only the column's own blocks go through LDS -- L_JJ^-1 (2 KB) and the solved panel (<= 7 x 2 KB):
+//   P0  the wave that owns (J,J): potrf + inverse of the 16x16 block in registers (potrf_inv16_mfma), L_JJ -> tile,
+//       L_JJ^-1 -> Dinv and -> LDS                                                           | barrier
+//   P1  every wave, its blocks (I,J), I > J: S(I,J) <- S(I,J) L_JJ^-T from the registers; -> registers, panel (LDS), tile;
+//       z_J = L_JJ^-1 w_J                                                                      | barrier
+//   P2  every wave, its blocks (I,K), I >= K > J: S(I,K) -= S(I,J) S(K,J)^T, both operands from the panel, accumulated on
+//       the registers; w_I -= L(I,J) z_J
+// 20 KB of LDS beside the update's 36 KB ring (they alias), registers for nine blocks: three workgroups per CU.
+// No inverse phase (the fused steps' tile tasks substitute against L_kk: tile_fused_body).
+constexpr int DIAGR_PANEL = 8 * 256;                         // doubles: solved panel, block row I at 256 I (column-major, ld 16)
+constexpr int DIAGR_LDS_DOUBLES = DIAGR_PANEL + 256 + 2 * TB + 2;   // + L_JJ^-1 + rhs block + z + first bad pivot
+constexpr int DIAGR_LDS_BYTES = ((NRING * KC2 * LDP > DIAGR_LDS_DOUBLES ? NRING * KC2 * LDP : DIAGR_LDS_DOUBLES) + 16) * (int)sizeof(double);
+
+// Which block an accumulator of wave W holds (the layout syrk_mainloop leaves): waves 0..2 a 3x3 square of blocks, wave 3 the
+// three 2x2 lower triangles on the diagonal.  Compile-time, so that with the block steps unrolled every "does this wave own
+// a block of column J" folds away and a step is straight-line code: the 16x16 factorisation of the NEXT diagonal block (a
+// latency-bound chain of vector instructions) and the wave's remaining trailing products (independent MFMAs) can interleave.
+__host__ __device__ constexpr int diagr_rb(int w, int i) {
+    return w == 3 ? (i / 3) * 3 + (i % 3 > 0 ? 1 : 0) : (w == 2 ? 2 : 5) + i / 3;
+}
+__host__ __device__ constexpr int diagr_cb(int w, int i) {
+    return w == 3 ? (i / 3) * 3 + (i % 3 > 1 ? 1 : 0) : (w == 1 ? 3 : 0) + i % 3;
+}
+static_assert(diagr_rb(3, 4) == 4 && diagr_cb(3, 4) == 3 && diagr_rb(3, 8) == 7 && diagr_cb(3, 8) == 7 && diagr_rb(0, 5) == 6 &&
+                  diagr_cb(0, 5) == 2 && diagr_rb(1, 4) == 6 && diagr_cb(1, 4) == 4 && diagr_rb(2, 8) == 4 && diagr_cb(2, 8) == 2,
+              "accumulator -> block map of syrk_mainloop");
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int W>
+__device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], double* S) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double* panel = S;
+    double* sLinv = S + DIAGR_PANEL;
+    double* wl = sLinv + 256;
+    double* zl = wl + TB;
+    int* sbad = reinterpret_cast<int*>(zl + TB);
+    const bool fuse = tk.wk != nullptr;
+    if (fuse && t < TB) {
+        wl[t] = tk.wk[t];
+        zl[t] = 0.0;
+    }
+    if (t == 0) sbad[0] = 0;
+    const int JN = (tk.nvalid + 15) >> 4;
+    {   // what is known to be zero in the tile goes out now (chol_diag_packed_body does the same)
+        const int mc = lane >> 3, mr = 2 * (lane & 7);
+        const d2 zero = {0.0, 0.0};
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int b = W + 4 * q, I = b >> 3, K = b & 7;
+            if (I < K || (I > K && K >= JN)) {
+                double* gT = tk.T + (size_t)(16 * I + mr) + (size_t)(16 * K + mc) * tk.ld;
+                *reinterpret_cast<d2*>(gT) = zero;
+                *reinterpret_cast<d2*>(gT + (size_t)8 * tk.ld) = zero;
+            }
+        }
+    }
+    const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    // P0 of block step J, by the wave that owns (J,J): L_JJ -> tile, L_JJ^-1 -> Dinv and LDS
+    auto factor_diag = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        static_for<9>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (diagr_rb(W, i) == J && diagr_cb(W, i) == J) {
+                d4 lt, xi;
+                const int bj = potrf_inv16_mfma(acc[i], lt, xi, lane);
+                if (bj != 0 && lane == 0 && sbad[0] == 0) sbad[0] = J * 16 + bj;
+                // lt register g = L(l15, 4g + l4), xi register g = L^-1(4g + l4, l15)
+                const gf64_ptr gT = AS_GLOBAL_F64(tk.T + (size_t)(16 * J + l15) + (size_t)(16 * J + l4) * tk.ld);
+                const gf64_ptr gD = AS_GLOBAL_F64(tk.Dinv + (size_t)(16 * J + l4) + (size_t)(16 * J + l15) * TB);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int q = 4 * g + l4;
+                    gT[(size_t)(4 * g) * tk.ld] = (l15 >= q) ? lt[g] : 0.0;
+                    const double x = (q >= l15) ? xi[g] : 0.0;
+                    gD[4 * g] = x;
+                    sLinv[l15 * 16 + q] = x;
+                }
+            }
+        });
+    };
+    lds_barrier();
+    factor_diag(std::integral_constant<int, 0>{});
+    static_for<8>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if (J < JN) {       // workgroup-uniform
+            lds_barrier();  // L_JJ^-1 is in LDS; the panel of step J - 1 is no longer read
+            // P1: S(I,J) <- S(I,J) L_JJ^-T for the wave's own blocks of column J
+            {
+                double la[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) la[q] = sLinv[(4 * q + l4) * 16 + l15];
+                static_for<9>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int rb = diagr_rb(W, i), cb = diagr_cb(W, i);
+                    if constexpr (cb == J && rb > J) {
+                        d4 u = __builtin_amdgcn_mfma_f64_16x16x4f64(la[0], acc[i][0], zero4, 0, 0, 0);
+                        d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(la[1], acc[i][1], zero4, 0, 0, 0);
+                        u = __builtin_amdgcn_mfma_f64_16x16x4f64(la[2], acc[i][2], u, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f64_16x16x4f64(la[3], acc[i][3], v, 0, 0, 0);
+                        const d4 x = u + v;
+                        acc[i] = x;
+                        double* ps = panel + rb * 256 + l15;
+                        const gf64_ptr g0 = AS_GLOBAL_F64(tk.T + (size_t)(16 * rb + l15) + (size_t)(16 * J + l4) * tk.ld);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ps[(l4 + 4 * r) * 16] = x[r];
+                            g0[(size_t)(4 * r) * tk.ld] = x[r];
+                        }
+                    }
+                });
+                if (W == 3 && fuse && lane < 16) {      // z_J = L_JJ^-1 w_J
+                    const double* linv = sLinv + lane;
+                    double sum = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) sum = fma(linv[c * 16], wl[16 * J + c], sum);
+                    zl[16 * J + lane] = sum;
+                }
+            }
+            lds_barrier();
+            // P2: S(I,K) -= S(I,J) S(K,J)^T on the registers, operands from the panel -- the next diagonal block first, and its
+            // factorisation (P0 of step J + 1: registers and sLinv only, which nobody reads before the next barrier) right
+            // behind it, beside the rest of this wave's products
+            auto trailing = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int rb = diagr_rb(W, i), cb = diagr_cb(W, i);
+                const double* pk = panel + cb * 256 + l15;
+                const double* pi = panel + rb * 256 + l15;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pk[(4 * q + l4) * 16], pi[(4 * q + l4) * 16], acc[i], 0, 0, 0);
+            };
+            static_for<9>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (diagr_rb(W, i) == J + 1 && diagr_cb(W, i) == J + 1) trailing(ic);
+            });
+            if constexpr (J + 1 < 8) {
+                if (J + 1 < JN) factor_diag(std::integral_constant<int, J + 1>{});
+            }
+            static_for<9>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (diagr_cb(W, i) > J && !(diagr_rb(W, i) == J + 1 && diagr_cb(W, i) == J + 1)) trailing(ic);
+            });
+            if (fuse && t < TB && t >= 16 * (J + 1)) {      // w_I -= L(I,J) z_J for the rows below block J
+                const double* lrow = panel + (t >> 4) * 256 + (t & 15);
+                double sum = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sum = fma(lrow[c * 16], zl[16 * J + c], sum);
+                wl[t] -= sum;
+            }
+        }
+    });
+    lds_barrier();
+    if (fuse && t < TB) tk.zk[t] = zl[t];
+    if (W == 0 && lane < 32) {             // identity diagonal blocks of the steps without data
+        const int c = l15;
+        const bool isb = (lane & 16) != 0;
+        for (int J = JN; J < 8; ++J) {
+            double* gdst = isb ? tk.Dinv + (size_t)(16 * J) + (size_t)(16 * J + c) * TB
+                               : tk.T + (size_t)(16 * J) + (size_t)(16 * J + c) * tk.ld;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                d2 v;
+                v[0] = (r == c) ? 1.0 : 0.0;
+                v[1] = (r + 1 == c) ? 1.0 : 0.0;
+                *reinterpret_cast<d2*>(gdst + r) = v;
+            }
+        }
+    }
+    if (t == 0) {
+        const int bad = sbad[0];
+        if (bad != 0 && bad <= tk.nvalid && *tk.info == 0) *tk.info = tk.row0 + bad;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void diag_fused_reg(const TileTask& tt, const DiagTask& d, const KParam* __restrict__ kp, int D, double* S) {
+    constexpr int SHAPE = W == 3 ? 1 : 0;
+    constexpr int rbase = (W == 2) ? 2 : 5, cbase = (W == 1) ? 3 : 0;
+    const int blk[6] = {W == 3 ? 0 : rbase, W == 3 ? 1 : rbase + 1, W == 3 ? 3 : rbase + 2,
+                        W == 3 ? 4 : cbase, W == 3 ? 6 : cbase + 1, W == 3 ? 7 : cbase + 2};
+    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
+    d4 acc[9];
+    syrk_mainloop<SHAPE>(tt, acc, sA, blk);                 // ends on a barrier: the ring is free
+    const KParam p = kp[tt.kid];
+    gram_stage_coords(tt, D, S, nullptr, false);            // coordinates over the ring (barrier inside)
+    if (p.kind == 0) syrk_gram_inplace<SHAPE, 0>(tt, p, D, acc, blk, S);
+    else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1>(tt, p, D, acc, blk, S);
+    else syrk_gram_inplace<SHAPE, 2>(tt, p, D, acc, blk, S);
+    __syncthreads();                                        // the coordinates are no longer read: panel and rhs take their place
+    diag_reg_body<W>(d, acc, S);
+}
+
+__global__ __launch_bounds__(256, DSMGP_DIAGR_WGS) void diag_fused_reg_kernel(const DiagFusedTask* __restrict__ tasks,
+                                                                              const KParam* __restrict__ kp, int D) {
+    extern __shared__ __attribute__((aligned(16))) double S[];   // DIAGR_LDS_BYTES: ring / coordinates / panel share the space
+    static_assert(GRAM_FUSE_MAX_D * TB * (int)sizeof(double) <= DIAGR_LDS_BYTES, "coordinates must fit");
     const DiagFusedTask ft = tasks[blockIdx.x];
     TileTask tt{};
     tt.A = ft.A;
@@ -577,17 +780,14 @@ __global__ __launch_bounds__(256, 2) void diag_fused_kernel(const DiagFusedTask*
     tt.gna = tt.gnb = ft.d.nvalid;
     tt.C = ft.d.T;
     tt.ldc = ft.d.ld;
+    // (Giving the role that owns six of the eight diagonal 16x16 blocks -- 3: their pivot chains -- to a different wave in every
+    // workgroup, so that the chains of co-resident tasks sit on different SIMDs, measured nothing: depth 4 0.0516-0.0522 s with
+    // the role shifted by blockIdx, blockIdx / 8 or blockIdx / 256 as without.)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (w == 3) {
-        const int blk[6] = {0, 1, 3, 4, 6, 7};
-        diag_fused_front<1>(tt, kp, D, S, blk);
-    } else {
-        const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
-        const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
-        diag_fused_front<0>(tt, kp, D, S, blk);
-    }
-    chol_diag_packed_body<false, false>(ft.d, S, true);      // its first barrier publishes the image; no inverse phase: the
-                                                             // step's tile tasks substitute against L_kk (tile_fused_body)
+    if (w == 0) diag_fused_reg<0>(tt, ft.d, kp, D, S);
+    else if (w == 1) diag_fused_reg<1>(tt, ft.d, kp, D, S);
+    else if (w == 2) diag_fused_reg<2>(tt, ft.d, kp, D, S);
+    else diag_fused_reg<3>(tt, ft.d, kp, D, S);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,11 +824,11 @@ __device__ __forceinline__ void diag_finish_body(const DiagFinishTask& ft, doubl
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (w == 3) {
         const int blk[6] = {0, 1, 3, 4, 6, 7};
-        diag_fused_front<1, true>(tt, nullptr, 0, S, blk);
+        diag_finish_front<1>(tt, S, blk);
     } else {
         const int rbase = (w == 2) ? 2 : 5, cbase = (w == 1) ? 3 : 0;
         const int blk[6] = {rbase, rbase + 1, rbase + 2, cbase, cbase + 1, cbase + 2};
-        diag_fused_front<0, true>(tt, nullptr, 0, S, blk);
+        diag_finish_front<0>(tt, S, blk);
     }
     chol_diag_packed_body(ft.d, S, true);                    // its first barrier publishes the image
 }

@@ -1318,7 +1318,7 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
     """Small-leaf regime: a table of 700 leaves of 130..700 rows -- last row tiles of every class (<= 32,
     <= 64, <= 96, whole), 10..150 routed test rows per leaf (short and whole test tiles, two tiles for some), a COPY and
     a PREFIX leaf -- has more diagonal blocks per step than the chip has CUs, so its block steps run fused
-    (diag_fused_kernel + tile_fused_kernel: each tile written once, short tiles in the 16-rows-per-wave form); with
+    (diag_fused_reg_kernel + tile_fused_kernel: each tile written once, short tiles in the 16-rows-per-wave form); with
     DSMGP_OPT_FUSED_STEPS = 0 the same table runs as update (short tiles in the column-split form) / packed diagonal
     block / panel solve launches.  Same arithmetic up to the order of one addition per entry: log-marginals 1e-12, the
     factor of sampled leaves 1e-11, moments 1e-9 (conditioning-limited); three leaves against the oracle at the
