@@ -69,7 +69,8 @@ enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 #ifndef DSMGP_FUSED_SHALLOW
 #define DSMGP_FUSED_SHALLOW 4
 #endif
-constexpr int FUSED_SHALLOW_STEPS = DSMGP_FUSED_SHALLOW;   // block steps 0..4 (K <= 512) always run fused
+constexpr int FUSED_SHALLOW_STEPS = DSMGP_FUSED_SHALLOW;   // block steps 0..4 (K <= 512) run fused where at least ...
+constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leaves take part in the step
 #ifndef DSMGP_SOLO_FACTOR
 #define DSMGP_SOLO_FACTOR 1.56             // time of one workgroup alone on a CU relative to its share of a co-resident pair
 #endif
@@ -1266,7 +1267,11 @@ int build_plan(dsmgp_ctx* c) {
             // fused: the diagonal blocks alone fill the chip -- or the step is shallow (K <= 512: the one workgroup that
             // updates a diagonal tile before factorising it is done in a few microseconds; deeper, that update belongs in
             // the many-workgroup update launch, split along K)
-            if (c->fuse_steps && (nd > c->ncu || k <= FUSED_SHALLOW_STEPS)) c->fused_step[ph][k] = STEP_FUSED;
+            // (round 4: the shallow rule only where the step has leaves enough to give the two fused launches something to
+            // do -- with the diagonal blocks one step ahead the classic steps of a handful of leaves are the shorter chain:
+            // single GP 2.49 -> 2.25-2.31 ms, 8-rank shards 0.0560-0.0568 -> 0.0553-0.0560 s with no shallow step fused; the
+            // headline model's 144 leaves and a PoE's 128 experts keep it)
+            if (c->fuse_steps && (nd > c->ncu || (k <= FUSED_SHALLOW_STEPS && nd >= FUSED_SHALLOW_MIN_LEAVES))) c->fused_step[ph][k] = STEP_FUSED;
         }
     }
     // Gram tasks: lower tiles of every owner; with the Gram fused into the update tasks only the tiles that have none --

@@ -526,21 +526,27 @@ m = dsm.buildDSMGP(X, y, 3, 4, M=80, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNois
 assert 0 < len(m.shard.local) < m.L
 z = dsm.update(m)
 mu, var = dsm.predict(m, Xt)
-assert np.array_equal(m.leaf_mll, ref["leaf_mll"]) and z == float(ref["z"])
+# per-leaf values: to rounding, not to the bit -- how a block step is scheduled (fused or classic launches, how many K-pieces
+# per tile) depends on how many leaves and tiles share the launch, i.e. on the shard
+assert np.allclose(m.leaf_mll, ref["leaf_mll"], rtol=1e-12, atol=0) and abs(z - float(ref["z"])) <= 1e-12 * abs(float(ref["z"]))
 # predict: every rank aggregates its own leaves on its device, the partial sums are added in rank order -- another
 # association than the single-context sum over all leaves, the same terms
 assert np.allclose(mu, ref["mu"], rtol=1e-12, atol=1e-13) and np.allclose(var, ref["var"], rtol=1e-10, atol=1e-13)
 dsm.updategradients(m)
-assert np.array_equal(dsm.grad_mll(m), ref["grad"])
+assert np.allclose(dsm.grad_mll(m), ref["grad"], rtol=1e-9, atol=1e-9)
+both = [None, None]
+td.all_gather_object(both, (m.leaf_mll.tobytes(), mu.tobytes(), var.tobytes()))
+assert both[0] == both[1]                       # the ranks hold the same bits
 td.barrier(); td.destroy_process_group()
 print("rank", rank, "ok", len(m.shard.local))
 """
 
 
-def test_two_ranks_sharing_leaves_reproduce_the_single_process_result_bitwise(tmp_path):
+def test_two_ranks_sharing_leaves_reproduce_the_single_process_result(tmp_path):
     """Leaf sharding through the real HIP contexts (two processes on the one GPU of this box, gloo for the
-    all-gathers): per-leaf results (log-marginals, gradients) are bit-identical to the unsharded run; the aggregated
-    prediction adds per-rank partial sums and agrees to rounding."""
+    all-gathers): per-leaf results (log-marginals, gradients) equal the unsharded run's to rounding (1e-12: the launch
+    schedule of a block step depends on how many leaves share it), the aggregated prediction adds per-rank partial sums and
+    agrees to rounding, and both ranks end up with the SAME bits."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
