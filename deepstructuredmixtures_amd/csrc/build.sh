@@ -3,6 +3,7 @@
 #   build.sh        the product library
 #   build.sh diag   libdsmgp_hip_diag.so: the same sources with -DDSMGP_DIAG (cycle stamps, micro-benchmarks,
 #                   scheduling knobs from the environment; tools/ only, never loaded by the package)
+#   OUT=path build.sh [-D...]   a variant build for same-box A/B runs (tools/ab_libs.sh), written to `path`
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libdsmgp_hip.so"
@@ -12,6 +13,7 @@ if [ "${1:-}" = "diag" ]; then
     out="$here/../libdsmgp_hip_diag.so"
     extra=(-DDSMGP_DIAG)
 fi
+out="${OUT:-$out}"
 # host_tree.cpp (tree builder, main-leaf search) is plain C++: no offload pass, and no fused multiply-add -- the builder
 # promises NumPy's floating-point results bit for bit
 obj="$(mktemp -d)"

@@ -69,6 +69,9 @@ enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 #ifndef DSMGP_FUSED_SHALLOW
 #define DSMGP_FUSED_SHALLOW 4
 #endif
+#ifndef DSMGP_FUSED8
+#define DSMGP_FUSED8 1                     // fused tile tasks in the eight-wave form (tile_fused8_kernel): 16-row blocks packed eight to a task
+#endif
 constexpr int FUSED_SHALLOW_STEPS = DSMGP_FUSED_SHALLOW;   // block steps 0..4 (K <= 512) run fused where at least ...
 constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leaves take part in the step
 #ifndef DSMGP_SOLO_FACTOR
@@ -92,6 +95,8 @@ struct StepLists {
     std::vector<char> mode;                                  // STEP_* per step
     DevBuf<DiagFusedTask> fdiag;
     DevBuf<FusedTask> ftile;
+    std::vector<int> ftile8_off;                             // eight-wave form of the fused tile tasks (DSMGP_FUSED8)
+    DevBuf<FusedTask8> ftile8;
     // classic steps with the diagonal block INSIDE the update launch (DiagFinishTask, kernels_fused.hpp): the update launch of
     // step k carries dfin[dfin_off[k] .. dfin_off[k+1]) behind its first dpos[k] tile tasks; a leaf whose diagonal block rides
     // there has no `diag` task in that step
@@ -613,6 +618,7 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.diag.p);
         dev_free(ph.fdiag.p);
         dev_free(ph.ftile.p);
+        dev_free(ph.ftile8.p);
         dev_free(ph.dfin.p);
         dev_free(ph.dinvc.p);
     }
@@ -664,6 +670,7 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.diag.p);
         dev_free(ph.fdiag.p);
         dev_free(ph.ftile.p);
+        dev_free(ph.ftile8.p);
         dev_free(ph.dfin.p);
         dev_free(ph.dinvc.p);
     }
@@ -810,6 +817,8 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         std::vector<TileTask> trsm;
         std::vector<DiagTask> diag;
         std::vector<FusedTask> ftile;
+        std::vector<FusedTask8> ftile8;
+        std::vector<RowBlock> blocks8;      // 16-row blocks of one leaf below the step's diagonal block: factor rows, then test rows
         std::vector<DiagFusedTask> fdiag;
         std::vector<DiagFinishTask> dfin;
         std::vector<DiagTask> dinvc;
@@ -821,6 +830,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.diag_off.assign(nsteps + 1, 0);
         S.fdiag_off.assign(nsteps + 1, 0);
         S.ftile_off.assign(nsteps + 1, 0);
+        S.ftile8_off.assign(nsteps + 1, 0);
         S.step_tiles.assign(nsteps, 0);
         S.pad.assign(nsteps, 0);
         S.mode.assign(nsteps, STEP_CLASSIC);
@@ -831,6 +841,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             S.diag_off[k] = (int)diag.size();
             S.fdiag_off[k] = (int)fdiag.size();
             S.ftile_off[k] = (int)ftile.size();
+            S.ftile8_off[k] = (int)ftile8.size();
             S.dfin_off[k] = (int)dfin.size();
             const int mode = k < (int)c->fused_step[ph].size() ? c->fused_step[ph][k] : STEP_CLASSIC;
             S.mode[k] = (char)mode;
@@ -859,6 +870,20 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         if (fstep) {      // fused step: the diagonal tile belongs to the diagonal-block task, the tiles below
                                           // are updated and solved in one task each
                             if (i == k) continue;
+                            if (DSMGP_FUSED8) {       // the tile's 16-row blocks that hold data; the rows beyond stay zero (zero_pad_rows)
+                                const int rows = std::max(0, std::min(TB, lf.n - i * TB));
+                                for (int r = 0; r < rows; r += 16) {
+                                    RowBlock b{};
+                                    b.A = d.F + (size_t)i * TB + r;
+                                    b.C = d.F + (size_t)i * TB + r + (size_t)k * TB * ld;
+                                    b.gx = d.Xg + (size_t)i * TB + r;
+                                    b.lda = b.ldc = b.glda = ld;
+                                    b.nvalid = std::min(16, rows - r);
+                                    if (ph != 1) b.wi = d.w + (size_t)i * TB + r;
+                                    blocks8.push_back(b);
+                                }
+                                continue;
+                            }
                             FusedTask f{};
                             f.A = d.F + (size_t)i * TB;
                             f.B = d.F + (size_t)k * TB;
@@ -979,6 +1004,23 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 if (with_test && lf.nt > 0) {
                     for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
                         double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
+                        if (fstep && DSMGP_FUSED8) {
+                            const int rows = std::max(0, std::min(TB, lf.nt - ti * TB));
+                            for (int r = 0; r < rows; r += 16) {
+                                RowBlock b{};
+                                b.A = d.Vt + (size_t)ti * TB + r;
+                                b.C = tile + r;
+                                b.gx = d.Xtg + (size_t)ti * TB + r;
+                                b.lda = b.ldc = b.glda = lf.ntpad;
+                                b.nvalid = std::min(16, rows - r);
+                                if (d.zfused) {
+                                    b.wi = d.macc + (size_t)ti * TB + r;
+                                    b.sq = d.sacc + (size_t)ti * TB + r;
+                                }
+                                blocks8.push_back(b);
+                            }
+                            continue;
+                        }
                         if (fstep) {
                             FusedTask f{};
                             f.A = d.Vt + (size_t)ti * TB;
@@ -1048,6 +1090,25 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         trsm.push_back(s);
                     }
                 }
+                // eight-wave fused tile tasks: the leaf's 16-row blocks of this step, eight to a task (the last factor rows and
+                // the test rows share tasks; all of them read the same B panel, L_kk and column coordinates)
+                for (size_t b0 = 0; b0 < blocks8.size(); b0 += 8) {
+                    FusedTask8 f{};
+                    f.B = d.F + (size_t)k * TB;
+                    f.Dinv = d.Dinv + (size_t)k * TB * TB;
+                    f.gxb = d.Xg + (size_t)k * TB;
+                    f.ldb = f.gldb = ld;
+                    f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                    f.k1 = k * TB;
+                    f.kid = lf.kid;
+                    f.nblk = (int)std::min<size_t>(8, blocks8.size() - b0);
+                    for (int q = 0; q < f.nblk; ++q) {
+                        f.rb[q] = blocks8[b0 + q];
+                        if (f.rb[q].wi != nullptr) f.zk = d.z + (size_t)k * TB;
+                    }
+                    ftile8.push_back(f);
+                }
+                blocks8.clear();
             }
             // The lower-blocks-only form of a diagonal tile takes ~0.6 of a full tile (tools/bench_tile_sym.py).  It pays
             // where diagonal tiles are a large share of a launch (many small leaves: -6 % on the update launches of the
@@ -1089,6 +1150,8 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 xcd_permute(trsm, unused, (size_t)S.trsm_off[k], trsm.size(), c->xcd_order);
                 std::vector<int> unused2(ftile.size());      // fused tiles of a leaf share its B panel and Dinv_k
                 xcd_permute(ftile, unused2, (size_t)S.ftile_off[k], ftile.size(), c->xcd_order);
+                std::vector<int> unused3(ftile8.size());
+                xcd_permute(ftile8, unused3, (size_t)S.ftile8_off[k], ftile8.size(), c->xcd_order);
             }
         }
         S.upd_off[nsteps] = (int)U.upd.size();
@@ -1097,6 +1160,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.diag_off[nsteps] = (int)diag.size();
         S.fdiag_off[nsteps] = (int)fdiag.size();
         S.ftile_off[nsteps] = (int)ftile.size();
+        S.ftile8_off[nsteps] = (int)ftile8.size();
         S.dfin_off[nsteps] = (int)dfin.size();
         if (int rc = dev_upload(c, S.dfin, dfin)) return rc;
         if (int rc = dev_upload(c, S.dinvc, dinvc)) return rc;
@@ -1104,6 +1168,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
         if (int rc = dev_upload(c, S.fdiag, fdiag)) return rc;
         if (int rc = dev_upload(c, S.ftile, ftile)) return rc;
+        if (int rc = dev_upload(c, S.ftile8, ftile8)) return rc;
     }
     {
         const size_t slabs = std::max(split[0].max_slabs, split[1].max_slabs);
@@ -1241,6 +1306,27 @@ int build_plan(dsmgp_ctx* c) {
             gather_leaf_kernel<<<grid, 256, 0, c->stream>>>(c->d_leaves, c->d_obs_ptr, c->d_obs_idx, c->dX, c->dy,
                                                             c->N, c->D, l0);
         }
+        HIPCHK(c, hipGetLastError());
+    }
+    // The eight-wave fused tile tasks write the 16-row blocks of a factor that hold data and nothing else: the rows below them
+    // in a leaf's last row tile -- padding, which the classic steps and every sweep over the factor expect to be zero -- are
+    // zeroed here, once per plan (nothing writes anything else there afterwards)
+    DevBuf<ZeroRowsTask> zrows;
+    if (DSMGP_FUSED8 && gram_fused(c)) {
+        std::vector<ZeroRowsTask> zr;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            const int last = lf.n - (lf.nb - 1) * TB;
+            if (lf.owner != l || lf.nb < 2 || last >= TB) continue;
+            ZeroRowsTask z{};
+            z.p = c->h_leaves[l].F + (size_t)(lf.nb - 1) * TB;
+            z.ld = lf.npad;
+            z.r0 = (std::max(0, last) + 15) / 16 * 16;
+            z.ncols = (lf.nb - 1) * TB;
+            if (z.r0 < TB) zr.push_back(z);
+        }
+        if (int rc = dev_upload(c, zrows, zr)) return rc;
+        if (!zr.empty()) zero_pad_rows_kernel<<<(int)zr.size(), 256, 0, c->stream>>>(zrows.p);
         HIPCHK(c, hipGetLastError());
     }
 
@@ -1416,6 +1502,7 @@ int build_plan(dsmgp_ctx* c) {
         if (int rc = dev_upload(c, c->bwd, bwd)) return rc;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(zrows.p);
     c->plan_ready = true;
     c->pool_mark_plan = c->pool_top;
     return 0;
@@ -1520,8 +1607,9 @@ struct PhaseTimer {
 int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
     for (int k = 0; k < S.nsteps; ++k) {
         const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
+        const int nft8 = S.ftile8_off[k + 1] - S.ftile8_off[k];
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
-        if (nfd > 0 || nft > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
+        if (nfd > 0 || nft > 0 || nft8 > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
             if (nfd > 0) {
                 pt.begin(2);
                 diag_fused_reg_kernel<<<nfd, 256, DIAGR_LDS_BYTES, c->stream>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
@@ -1532,6 +1620,13 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
                 pt.begin(18);
                 tile_fused_kernel<<<nft, 256, 0, c->stream>>>(S.ftile.p + S.ftile_off[k], c->d_kp, c->D);
                 pt.note(k, nft, nft);
+                pt.end();
+                if (count_launches) c->n_fused_launches++;
+            }
+            if (nft8 > 0) {
+                pt.begin(18);
+                tile_fused8_kernel<<<nft8, 512, 0, c->stream>>>(S.ftile8.p + S.ftile8_off[k], c->d_kp, c->D);
+                pt.note(k, nft8, nft8);
                 pt.end();
                 if (count_launches) c->n_fused_launches++;
             }

@@ -243,13 +243,45 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 
 // Coordinates of a fused-Gram tile -> LDS: sa[d * TB + r] = x_row(r)[d], sb likewise for the columns (zeros beyond the
 // valid counts).  The ring is free once the main loop has passed its last barrier.
-__device__ __forceinline__ void gram_stage_coords(const TileTask& tk, int D, double* sa, double* sb, bool cols) {
+// Four passes of the block at a time, loads first: written as one load and one LDS store per pass the loop waits for every
+// pass's memory round trip on its own (D / 2 of them per task at D = 8).
+#ifndef DSMGP_COORDS_BATCH
+#define DSMGP_COORDS_BATCH 1
+#endif
+template <int NT = 256>
+__device__ __forceinline__ void stage_coords(const double* gxa, int glda, int gna, const double* gxb, int gldb, int gnb, int D,
+                                             double* sa, double* sb, bool cols) {
     const int t = threadIdx.x;
-    for (int e = t; e < D * TB; e += 256) {
-        const int d = e >> 7, r = e & (TB - 1);
-        sa[e] = (r < tk.gna) ? tk.gxa[r + (size_t)d * tk.glda] : 0.0;
-        if (cols) sb[e] = (r < tk.gnb) ? tk.gxb[r + (size_t)d * tk.gldb] : 0.0;
+    const int n = D * TB;
+#if DSMGP_COORDS_BATCH
+    for (int e0 = t; e0 < n; e0 += 4 * NT) {
+        double va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + NT * u;
+            const int d = e >> 7, r = e & (TB - 1);
+            va[u] = (e < n && r < gna) ? gxa[r + (size_t)d * glda] : 0.0;
+            vb[u] = (cols && e < n && r < gnb) ? gxb[r + (size_t)d * gldb] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + NT * u;
+            if (e < n) {
+                sa[e] = va[u];
+                if (cols) sb[e] = vb[u];
+            }
+        }
     }
+#else
+    for (int e = t; e < n; e += NT) {
+        const int d = e >> 7, r = e & (TB - 1);
+        sa[e] = (r < gna) ? gxa[r + (size_t)d * glda] : 0.0;
+        if (cols) sb[e] = (r < gnb) ? gxb[r + (size_t)d * gldb] : 0.0;
+    }
+#endif
+}
+__device__ __forceinline__ void gram_stage_coords(const TileTask& tk, int D, double* sa, double* sb, bool cols) {
+    stage_coords(tk.gxa, tk.glda, tk.gna, tk.gxb, tk.gldb, tk.gnb, D, sa, sb, cols);
     __syncthreads();
 }
 

@@ -32,9 +32,24 @@ namespace dsmgp {
 #ifndef DSMGP_SOLVE_DUAL
 #define DSMGP_SOLVE_DUAL 1
 #endif
+#ifndef DSMGP_TF_TAIL
+#define DSMGP_TF_TAIL 1                   // fused tile task: z_k staged in LDS with L_kk, w_i / sums of the riders fetched before the solve
+#endif
+#ifndef DSMGP_TF_QALT
+#define DSMGP_TF_QALT 0                   // 16-rows-per-wave form: the solve's two accumulators alternate per k-slab, not per block
+#endif
 #ifndef DSMGP_DIAGR_WGS
 #define DSMGP_DIAGR_WGS 3                 // workgroups per CU the register-resident diagonal-block task is compiled for
 #endif
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 struct FusedTask {
     const double* A;      // row panel F[i, 0:K] (or the rows of K_tn L^-T so far), ld lda
@@ -227,6 +242,20 @@ struct LowerBlocks {
     }
 };
 __constant__ const LowerBlocks LOWER_BLOCKS{};
+// (cb, jb) of lower block b for the staging loads of L_kk.  The block index of a load is <compile-time part> + <wave-uniform
+// part>; looked up in the table in memory, every one of a thread's loads waited for its own two table bytes first -- 18
+// dependent round trips where one would do (found in the ISA in round 4: global_load_ubyte / s_waitcnt vmcnt(1) chains).
+// Packed here into immediates, selected with scalar shifts: the loads issue back to back.
+constexpr LowerBlocks LOWER_BLOCKS_CT{};
+template <int STRIDE>       // blocks b0 .. b0 + STRIDE - 1 (clamped to nblk - 1), 8 bits each: cb in the low, jb in the high nibble
+__host__ __device__ constexpr unsigned lower_block_pack(int b0, int nblk) {
+    unsigned v = 0;
+    for (int i = 0; i < STRIDE; ++i) {
+        const int b = (b0 + i < nblk - 1) ? b0 + i : nblk - 1;
+        v |= (unsigned)(LOWER_BLOCKS_CT.cb[b] | (LOWER_BLOCKS_CT.jb[b] << 4)) << (8 * i);
+    }
+    return v;
+}
 static_assert(lower_block_base(0) == 0 && lower_block_base(5) == 15 && lower_block_base(7) == 28, "block order");
 
 // acc <- -k(row, col) in the accumulator layout of gemm_mainloop_rowsplit (register q of acc[cb][rn] is the entry
@@ -235,7 +264,7 @@ static_assert(lower_block_base(0) == 0 && lower_block_base(5) == 15 && lower_blo
 // task starts with the kernel function -- under the memory latency of its first operand loads, with the accumulators not
 // yet live -- and the accumulators end as -(K - A B^T) = -C.
 template <int KIND, int NRW, int NCB = 8>
-__device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KParam& p, int D, d4 (&acc)[NCB][NRW], const double* sa,
+__device__ __forceinline__ void rowsplit_gram_init(int gna, int gnb, const KParam& p, int D, d4 (&acc)[NCB][NRW], const double* sa,
                                                       const double* sb) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -265,7 +294,7 @@ __device__ __forceinline__ void rowsplit_gram_init(const FusedTask& tk, const KP
             const int cidx = 16 * CG * cp + 16 * (j >> 2) + l4 + 4 * (j & 3);
 #pragma unroll
             for (int rn = 0; rn < NRW; ++rn) {
-                acc[CG * cp + (j >> 2)][rn][j & 3] = -gram_finish<KIND, true>(z[rn][j], p, rowbase + 16 * rn, cidx, tk.gna, tk.gnb, false);
+                acc[CG * cp + (j >> 2)][rn][j & 3] = -gram_finish<KIND, true>(z[rn][j], p, rowbase + 16 * rn, cidx, gna, gnb, false);
             }
         }
     }
@@ -292,9 +321,11 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
     constexpr int NBLK = lower_block_base(NCB), NE = (NBLK + 1) / 2;
     const int dj = (t & 127) >> 3, di = 2 * (t & 7), dhalf = __builtin_amdgcn_readfirstlane(t >> 7);
     const double* Lkk = tk.B + (size_t)tk.k1 * (size_t)tk.ldb;
-    auto dinv_load = [&](int e) {
-        const int b = min(2 * e + dhalf, NBLK - 1);
-        const int cb = LOWER_BLOCKS.cb[b], jb = LOWER_BLOCKS.jb[b];
+    auto dinv_load = [&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        constexpr unsigned pk = lower_block_pack<2>(2 * e, NBLK);
+        const int sel = (int)(pk >> (8 * dhalf)) & 0xff;         // scalar: dhalf is wave-uniform
+        const int cb = sel & 15, jb = sel >> 4;
         const double* src = (cb == jb) ? tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB
                                        : Lkk + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * (size_t)tk.ldb;
         return *AS_GLOBAL_D2(src);
@@ -306,28 +337,36 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
         const KParam p = kp[tk.kid];
         double* sa = &sA[0][0];
         double* sb = &sB[0][0];
-        for (int e = t; e < D * TB; e += 256) {
-            const int d = e >> 7, r = e & (TB - 1);
-            sa[e] = (r < tk.gna) ? tk.gxa[r + (size_t)d * tk.glda] : 0.0;
-            sb[e] = (r < tk.gnb) ? tk.gxb[r + (size_t)d * tk.gldb] : 0.0;
-        }
+        stage_coords(tk.gxa, tk.glda, tk.gna, tk.gxb, tk.gldb, tk.gnb, D, sa, sb, true);
         __syncthreads();
-        if (p.kind == 0) rowsplit_gram_init<0, NRW, NCB>(tk, p, D, acc, sa, sb);
-        else if (p.kind == 1) rowsplit_gram_init<1, NRW, NCB>(tk, p, D, acc, sa, sb);
-        else rowsplit_gram_init<2, NRW, NCB>(tk, p, D, acc, sa, sb);
+        if (p.kind == 0) rowsplit_gram_init<0, NRW, NCB>(tk.gna, tk.gnb, p, D, acc, sa, sb);
+        else if (p.kind == 1) rowsplit_gram_init<1, NRW, NCB>(tk.gna, tk.gnb, p, D, acc, sa, sb);
+        else rowsplit_gram_init<2, NRW, NCB>(tk.gna, tk.gnb, p, D, acc, sa, sb);
         __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
     }
     gemm_mainloop_rowsplit<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB, pf);   // acc = -C; ends on a barrier: the ring is free
     double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256; block b sits at 256 b
     constexpr int NE1 = (NCB == 8) ? 9 : NE;            // first stage (NCB = 8: block rows 0..4 and three blocks of row 5)
     d2 dv[NE1];
-#pragma unroll
-    for (int e = 0; e < NE1; ++e) dv[e] = dinv_load(e);
+    static_for<NE1>([&](auto ec) { dv[decltype(ec)::value] = dinv_load(ec); });
     d2 dw[9];
-    if (NCB == 8) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) dw[e] = dinv_load(9 + e);
+    if constexpr (NCB == 8) {
+        static_for<9>([&](auto ec) { dw[decltype(ec)::value] = dinv_load(std::integral_constant<int, 9 + decltype(ec)::value>{}); });
     }
+#if DSMGP_TF_TAIL
+    // riders: z_k goes through LDS with the blocks of L_kk and the sums the task adds to are fetched now, so that the task does
+    // not end on two dependent memory round trips (z_k, then w_i read-modify-write) with its waves idle
+    double* sZ = sD + 36 * 256;
+    double wpre[NRW], spre[NRW];
+    if (tk.wi != nullptr) {
+        if (t < TB) sZ[t] = tk.zk[t];
+#pragma unroll
+        for (int rn = 0; rn < NRW; ++rn) {
+            wpre[rn] = tk.wi[16 * NRW * w + 16 * rn + l15];
+            spre[rn] = (tk.sq != nullptr) ? tk.sq[16 * NRW * w + 16 * rn + l15] : 0.0;
+        }
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < NE1; ++e)
         if (2 * e + dhalf < NBLK) *reinterpret_cast<d2*>(sD + (size_t)(2 * e + dhalf) * 256 + 2 * (t & 127)) = dv[e];
@@ -355,26 +394,32 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
                     const double a = blk[(4 * q + l4) * 16];
 #pragma unroll
                     for (int rn = 0; rn < NRW; ++rn) {
-                        if (DSMGP_SOLVE_DUAL && (jb & 1)) x1[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x1[rn], 0, 0, 0);
+                        const bool second = (DSMGP_TF_QALT && NRW == 1) ? (q & 1) != 0 : (jb & 1) != 0;
+                        if (DSMGP_SOLVE_DUAL && second) x1[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x1[rn], 0, 0, 0);
                         else x0[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x0[rn], 0, 0, 0);
                     }
                 }
             }
-            d4 tt[NRW], y[NRW];
+            constexpr bool QALT = DSMGP_TF_QALT && NRW == 1;
+            d4 tt[NRW], y[NRW], y2[NRW];
 #pragma unroll
             for (int rn = 0; rn < NRW; ++rn) {
-                tt[rn] = (DSMGP_SOLVE_DUAL && cb > 1) ? x0[rn] + x1[rn] : x0[rn];
+                tt[rn] = (DSMGP_SOLVE_DUAL && cb > (QALT ? 0 : 1)) ? x0[rn] + x1[rn] : x0[rn];
                 y[rn] = (d4){0.0, 0.0, 0.0, 0.0};
+                y2[rn] = (d4){0.0, 0.0, 0.0, 0.0};
             }
             const double* dblk = sD + (lower_block_base(cb) + cb) * 256 + l15;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double a = dblk[(4 * q + l4) * 16];
 #pragma unroll
-                for (int rn = 0; rn < NRW; ++rn) y[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt[rn][q], y[rn], 0, 0, 0);
+                for (int rn = 0; rn < NRW; ++rn) {
+                    if (QALT && (q & 1)) y2[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt[rn][q], y2[rn], 0, 0, 0);
+                    else y[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt[rn][q], y[rn], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = -y[rn];     // X itself from here on
+            for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = QALT ? -(y[rn] + y2[rn]) : -y[rn];     // X itself from here on
             __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later column blocks from piling up in registers
         }
     };
@@ -411,7 +456,11 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+#if DSMGP_TF_TAIL
+                const double z = sZ[16 * cb + l4 + 4 * q];
+#else
                 const double z = tk.zk[16 * cb + l4 + 4 * q];
+#endif
 #pragma unroll
                 for (int rn = 0; rn < NRW; ++rn) {
                     p[rn] = fma(acc[cb][rn][q], z, p[rn]);
@@ -429,11 +478,19 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
 #pragma unroll
             for (int rn = 0; rn < NRW; ++rn) {
                 const int row = 16 * NRW * w + 16 * rn + l15;
+#if DSMGP_TF_TAIL
+                if (tk.sq == nullptr) tk.wi[row] = wpre[rn] - p[rn];
+                else {
+                    tk.wi[row] = wpre[rn] + p[rn];
+                    tk.sq[row] = spre[rn] + q2[rn];
+                }
+#else
                 if (tk.sq == nullptr) tk.wi[row] -= p[rn];
                 else {
                     tk.wi[row] += p[rn];
                     tk.sq[row] += q2[rn];
                 }
+#endif
             }
         }
     }
@@ -441,7 +498,7 @@ __device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA
 
 __global__ __launch_bounds__(256, 2) void tile_fused_kernel(const FusedTask* __restrict__ tasks, const KParam* __restrict__ kp,
                                                             int D) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP];
+    __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP + (DSMGP_TF_TAIL ? TB : 0)];
     static_assert(2 * NRING * KC2 * LDP == 36 * 256, "the ring holds the 36 lower blocks of Dinv_k exactly");
     static_assert(GRAM_FUSE_MAX_D * TB <= NRING * KC2 * LDP, "coordinate image of a tile must fit half the ring");
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
@@ -463,6 +520,291 @@ __global__ __launch_bounds__(256, 2) void tile_fused_kernel(const FusedTask* __r
         if (half) tile_fused_body<1, 8>(tk, sA, sB, kp, D);
         else tile_fused_body<2, 8>(tk, sA, sB, kp, D);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused tile task, EIGHT waves (round 4, second half).  tile_fused_kernel runs two workgroups of four waves per CU -- two waves
+// per SIMD at 228-254 registers each -- and one wave cannot keep the f64 matrix pipe busy: it issues an MFMA about every 100
+// cycles where the pipe takes one every 64, and every phase change of a task (coordinates, kernel function, product, L_kk,
+// solve, store) leaves its SIMD to the one other wave.  At depth 4 the launches ran at 60 % of their matrix-pipe time.
+// Here a wave owns ONE 16-row block and all 128 columns (the 16-rows-per-wave form of tile_fused_body, acc[8][1]): 128 registers,
+// so two workgroups of eight waves share a CU -- FOUR waves per SIMD.  And because a wave stages, evaluates, solves and stores
+// its own 16 rows, the eight row blocks of a task need not come from one 128-row tile: a task is ANY eight 16-row blocks below
+// the same diagonal block -- the short last row tile of a leaf's factor and its routed test rows share tasks, nothing is padded
+// beyond 16 rows (executed / algorithmic rows of the depth-4 model 1.31 -> 1.08).  Same arithmetic per row as the
+// 16-rows-per-wave form: -k(row, col) first, the product accumulated on it chunk by chunk, block forward substitution against
+// L_kk with two accumulators, riders reduced inside the wave.
+struct RowBlock {
+    const double* A;      // the 16 rows of the row panel (F[16 r .., 0:K] or rows of Vt), ld lda; nullptr = no block: the wave only stages
+    double* C;            // where the solved 16 x 128 block goes, ld ldc
+    const double* gx;     // coordinates of the rows, ld glda
+    double* wi;           // rider target as in FusedTask (w_i of train rows / mu sums of test rows), nullptr = none
+    double* sq;           // test rows: sum of squares of the solved row
+    int lda, ldc, glda;
+    int nvalid;           // rows that hold data (1..16); the others are written as zeros
+    int pad[2];
+};
+static_assert(sizeof(RowBlock) == 64, "RowBlock is read with scalar loads: one cache line");
+struct FusedTask8 {
+    const double* B;      // column panel F[k, 0:K], ld ldb; L_kk sits behind it (column k1)
+    const double* Dinv;   // Dinv_k: its diagonal 16x16 blocks are read
+    const double* zk;     // z_k for the riders
+    const double* gxb;    // coordinates of the columns, ld gldb
+    int ldb, gldb, gnb, k1;
+    int kid, nblk;
+    int pad[2];
+    RowBlock rb[8];
+};
+static_assert(sizeof(FusedTask8) == 64 + 8 * 64, "FusedTask8 layout");
+
+template <int NCB>
+__device__ __forceinline__ void tile_fused8_body(const FusedTask8* __restrict__ task, double* smem, const KParam* __restrict__ kp, int D) {
+    static_assert(NCB == 8 || NCB == 4 || NCB == 2 || NCB == 1, "column-block classes");
+    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
+    double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem + NRING * KC2 * LDP);
+    double* sD = smem;                          // the 36 lower blocks of L_kk take the ring's place after the product
+    double* sZ = smem + 2 * NRING * KC2 * LDP;  // z_k
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);       // 0..7: the row block
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const RowBlock rb = task->rb[w];
+    const double* const tB = task->B;
+    const int ldb = task->ldb, K = task->k1, gnb = task->gnb;
+    const bool active = rb.A != nullptr;        // wave-uniform
+    // staging: a wave moves its own 16 rows of either panel, 8 lanes (2 rows each) per column of the chunk
+    const int scol = lane >> 3, srow = 2 * (lane & 7);
+    // (a wave without a block, and the B rows beyond the tile's valid columns, load all the same -- from the B panel, whose 128
+    // rows exist in memory: loads under a condition cost the loop its counted vmcnt waits)
+    const double* gB = tB + 16 * w + srow + (size_t)scol * ldb;
+    const double* gA = active ? rb.A + srow + (size_t)scol * rb.lda : gB;
+    const int lda = active ? rb.lda : ldb;
+    const int sOff = scol * LDP + 16 * w + srow;
+    const int nch = K / KC2;
+    const d2 zero2 = {0.0, 0.0};
+    d2 ra0 = zero2, rb0 = zero2, ra1 = zero2, rb1 = zero2;
+#define F8LOAD(RA, RB, CH)                                                                       \
+    do {                                                                                         \
+        const size_t ch_ = (size_t)(CH) * KC2;                                                   \
+        RA = *AS_GLOBAL_D2(gA + ch_ * lda);                                                      \
+        RB = *AS_GLOBAL_D2(gB + ch_ * ldb);                                                      \
+    } while (0)
+#define F8WRITE(RA, RB, BUF)                                                                     \
+    do {                                                                                         \
+        *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA;                                             \
+        *reinterpret_cast<d2*>(&sB[BUF][sOff]) = RB;                                             \
+    } while (0)
+    if (nch > 0) {      // the first two chunks: their latency passes under the kernel function
+        F8LOAD(ra0, rb0, 0);
+        F8LOAD(ra1, rb1, min(1, nch - 1));
+    }
+    d4 acc[NCB][1];
+    {   // acc = -k(row, col): coordinates through the (still unused) ring, every wave its own 16 rows and 16 columns
+        const KParam p = kp[task->kid];
+        double* sa = &sA[0][0];
+        double* sb = &sB[0][0];
+        const double* gxb = task->gxb;
+        const int gldb = task->gldb;
+        const int navalid = active ? rb.nvalid : 0;
+        for (int d0 = l4; d0 < D; d0 += 16) {       // four dimensions per lane and pass, loads first
+            double va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d = d0 + 4 * u;
+                va[u] = (d < D && l15 < navalid) ? rb.gx[l15 + (size_t)d * rb.glda] : 0.0;
+                vb[u] = (d < D && 16 * w + l15 < gnb) ? gxb[16 * w + l15 + (size_t)d * gldb] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d = d0 + 4 * u;
+                if (d < D) {
+                    sa[d * TB + 16 * w + l15] = va[u];
+                    sb[d * TB + 16 * w + l15] = vb[u];
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int gna = 16 * w + rb.nvalid;     // rowsplit_gram_init counts rows from the top of the 128-row image
+            if (p.kind == 0) rowsplit_gram_init<0, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
+            else if (p.kind == 1) rowsplit_gram_init<1, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
+            else rowsplit_gram_init<2, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
+        }
+        __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
+    }
+    // product: ring and barrier protocol of gemm_mainloop_rowsplit (chunk c is computed from buffer c & 3 while chunk c + 3 is
+    // written and chunk c + 4 is in flight), one barrier per chunk; with four waves per SIMD the hardware interleaves the
+    // waves' memory and matrix instructions, so the loop is written plainly
+    if (nch > 0) {
+        F8WRITE(ra0, rb0, 0);
+        F8LOAD(ra0, rb0, min(2, nch - 1));
+        F8WRITE(ra1, rb1, 1);
+        F8LOAD(ra1, rb1, min(3, nch - 1));
+        F8WRITE(ra0, rb0, 2);
+    }
+    __syncthreads();
+    const int rowoff = 16 * w + l15;
+#define F8COMPUTE(BUF)                                                                           \
+    do {                                                                                         \
+        if (active) {                                                                            \
+            _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                   \
+                const double* pa_ = &sB[BUF][(g_ * 4 + l4) * LDP + l15];                         \
+                const double fb_ = sA[BUF][(g_ * 4 + l4) * LDP + rowoff];                        \
+                double fa_[NCB];                                                                 \
+                _Pragma("unroll") for (int i_ = 0; i_ < NCB; ++i_) fa_[i_] = pa_[16 * i_];       \
+                _Pragma("unroll") for (int i_ = 0; i_ < NCB; ++i_)                               \
+                    acc[i_][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa_[i_], fb_, acc[i_][0], 0, 0, 0); \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+    {
+        int c = 0;
+        for (; c + 1 < nch; c += 2) {
+            F8LOAD(ra0, rb0, min(c + 4, nch - 1));
+            F8COMPUTE(c & (NRING - 1));
+            F8WRITE(ra1, rb1, (c + 3) & (NRING - 1));
+            __syncthreads();
+            F8LOAD(ra1, rb1, min(c + 5, nch - 1));
+            F8COMPUTE((c + 1) & (NRING - 1));
+            F8WRITE(ra0, rb0, (c + 4) & (NRING - 1));
+            __syncthreads();
+        }
+        if (c < nch) {
+            F8COMPUTE(c & (NRING - 1));
+            __syncthreads();
+        }
+    }
+#undef F8COMPUTE
+#undef F8WRITE
+#undef F8LOAD
+    // the ring is free: lower blocks of L_kk (off-diagonal ones from the factorised diagonal tile behind the B panel, the
+    // diagonal inverses from Dinv_k), block b at 256 b as in tile_fused_body; thread t moves the doubles 2 (t & 127), + 1 of
+    // block 4 e + (t >> 7) -- NCB = 8: blocks 0..19 now (all that block columns 0..4 need), 20..35 under their solve
+    constexpr int NBLK = lower_block_base(NCB);
+    constexpr int NE = (NBLK + 3) / 4, NE1 = (NCB == 8) ? 5 : NE;
+    const int dj = (t & 127) >> 3, di = 2 * (t & 7), dq = __builtin_amdgcn_readfirstlane(t >> 7);
+    const double* Lkk = tB + (size_t)K * (size_t)ldb;
+    const double* Dv = task->Dinv;
+    auto dinv_load = [&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        constexpr unsigned pk = lower_block_pack<4>(4 * e, NBLK);
+        const int sel = (int)(pk >> (8 * dq)) & 0xff;            // scalar: dq is wave-uniform
+        const int cb = sel & 15, jb = sel >> 4;
+        const double* src = (cb == jb) ? Dv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB
+                                       : Lkk + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * (size_t)ldb;
+        return *AS_GLOBAL_D2(src);
+    };
+    d2 dv[NE1];
+    static_for<NE1>([&](auto ec) { dv[decltype(ec)::value] = dinv_load(ec); });
+    d2 dw[4];
+    if constexpr (NCB == 8) {
+        static_for<4>([&](auto ec) { dw[decltype(ec)::value] = dinv_load(std::integral_constant<int, 5 + decltype(ec)::value>{}); });
+    }
+    const bool riders = active && rb.wi != nullptr;
+    double wpre = 0.0, spre = 0.0;
+    if (task->zk != nullptr && t < TB) sZ[t] = task->zk[t];
+    if (riders) {
+        wpre = rb.wi[l15];
+        if (rb.sq != nullptr) spre = rb.sq[l15];
+    }
+#pragma unroll
+    for (int e = 0; e < NE1; ++e)
+        if (4 * e + dq < NBLK) *reinterpret_cast<d2*>(sD + (size_t)(4 * e + dq) * 256 + 2 * (t & 127)) = dv[e];
+    __syncthreads();
+    auto solve_block_column = [&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        if constexpr (cb < NCB) {
+            if (active) {
+                d4 x0 = acc[cb][0], x1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int jb = 0; jb < cb; ++jb) {
+                    const double* blk = sD + (lower_block_base(cb) + jb) * 256 + l15;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double a = blk[(4 * q + l4) * 16];
+                        if (jb & 1) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][0][q], x1, 0, 0, 0);
+                        else x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][0][q], x0, 0, 0, 0);
+                    }
+                }
+                const d4 tt = (cb > 1) ? x0 + x1 : x0;
+                d4 y = (d4){0.0, 0.0, 0.0, 0.0};
+                const double* dblk = sD + (lower_block_base(cb) + cb) * 256 + l15;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(dblk[(4 * q + l4) * 16], tt[q], y, 0, 0, 0);
+                acc[cb][0] = -y;
+            }
+        }
+    };
+    solve_block_column(std::integral_constant<int, 0>{});
+    solve_block_column(std::integral_constant<int, 1>{});
+    solve_block_column(std::integral_constant<int, 2>{});
+    solve_block_column(std::integral_constant<int, 3>{});
+    solve_block_column(std::integral_constant<int, 4>{});
+    if (NCB == 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<d2*>(sD + (size_t)(4 * (5 + e) + dq) * 256 + 2 * (t & 127)) = dw[e];
+        __syncthreads();
+    }
+    solve_block_column(std::integral_constant<int, 5>{});
+    solve_block_column(std::integral_constant<int, 6>{});
+    solve_block_column(std::integral_constant<int, 7>{});
+    if (!active) return;
+    // store: register q of acc[cb][0] is X(row = l15, col = 16 cb + l4 + 4 q) of the wave's block; zeros beyond NCB
+    {
+        const unsigned lofs = (unsigned)l15 + (unsigned)l4 * (unsigned)rb.ldc;
+        const size_t ldc = (size_t)rb.ldc;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const gf64_ptr col = AS_GLOBAL_F64(rb.C + (size_t)(16 * cb + 4 * q) * ldc);
+                col[lofs] = (cb < NCB) ? acc[cb < NCB ? cb : 0][0][q] : 0.0;
+            }
+    }
+    if (riders) {       // reduced inside the wave in the order of tile_fused_body (same bits)
+        double p = 0.0, q2 = 0.0;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double z = sZ[16 * cb + l4 + 4 * q];
+                p = fma(acc[cb][0][q], z, p);
+                q2 = fma(acc[cb][0][q], acc[cb][0][q], q2);
+            }
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        q2 += __shfl_xor(q2, 16);
+        q2 += __shfl_xor(q2, 32);
+        if (l4 == 0) {
+            if (rb.sq == nullptr) rb.wi[l15] = wpre - p;
+            else {
+                rb.wi[l15] = wpre + p;
+                rb.sq[l15] = spre + q2;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void tile_fused8_kernel(const FusedTask8* __restrict__ tasks, const KParam* __restrict__ kp, int D) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP + TB];
+    const FusedTask8* task = tasks + blockIdx.x;
+    const int ncb = (task->gnb + 15) >> 4;      // valid columns: fewer than 128 only in the last block column of a leaf
+    if (ncb <= 1) tile_fused8_body<1>(task, smem, kp, D);
+    else if (ncb <= 2) tile_fused8_body<2>(task, smem, kp, D);
+    else if (ncb <= 4) tile_fused8_body<4>(task, smem, kp, D);
+    else tile_fused8_body<8>(task, smem, kp, D);
+}
+
+// Rows [r0, 128) of a block row of a factor over `ncols` columns <- 0 (build_plan: the padding rows below a leaf's last data rows)
+struct ZeroRowsTask {
+    double* p;
+    int ld, r0, ncols;
+};
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(const ZeroRowsTask* __restrict__ tasks) {
+    const ZeroRowsTask tk = tasks[blockIdx.x];
+    const int r = threadIdx.x & (TB - 1);
+    if (r < tk.r0) return;
+    for (int col = threadIdx.x >> 7; col < tk.ncols; col += 2) tk.p[r + (size_t)col * tk.ld] = 0.0;
 }
 
 // Gram values of a wave's 9 lower blocks of the diagonal tile, S = k - product in place (syrk_gram_epilogue without the
@@ -590,14 +932,6 @@ __host__ __device__ constexpr int diagr_cb(int w, int i) {
 static_assert(diagr_rb(3, 4) == 4 && diagr_cb(3, 4) == 3 && diagr_rb(3, 8) == 7 && diagr_cb(3, 8) == 7 && diagr_rb(0, 5) == 6 &&
                   diagr_cb(0, 5) == 2 && diagr_rb(1, 4) == 6 && diagr_cb(1, 4) == 4 && diagr_rb(2, 8) == 4 && diagr_cb(2, 8) == 2,
               "accumulator -> block map of syrk_mainloop");
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
 
 template <int W>
 __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], double* S) {
