@@ -438,7 +438,7 @@ def main():
     assert args.simulate_shard or (np.all(np.isfinite(mu)) and np.all(var > 0))
 
     # roofline of the dominant kernel on this rank: the f64-MFMA update launches (tile_gemm_kernel_v2) -- or, where the fused
-    # block steps dominate (many small leaves), the fused tile launches (tile_fused_kernel: update + solve)
+    # block steps dominate (many small leaves), the fused tile launches (tile_fused8_kernel: update + solve)
     alg_flops, _ = ctx.work()
     alg_fused, _ = ctx.work_fused()
     roof = None
@@ -446,14 +446,14 @@ def main():
     if not args.no_profile and max(cats.get("chol_update", 0.0), cats.get("chol_fused", 0.0)) > 0:
         if fused_dominant:
             t_cat, n_l, fl_step = cats["chol_fused"], fused_launches, alg_fused
-            kname = ("tile_fused_kernel (fused block steps: update of a tile from the kernel function, solve against the step's "
+            kname = ("tile_fused8_kernel (fused block steps: update of a tile from the kernel function, solve against the step's "
                      "diagonal block from the accumulators, one write; algorithmic flops = update + c_k^2 per solved row)")
         else:
             t_cat, n_l, fl_step = cats["chol_update"], upd_launches, alg_flops
             kname = ("tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along, each task "
                      "evaluating the kernel function of its own tile; <false, 0, true> in launches with >= 10 % short tiles; "
                      "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel, the shallow block steps "
-                     "(K <= 512) as diag_fused_reg_kernel + tile_fused_kernel: all timed apart, device_seconds_per_step; the diagonal blocks of the other steps ride in these launches as DiagFinishTasks)")
+                     "(K <= 512) as diag_fused_reg_kernel + tile_fused8_kernel: all timed apart, device_seconds_per_step; the diagonal blocks of the other steps ride in these launches as DiagFinishTasks)")
         avg_launch = t_cat / max(1, n_l)
         flops_per_launch = fl_step * args.steps / max(1, n_l)
         achieved = flops_per_launch / avg_launch / 1e12

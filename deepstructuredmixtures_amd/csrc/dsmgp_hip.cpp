@@ -69,9 +69,6 @@ enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 #ifndef DSMGP_FUSED_SHALLOW
 #define DSMGP_FUSED_SHALLOW 4
 #endif
-#ifndef DSMGP_FUSED8
-#define DSMGP_FUSED8 1                     // fused tile tasks in the eight-wave form (tile_fused8_kernel): 16-row blocks packed eight to a task
-#endif
 constexpr int FUSED_SHALLOW_STEPS = DSMGP_FUSED_SHALLOW;   // block steps 0..4 (K <= 512) run fused where at least ...
 constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leaves take part in the step
 #ifndef DSMGP_SOLO_FACTOR
@@ -90,13 +87,11 @@ struct StepLists {
     DevBuf<TileTask> upd, trsm;
     DevBuf<ReduceTask> red;
     DevBuf<DiagTask> diag;
-    // steps with more diagonal blocks than CUs run fused (kernels_fused.hpp): diag_fused_reg_kernel, then tile_fused_kernel
-    std::vector<int> fdiag_off, ftile_off;                   // size nsteps+1; a fused step has no classic tasks and vice versa
+    // steps with more diagonal blocks than CUs run fused (kernels_fused.hpp): diag_fused_reg_kernel, then tile_fused8_kernel
+    std::vector<int> fdiag_off, ftile8_off;                  // size nsteps+1; a fused step has no classic tasks and vice versa
     std::vector<char> mode;                                  // STEP_* per step
     DevBuf<DiagFusedTask> fdiag;
-    DevBuf<FusedTask> ftile;
-    std::vector<int> ftile8_off;                             // eight-wave form of the fused tile tasks (DSMGP_FUSED8)
-    DevBuf<FusedTask8> ftile8;
+    DevBuf<FusedTask8> ftile8;                               // eight 16-row blocks below a diagonal block each
     // classic steps with the diagonal block INSIDE the update launch (DiagFinishTask, kernels_fused.hpp): the update launch of
     // step k carries dfin[dfin_off[k] .. dfin_off[k+1]) behind its first dpos[k] tile tasks; a leaf whose diagonal block rides
     // there has no `diag` task in that step
@@ -377,7 +372,7 @@ struct dsmgp_ctx {
                                     // the update launch (DiagFinishTask, kernels_fused.hpp)
     // per phase and block step (decided by build_plan):
     //   STEP_CLASSIC    update (all tiles, split-K) / reduce / diagonal block / panel solve launches, one after the other
-    //   STEP_FUSED      many leaves: diag_fused_reg_kernel, then tile_fused_kernel, from the kernel function (kernels_fused.hpp)
+    //   STEP_FUSED      many leaves: diag_fused_reg_kernel, then tile_fused8_kernel, from the kernel function (kernels_fused.hpp)
     // (A third, lookahead schedule -- the update of step k cut at its last block column, the bulk on this stream, the rank-128
     // finish + diagonal block + solve on a second, high-priority stream beside the bulk of step k + 1 -- was built in round 3
     // and measured in every regime it was meant for: headline 0.4037 / 0.4055 s against 0.3906 / 0.3992, config 2 3.51 against
@@ -617,7 +612,6 @@ void free_plan(dsmgp_ctx* c) {
         dev_free(ph.red.p);
         dev_free(ph.diag.p);
         dev_free(ph.fdiag.p);
-        dev_free(ph.ftile.p);
         dev_free(ph.ftile8.p);
         dev_free(ph.dfin.p);
         dev_free(ph.dinvc.p);
@@ -669,7 +663,6 @@ void free_test(dsmgp_ctx* c) {
         dev_free(ph.red.p);
         dev_free(ph.diag.p);
         dev_free(ph.fdiag.p);
-        dev_free(ph.ftile.p);
         dev_free(ph.ftile8.p);
         dev_free(ph.dfin.p);
         dev_free(ph.dinvc.p);
@@ -816,7 +809,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.nsteps = nsteps;
         std::vector<TileTask> trsm;
         std::vector<DiagTask> diag;
-        std::vector<FusedTask> ftile;
         std::vector<FusedTask8> ftile8;
         std::vector<RowBlock> blocks8;      // 16-row blocks of one leaf below the step's diagonal block: factor rows, then test rows
         std::vector<DiagFusedTask> fdiag;
@@ -829,7 +821,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.trsm_off.assign(nsteps + 1, 0);
         S.diag_off.assign(nsteps + 1, 0);
         S.fdiag_off.assign(nsteps + 1, 0);
-        S.ftile_off.assign(nsteps + 1, 0);
         S.ftile8_off.assign(nsteps + 1, 0);
         S.step_tiles.assign(nsteps, 0);
         S.pad.assign(nsteps, 0);
@@ -840,7 +831,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
             S.trsm_off[k] = (int)trsm.size();
             S.diag_off[k] = (int)diag.size();
             S.fdiag_off[k] = (int)fdiag.size();
-            S.ftile_off[k] = (int)ftile.size();
             S.ftile8_off[k] = (int)ftile8.size();
             S.dfin_off[k] = (int)dfin.size();
             const int mode = k < (int)c->fused_step[ph].size() ? c->fused_step[ph][k] : STEP_CLASSIC;
@@ -867,43 +857,21 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                     const bool own_diag = (k >= lf.kb);
                     const bool fin = finish_here && own_diag;    // tile (k,k) got all but its last block column one step ago
                     for (int i = i_first; i < lf.nb; ++i) {
-                        if (fstep) {      // fused step: the diagonal tile belongs to the diagonal-block task, the tiles below
-                                          // are updated and solved in one task each
+                        if (fstep) {      // fused step: the diagonal tile belongs to the diagonal-block task; of the tiles below
+                                          // the 16-row blocks that hold data are updated and solved, eight to a task (the rows
+                                          // beyond stay zero: zero_pad_rows_kernel)
                             if (i == k) continue;
-                            if (DSMGP_FUSED8) {       // the tile's 16-row blocks that hold data; the rows beyond stay zero (zero_pad_rows)
-                                const int rows = std::max(0, std::min(TB, lf.n - i * TB));
-                                for (int r = 0; r < rows; r += 16) {
-                                    RowBlock b{};
-                                    b.A = d.F + (size_t)i * TB + r;
-                                    b.C = d.F + (size_t)i * TB + r + (size_t)k * TB * ld;
-                                    b.gx = d.Xg + (size_t)i * TB + r;
-                                    b.lda = b.ldc = b.glda = ld;
-                                    b.nvalid = std::min(16, rows - r);
-                                    if (ph != 1) b.wi = d.w + (size_t)i * TB + r;
-                                    blocks8.push_back(b);
-                                }
-                                continue;
+                            const int rows = std::max(0, std::min(TB, lf.n - i * TB));
+                            for (int r = 0; r < rows; r += 16) {
+                                RowBlock b{};
+                                b.A = d.F + (size_t)i * TB + r;
+                                b.C = d.F + (size_t)i * TB + r + (size_t)k * TB * ld;
+                                b.gx = d.Xg + (size_t)i * TB + r;
+                                b.lda = b.ldc = b.glda = ld;
+                                b.nvalid = std::min(16, rows - r);
+                                if (ph != 1) b.wi = d.w + (size_t)i * TB + r;     // fused forward substitution
+                                blocks8.push_back(b);
                             }
-                            FusedTask f{};
-                            f.A = d.F + (size_t)i * TB;
-                            f.B = d.F + (size_t)k * TB;
-                            f.C = d.F + (size_t)i * TB + (size_t)k * TB * ld;
-                            f.Dinv = d.Dinv + (size_t)k * TB * TB;
-                            f.lda = f.ldb = f.ldc = ld;
-                            f.k1 = k * TB;
-                            f.gxa = d.Xg + (size_t)i * TB;
-                            f.gxb = d.Xg + (size_t)k * TB;
-                            f.glda = f.gldb = ld;
-                            f.gna = std::max(0, std::min(TB, lf.n - i * TB));
-                            f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
-                            f.kid = lf.kid;
-                            f.mrows = tile_mrows(lf.n - i * TB);
-                            f.zpad = 1;
-                            if (ph != 1) {
-                                f.zk = d.z + (size_t)k * TB;
-                                f.wi = d.w + (size_t)i * TB;
-                            }
-                            ftile.push_back(f);
                             continue;
                         }
                         if (k > 0 && !(i == k && fin)) {
@@ -1004,7 +972,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 if (with_test && lf.nt > 0) {
                     for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
                         double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
-                        if (fstep && DSMGP_FUSED8) {
+                        if (fstep) {
                             const int rows = std::max(0, std::min(TB, lf.nt - ti * TB));
                             for (int r = 0; r < rows; r += 16) {
                                 RowBlock b{};
@@ -1019,32 +987,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                                 }
                                 blocks8.push_back(b);
                             }
-                            continue;
-                        }
-                        if (fstep) {
-                            FusedTask f{};
-                            f.A = d.Vt + (size_t)ti * TB;
-                            f.B = d.F + (size_t)k * TB;
-                            f.C = tile;
-                            f.Dinv = d.Dinv + (size_t)k * TB * TB;
-                            f.lda = lf.ntpad;
-                            f.ldb = ld;
-                            f.ldc = lf.ntpad;
-                            f.k1 = k * TB;
-                            f.gxa = d.Xtg + (size_t)ti * TB;
-                            f.gxb = d.Xg + (size_t)k * TB;
-                            f.glda = lf.ntpad;
-                            f.gldb = ld;
-                            f.gna = std::max(0, std::min(TB, lf.nt - ti * TB));
-                            f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
-                            f.kid = lf.kid;
-                            f.mrows = tile_mrows(lf.nt - ti * TB);
-                            if (d.zfused) {
-                                f.zk = d.z + (size_t)k * TB;
-                                f.wi = d.macc + (size_t)ti * TB;
-                                f.sq = d.sacc + (size_t)ti * TB;
-                            }
-                            ftile.push_back(f);
                             continue;
                         }
                         if (k > 0) {
@@ -1148,9 +1090,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                 // model's panel-solve launches fetched 2.6x their tile bytes)
                 std::vector<int> unused(trsm.size());
                 xcd_permute(trsm, unused, (size_t)S.trsm_off[k], trsm.size(), c->xcd_order);
-                std::vector<int> unused2(ftile.size());      // fused tiles of a leaf share its B panel and Dinv_k
-                xcd_permute(ftile, unused2, (size_t)S.ftile_off[k], ftile.size(), c->xcd_order);
-                std::vector<int> unused3(ftile8.size());
+                std::vector<int> unused3(ftile8.size());     // the fused tile tasks of a leaf share its B panel and L_kk
                 xcd_permute(ftile8, unused3, (size_t)S.ftile8_off[k], ftile8.size(), c->xcd_order);
             }
         }
@@ -1159,7 +1099,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.trsm_off[nsteps] = (int)trsm.size();
         S.diag_off[nsteps] = (int)diag.size();
         S.fdiag_off[nsteps] = (int)fdiag.size();
-        S.ftile_off[nsteps] = (int)ftile.size();
         S.ftile8_off[nsteps] = (int)ftile8.size();
         S.dfin_off[nsteps] = (int)dfin.size();
         if (int rc = dev_upload(c, S.dfin, dfin)) return rc;
@@ -1167,7 +1106,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
         if (int rc = dev_upload(c, S.fdiag, fdiag)) return rc;
-        if (int rc = dev_upload(c, S.ftile, ftile)) return rc;
         if (int rc = dev_upload(c, S.ftile8, ftile8)) return rc;
     }
     {
@@ -1184,7 +1122,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         }
     }
     // algorithmic flops of the launches timed as "update" (slot 1: tile_gemm_kernel_v2): 2 K per element of block column k with
-    // K = 128 k, nothing where it runs fused.  Fused tile launches (slot 18: tile_fused_kernel) are counted apart: their update flops
+    // K = 128 k, nothing where it runs fused.  Fused tile launches (slot 18: tile_fused8_kernel) are counted apart: their update flops
     // plus the triangular solve of the tiles below the diagonal block (c_k^2 per row, c_k = columns of block k).
     alg_flops_fused = 0.0;
     for (int l = 0; l < L; ++l) {
@@ -1312,7 +1250,7 @@ int build_plan(dsmgp_ctx* c) {
     // in a leaf's last row tile -- padding, which the classic steps and every sweep over the factor expect to be zero -- are
     // zeroed here, once per plan (nothing writes anything else there afterwards)
     DevBuf<ZeroRowsTask> zrows;
-    if (DSMGP_FUSED8 && gram_fused(c)) {
+    if (gram_fused(c)) {
         std::vector<ZeroRowsTask> zr;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
@@ -1603,25 +1541,17 @@ struct PhaseTimer {
 };
 
 // One factorisation phase on the context's stream.  Classic step: update (-> split-K reduce) -> diagonal block -> panel solve.
-// Fused step (many leaves, or shallow): diag_fused_reg_kernel -> tile_fused_kernel.
+// Fused step (many leaves, or shallow): diag_fused_reg_kernel -> tile_fused8_kernel.
 int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
     for (int k = 0; k < S.nsteps; ++k) {
-        const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft = S.ftile_off[k + 1] - S.ftile_off[k];
-        const int nft8 = S.ftile8_off[k + 1] - S.ftile8_off[k];
+        const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft8 = S.ftile8_off[k + 1] - S.ftile8_off[k];
         const int nu = S.upd_off[k + 1] - S.upd_off[k];
-        if (nfd > 0 || nft > 0 || nft8 > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
+        if (nfd > 0 || nft8 > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
             if (nfd > 0) {
                 pt.begin(2);
                 diag_fused_reg_kernel<<<nfd, 256, DIAGR_LDS_BYTES, c->stream>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
                 pt.note(k, nfd, 0);
                 pt.end();
-            }
-            if (nft > 0) {
-                pt.begin(18);
-                tile_fused_kernel<<<nft, 256, 0, c->stream>>>(S.ftile.p + S.ftile_off[k], c->d_kp, c->D);
-                pt.note(k, nft, nft);
-                pt.end();
-                if (count_launches) c->n_fused_launches++;
             }
             if (nft8 > 0) {
                 pt.begin(18);

@@ -9,19 +9,18 @@
 // chip by themselves, so the step is reordered (src/AdvancedCholeskey.jl:161-171 does the same per leaf: the diagonal
 // block first, then the panel below it):
 //     diag_fused_reg_kernel  per leaf: S = K(k,k) - F[k,0:K] F[k,0:K]^T (lower blocks; they STAY in the accumulators: round 4),
-//                         L_kk = chol(S), z_k, Dinv_k               -- the tile never exists unfactorised in memory
-//     tile_fused_kernel   per tile below: C = K(i,k) - F[i,0:K] F[k,0:K]^T stays in the accumulators, which ARE the
-//                         second operand of the solve (register r of a 16x16 result = k-slab r of the operand);
-//                         X L_kk^T = C by block forward substitution against L_kk's blocks staged once in LDS (round 4;
-//                         a product with Dinv_k before); the tile is written once
+//                         L_kk = chol(S), z_k, the 16x16 diagonal inverses  -- the tile never exists unfactorised in memory
+//     tile_fused8_kernel  per eight 16-row blocks below: C = K(i,k) - F[i,0:K] F[k,0:K]^T stays in the accumulators, which ARE
+//                         the second operand of the solve (register r of a 16x16 result = k-slab r of the operand);
+//                         X L_kk^T = C by block forward substitution against L_kk's blocks staged once in LDS; every block
+//                         is written once
 // Two launches per step, no Gram launch for block column 0 (K = 0: the tasks start at the kernel function), and at depth 4
 // about 60 GB of the 210 GB a fit moves are not moved.  The arithmetic is that of the classic step -- the products sum over
 // K chunk by chunk, the Gram values come from gram_accumulate / gram_finish, the solve sums over j in groups of four
-// ascending, the riders reduce inside a wave as in tile_trsm_kernel -- with one difference in ORDER: a tile below the
-// diagonal starts from -K(i,k) and accumulates the product on it (the kernel function is evaluated first, while the
-// accumulators are not yet live and the first operand loads are in flight) where the classic update subtracts the
-// finished product from K(i,k).  Diagonal blocks are bit-identical to the classic step's, tiles below agree to rounding
-// (test_fused_steps_agree_with_the_classic_steps).
+// ascending, the riders reduce inside a wave as in tile_trsm_kernel -- with one difference in ORDER: a block below the
+// diagonal starts from -K(i,k) and accumulates the product on it (the kernel function is evaluated first, while the first
+// operand loads are in flight) where the classic update subtracts the finished product from K(i,k).  Diagonal blocks are
+// bit-identical to the classic step's, the blocks below agree to rounding (test_fused_steps_agree_with_the_classic_steps).
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -29,15 +28,6 @@
 
 namespace dsmgp {
 
-#ifndef DSMGP_SOLVE_DUAL
-#define DSMGP_SOLVE_DUAL 1
-#endif
-#ifndef DSMGP_TF_TAIL
-#define DSMGP_TF_TAIL 1                   // fused tile task: z_k staged in LDS with L_kk, w_i / sums of the riders fetched before the solve
-#endif
-#ifndef DSMGP_TF_QALT
-#define DSMGP_TF_QALT 0                   // 16-rows-per-wave form: the solve's two accumulators alternate per k-slab, not per block
-#endif
 #ifndef DSMGP_DIAGR_WGS
 #define DSMGP_DIAGR_WGS 3                 // workgroups per CU the register-resident diagonal-block task is compiled for
 #endif
@@ -51,25 +41,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
-struct FusedTask {
-    const double* A;      // row panel F[i, 0:K] (or the rows of K_tn L^-T so far), ld lda
-    const double* B;      // column panel F[k, 0:K], ld ldb
-    double* C;            // the tile, written once: (K(i,k) - A B^T) Dinv_k^T
-    const double* Dinv;   // Dinv_k (ld 128) from the diagonal-block task of the same step: its diagonal 16x16 blocks are what is read
-    const double* zk;     // riders, as in TileTask: z_k (128) ...
-    double* wi;           // ... train rows: w_i -= X z_k; test rows (sq set): mu += X z_k.  NULL = none
-    double* sq;           // test rows: sum of squares of the solved row
-    const double* gxa;    // coordinates of the tile's rows, column-major [glda x D], offset to the first row
-    const double* gxb;    // ... of its columns
-    int lda, ldb, ldc, k1;        // K range [0, k1)
-    int glda, gldb, gna, gnb;     // valid rows / columns (<= 128)
-    int kid;
-    int mrows;            // rows that hold data, rounded up to 16; 0 = all 128.  <= 64: a wave takes 16 rows instead of 32
-    int zpad;             // tile of the factor: its padding rows are written here too (zeros)
-    int pad[3];
-};
-static_assert(sizeof(FusedTask) == 128, "FusedTask is read with scalar loads: keep it two cache lines");
-
 struct DiagFusedTask {
     DiagTask d;           // the diagonal block: T (the tile of F), Dinv, wk / zk, info, ld, nvalid, row0
     const double* A;      // F[k, 0:K]: the block row left of the tile, ld = d.ld
@@ -78,148 +49,8 @@ struct DiagFusedTask {
     int pad;
 };
 
-// Row-split tile product: wave w owns the rows RW w .. RW w + RW - 1 (RW = 16 NRW: 32 for a whole tile, 16 for a tile of
-// at most 64 data rows) and ALL 128 columns, acc[8][NRW] -- whole rows of the tile in one wave are what the solve that
-// follows needs.  Ring, prefetch and barrier protocol of gemm_mainloop_v2; rows 64.. of the A panel are not staged for
-// NRW = 1.
-// The first two chunks of the operand panels, loaded by rowsplit_prefetch BEFORE the task's kernel-function phase so that
-// their memory latency passes under its arithmetic; gemm_mainloop_rowsplit starts from them.
-struct RowsplitPrefetch {
-    d2 ra0[2], rb0[2], ra1[2], rb1[2];
-};
-template <int NRW, int NCB = 8>
-__device__ __forceinline__ void rowsplit_prefetch(const double* A, int lda, const double* B, int ldb, int K, RowsplitPrefetch& pf) {
-    const int t = threadIdx.x;
-    const int nch = K / KC2;
-    if (nch <= 0) return;
-    const int scol = t >> 5, srow = 2 * (t & 31);
-    const double* gA = A + srow + (size_t)scol * lda;
-    const double* gB = B + srow + (size_t)scol * ldb;
-    const size_t o1a = (size_t)min(1, nch - 1) * KC2 * lda, o1b = (size_t)min(1, nch - 1) * KC2 * ldb;
-    pf.ra0[0] = *AS_GLOBAL_D2(gA);
-    if (NRW > 1) pf.ra0[1] = *AS_GLOBAL_D2(gA + 64);
-    pf.rb0[0] = *AS_GLOBAL_D2(gB);
-    if (NCB > 4) pf.rb0[1] = *AS_GLOBAL_D2(gB + 64);
-    pf.ra1[0] = *AS_GLOBAL_D2(gA + o1a);
-    if (NRW > 1) pf.ra1[1] = *AS_GLOBAL_D2(gA + o1a + 64);
-    pf.rb1[0] = *AS_GLOBAL_D2(gB + o1b);
-    if (NCB > 4) pf.rb1[1] = *AS_GLOBAL_D2(gB + o1b + 64);
-}
-
-template <int NRW, int NCB = 8>
-__device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda, const double* B, int ldb, int K,
-                                                       d4 (&acc)[NCB][NRW], double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
-                                                       const RowsplitPrefetch& pf) {
-    // acc comes in initialised by the caller (-K(i,k): rowsplit_gram_init) and goes out as acc + A B^T
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l15 = lane & 15, l4 = lane >> 4;
-    constexpr bool AHI = NRW > 1;       // rows 64.. of the A panel are staged
-    constexpr bool BHI = NCB > 4;       // rows 64.. of the B panel (= columns 64.. of the tile) are staged
-    constexpr int NMEM_G = (AHI ? 2 : 1) + (BHI ? 2 : 1);
-    constexpr int NFRAG = (NCB + NRW + 1) / 2;
-    constexpr int NMFMA = NCB * NRW;
-    constexpr int NI_A = NMEM_G < NMFMA ? NMEM_G : NMFMA;
-    constexpr int NI_B = (NMFMA - NI_A) < NFRAG ? (NMFMA - NI_A) : NFRAG;
-    constexpr int NI_REST = NMFMA - NI_A - NI_B;
-    const int scol = t >> 5, srow = 2 * (t & 31);
-    const double* gA = A + srow + (size_t)scol * lda;
-    const double* gB = B + srow + (size_t)scol * ldb;
-    const int sOff = scol * LDP + srow;
-    const int rowoff = 16 * NRW * w + l15;
-    d2 ra0[2], rb0[2], ra1[2], rb1[2];
-#pragma unroll
-    for (int i_ = 0; i_ < 2; ++i_) {
-        ra0[i_] = pf.ra0[i_];
-        rb0[i_] = pf.rb0[i_];
-        ra1[i_] = pf.ra1[i_];
-        rb1[i_] = pf.rb1[i_];
-    }
-#define FGLOAD(RA, RB, CH)                                                                       \
-    do {                                                                                         \
-        const size_t oa_ = (size_t)(CH) * KC2 * lda, ob_ = (size_t)(CH) * KC2 * ldb;             \
-        RA[0] = *AS_GLOBAL_D2(gA + oa_);                                                         \
-        if (AHI) RA[1] = *AS_GLOBAL_D2(gA + oa_ + 64);                                           \
-        RB[0] = *AS_GLOBAL_D2(gB + ob_);                                                         \
-        if (BHI) RB[1] = *AS_GLOBAL_D2(gB + ob_ + 64);                                           \
-    } while (0)
-#define FSWRITE(RA, RB, BUF)                                                                     \
-    do {                                                                                         \
-        *reinterpret_cast<d2*>(&sA[BUF][sOff]) = RA[0];                                          \
-        if (AHI) *reinterpret_cast<d2*>(&sA[BUF][sOff + 64]) = RA[1];                            \
-        *reinterpret_cast<d2*>(&sB[BUF][sOff]) = RB[0];                                          \
-        if (BHI) *reinterpret_cast<d2*>(&sB[BUF][sOff + 64]) = RB[1];                            \
-    } while (0)
-#define FFRAGS(FA, FB, BUF, G)                                                                   \
-    do {                                                                                         \
-        const double* pa_ = &sB[BUF][((G) * 4 + l4) * LDP + l15];                                \
-        const double* pb_ = &sA[BUF][((G) * 4 + l4) * LDP + rowoff];                             \
-        _Pragma("unroll") for (int i_ = 0; i_ < NCB; ++i_) FA[i_] = pa_[16 * i_];                \
-        _Pragma("unroll") for (int i_ = 0; i_ < NRW; ++i_) FB[i_] = pb_[16 * i_];                \
-    } while (0)
-#define FMFMA(FA, FB)                                                                            \
-    do {                                                                                         \
-        _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_)                                    \
-            _Pragma("unroll") for (int rn_ = 0; rn_ < NRW; ++rn_)                                \
-                acc[cb_][rn_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[cb_], FB[rn_], acc[cb_][rn_], 0, 0, 0); \
-    } while (0)
-#define FINTERLEAVE(MASK_A)                                                                      \
-    do {                                                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < NI_A; ++i_) {                                    \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
-            __builtin_amdgcn_sched_group_barrier(MASK_A, 1, 0);                                  \
-        }                                                                                        \
-        _Pragma("unroll") for (int i_ = 0; i_ < NI_B; ++i_) {                                    \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
-        }                                                                                        \
-        if constexpr (NI_REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, NI_REST, 0);      \
-    } while (0)
-    const int nch = K / KC2;
-    if (nch > 0) {      // chunks 0 and 1 arrive in `pf`
-        FSWRITE(ra0, rb0, 0);
-        FGLOAD(ra0, rb0, min(2, nch - 1));
-        FSWRITE(ra1, rb1, 1);
-        FGLOAD(ra1, rb1, min(3, nch - 1));
-        FSWRITE(ra0, rb0, 2);
-    }
-    __syncthreads();
-    double fa0[NCB], fb0[NRW], fa1[NCB], fb1[NRW];
-    if (nch > 0) FFRAGS(fa0, fb0, 0, 0);
-#define FCHUNK(C, LRA, LRB, WRA, WRB)                                                            \
-    do {                                                                                         \
-        const int c_ = (C);                                                                      \
-        const int buf_ = c_ & (NRING - 1);                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        FGLOAD(LRA, LRB, min(c_ + 4, nch - 1));                                                  \
-        FFRAGS(fa1, fb1, buf_, 1);                                                               \
-        FMFMA(fa0, fb0);                                                                         \
-        FINTERLEAVE(0x020);                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        FSWRITE(WRA, WRB, (c_ + 3) & (NRING - 1));                                               \
-        FFRAGS(fa0, fb0, (c_ + 1) & (NRING - 1), 0);                                             \
-        FMFMA(fa1, fb1);                                                                         \
-        FINTERLEAVE(0x200);                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        __syncthreads();                                                                         \
-    } while (0)
-    int c = 0;
-    for (; c + 1 < nch; c += 2) {
-        FCHUNK(c, ra0, rb0, ra1, rb1);
-        FCHUNK(c + 1, ra1, rb1, ra0, rb0);
-    }
-    if (c < nch) FCHUNK(c, ra0, rb0, ra1, rb1);
-#undef FCHUNK
-#undef FINTERLEAVE
-#undef FMFMA
-#undef FFRAGS
-#undef FSWRITE
-#undef FGLOAD
-}
-
 // The solve of a fused tile task (round 4): block forward substitution against L_kk instead of a product with Dinv_k, so that
-// the diagonal-block task of a fused step can leave its whole inverse phase out (40 % of its MFMAs):
+// the diagonal-block task of a fused step can leave its whole inverse phase out:
 //     X(:, cb) = ( C(:, cb) - sum_{jb < cb} X(:, jb) L(cb, jb)^T ) L(cb, cb)^-T ,      cb = 0 .. 7
 // with the 28 blocks L(cb, jb), jb < cb, of the factorised diagonal tile and the eight 16x16 inverses L(cb, cb)^-1 that phase
 // 1 of the diagonal-block kernel leaves on the diagonal of Dinv_k: the same 36 block products (144 MFMAs per 16 rows) as the
@@ -227,7 +58,7 @@ __device__ __forceinline__ void gemm_mainloop_rowsplit(const double* A, int lda,
 // one down -- block (cb, jb), jb <= cb, at 256 (lower_block_base(cb) + jb) -- each column-major with leading dimension 16: the
 // MFMA operand read (16 rows per k column, four k columns per lane group) touches 64 consecutive doubles, conflict-free.
 // 36 x 256 doubles = the ring's 73,728 bytes exactly.  The substitution runs from the first block column to the last, so the
-// first half of this order (18 blocks: block rows 0..4 and three blocks of row 5) is all it needs to start.
+// first blocks of this order are all it needs to start.
 __host__ __device__ constexpr int lower_block_base(int cb) { return cb * (cb + 1) / 2; }   // sum_{c < cb} (c + 1)
 struct LowerBlocks {
     unsigned char cb[36], jb[36];
@@ -241,7 +72,6 @@ struct LowerBlocks {
             }
     }
 };
-__constant__ const LowerBlocks LOWER_BLOCKS{};
 // (cb, jb) of lower block b for the staging loads of L_kk.  The block index of a load is <compile-time part> + <wave-uniform
 // part>; looked up in the table in memory, every one of a thread's loads waited for its own two table bytes first -- 18
 // dependent round trips where one would do (found in the ISA in round 4: global_load_ubyte / s_waitcnt vmcnt(1) chains).
@@ -258,8 +88,8 @@ __host__ __device__ constexpr unsigned lower_block_pack(int b0, int nblk) {
 }
 static_assert(lower_block_base(0) == 0 && lower_block_base(5) == 15 && lower_block_base(7) == 28, "block order");
 
-// acc <- -k(row, col) in the accumulator layout of gemm_mainloop_rowsplit (register q of acc[cb][rn] is the entry
-// (row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q)); the operations of gram_half_tile in its order (gram_accumulate /
+// acc <- -k(row, col) in the accumulator layout of the fused tile task (wave w owns the rows 16 NRW w ..; register q of
+// acc[cb][rn] is the entry (row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q)); the operations of gram_half_tile in its order (gram_accumulate /
 // gram_finish): the values the Gram launch would have written, negated.  The product is then accumulated ON it, so the
 // task starts with the kernel function -- under the memory latency of its first operand loads, with the accumulators not
 // yet live -- and the accumulators end as -(K - A B^T) = -C.
@@ -300,245 +130,25 @@ __device__ __forceinline__ void rowsplit_gram_init(int gna, int gnb, const KPara
     }
 }
 
-// NCB = number of 16-column blocks of the tile that hold data (8, or 4 / 2 / 1 for a tile in the LAST block column of a leaf with
-// at most 64 / 32 / 16 valid columns: the test-row tile of every leaf's last block step, and 43 % of the matrix work of a PoE of
-// 391-row experts).  Columns beyond are padding -- K is zero there, the padding rows of the B panel are zero, Dinv_k is the
-// identity there -- so X is exactly zero in them: they are neither accumulated, nor evaluated, nor solved, only stored as zeros;
-// rows 64.. of the B panel are not staged and only the block rows of Dinv_k below NCB are fetched.
-template <int NRW, int NCB>
-__device__ __forceinline__ void tile_fused_body(const FusedTask& tk, double (*sA)[KC2 * LDP], double (*sB)[KC2 * LDP],
-                                                const KParam* __restrict__ kp, int D) {
-    static_assert(NCB == 8 || NCB == 4 || NCB == 2 || NCB == 1, "column-block classes");
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // The lower blocks of the block rows < NCB (all 36 for NCB = 8) go global (L2: the diagonal-block launch of this step wrote
-    // them) -> registers -> LDS: off-diagonal blocks from the factorised diagonal tile L_kk (it sits behind the B panel: column
-    // k1 of block row k), diagonal ones -- the inverses L(cb, cb)^-1 -- from Dinv_k.  For NCB = 8 in two halves of 9 loads per
-    // thread, both issued when the product is done: the second lands under the first five block columns of the solve.
-    // Thread t moves the doubles 2 (t & 127), + 1 of block 2 e + (t >> 7).
-    constexpr int NBLK = lower_block_base(NCB), NE = (NBLK + 1) / 2;
-    const int dj = (t & 127) >> 3, di = 2 * (t & 7), dhalf = __builtin_amdgcn_readfirstlane(t >> 7);
-    const double* Lkk = tk.B + (size_t)tk.k1 * (size_t)tk.ldb;
-    auto dinv_load = [&](auto ec) {
-        constexpr int e = decltype(ec)::value;
-        constexpr unsigned pk = lower_block_pack<2>(2 * e, NBLK);
-        const int sel = (int)(pk >> (8 * dhalf)) & 0xff;         // scalar: dhalf is wave-uniform
-        const int cb = sel & 15, jb = sel >> 4;
-        const double* src = (cb == jb) ? tk.Dinv + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * TB
-                                       : Lkk + (size_t)(16 * cb + di) + (size_t)(16 * jb + dj) * (size_t)tk.ldb;
-        return *AS_GLOBAL_D2(src);
-    };
-    RowsplitPrefetch pf;
-    rowsplit_prefetch<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, pf);
-    d4 acc[NCB][NRW];
-    {               // acc = -k(row, col): coordinates through the (still unused) ring
-        const KParam p = kp[tk.kid];
-        double* sa = &sA[0][0];
-        double* sb = &sB[0][0];
-        stage_coords(tk.gxa, tk.glda, tk.gna, tk.gxb, tk.gldb, tk.gnb, D, sa, sb, true);
-        __syncthreads();
-        if (p.kind == 0) rowsplit_gram_init<0, NRW, NCB>(tk.gna, tk.gnb, p, D, acc, sa, sb);
-        else if (p.kind == 1) rowsplit_gram_init<1, NRW, NCB>(tk.gna, tk.gnb, p, D, acc, sa, sb);
-        else rowsplit_gram_init<2, NRW, NCB>(tk.gna, tk.gnb, p, D, acc, sa, sb);
-        __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
-    }
-    gemm_mainloop_rowsplit<NRW, NCB>(tk.A, tk.lda, tk.B, tk.ldb, tk.k1, acc, sA, sB, pf);   // acc = -C; ends on a barrier: the ring is free
-    double* sD = &sA[0][0]; // sA and sB are adjacent: 2 x 4608 doubles = 36 blocks of 256; block b sits at 256 b
-    constexpr int NE1 = (NCB == 8) ? 9 : NE;            // first stage (NCB = 8: block rows 0..4 and three blocks of row 5)
-    d2 dv[NE1];
-    static_for<NE1>([&](auto ec) { dv[decltype(ec)::value] = dinv_load(ec); });
-    d2 dw[9];
-    if constexpr (NCB == 8) {
-        static_for<9>([&](auto ec) { dw[decltype(ec)::value] = dinv_load(std::integral_constant<int, 9 + decltype(ec)::value>{}); });
-    }
-#if DSMGP_TF_TAIL
-    // riders: z_k goes through LDS with the blocks of L_kk and the sums the task adds to are fetched now, so that the task does
-    // not end on two dependent memory round trips (z_k, then w_i read-modify-write) with its waves idle
-    double* sZ = sD + 36 * 256;
-    double wpre[NRW], spre[NRW];
-    if (tk.wi != nullptr) {
-        if (t < TB) sZ[t] = tk.zk[t];
-#pragma unroll
-        for (int rn = 0; rn < NRW; ++rn) {
-            wpre[rn] = tk.wi[16 * NRW * w + 16 * rn + l15];
-            spre[rn] = (tk.sq != nullptr) ? tk.sq[16 * NRW * w + 16 * rn + l15] : 0.0;
-        }
-    }
-#endif
-#pragma unroll
-    for (int e = 0; e < NE1; ++e)
-        if (2 * e + dhalf < NBLK) *reinterpret_cast<d2*>(sD + (size_t)(2 * e + dhalf) * 256 + 2 * (t & 127)) = dv[e];
-    __syncthreads();
-    // Block forward substitution on -C (the accumulators hold -C): block column cb reads the solved columns before it -- the
-    // accumulators ARE the second operand as they stand: register q of X(:, jb) holds the columns 16 jb + l4 + 4 q = the
-    // k-slab q of the product -- and takes over the registers of C(:, cb):
-    //     t = -C(:, cb) + sum_{jb < cb} X(:, jb) L(cb, jb)^T = -T ;   -X(:, cb) = t L(cb, cb)^-T
-    // The sum runs on two accumulators per row block (even and odd jb): a dependent f64 MFMA waits ~100 cycles for its
-    // predecessor where an independent one issues after 64.
-    auto solve_block_column = [&](auto cbc) {
-        constexpr int cb = decltype(cbc)::value;
-        if constexpr (cb < NCB) {
-            d4 x0[NRW], x1[NRW];
-#pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) {
-                x0[rn] = acc[cb][rn];
-                x1[rn] = (d4){0.0, 0.0, 0.0, 0.0};
-            }
-#pragma unroll
-            for (int jb = 0; jb < cb; ++jb) {
-                const double* blk = sD + (lower_block_base(cb) + jb) * 256 + l15;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double a = blk[(4 * q + l4) * 16];
-#pragma unroll
-                    for (int rn = 0; rn < NRW; ++rn) {
-                        const bool second = (DSMGP_TF_QALT && NRW == 1) ? (q & 1) != 0 : (jb & 1) != 0;
-                        if (DSMGP_SOLVE_DUAL && second) x1[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x1[rn], 0, 0, 0);
-                        else x0[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[jb][rn][q], x0[rn], 0, 0, 0);
-                    }
-                }
-            }
-            constexpr bool QALT = DSMGP_TF_QALT && NRW == 1;
-            d4 tt[NRW], y[NRW], y2[NRW];
-#pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) {
-                tt[rn] = (DSMGP_SOLVE_DUAL && cb > (QALT ? 0 : 1)) ? x0[rn] + x1[rn] : x0[rn];
-                y[rn] = (d4){0.0, 0.0, 0.0, 0.0};
-                y2[rn] = (d4){0.0, 0.0, 0.0, 0.0};
-            }
-            const double* dblk = sD + (lower_block_base(cb) + cb) * 256 + l15;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double a = dblk[(4 * q + l4) * 16];
-#pragma unroll
-                for (int rn = 0; rn < NRW; ++rn) {
-                    if (QALT && (q & 1)) y2[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt[rn][q], y2[rn], 0, 0, 0);
-                    else y[rn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt[rn][q], y[rn], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) acc[cb][rn] = QALT ? -(y[rn] + y2[rn]) : -y[rn];     // X itself from here on
-            __builtin_amdgcn_sched_barrier(0);      // keep the operand reads of later column blocks from piling up in registers
-        }
-    };
-    solve_block_column(std::integral_constant<int, 0>{});
-    solve_block_column(std::integral_constant<int, 1>{});
-    solve_block_column(std::integral_constant<int, 2>{});
-    solve_block_column(std::integral_constant<int, 3>{});
-    solve_block_column(std::integral_constant<int, 4>{});
-    if (NCB == 8) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) *reinterpret_cast<d2*>(sD + (size_t)(2 * (9 + e) + dhalf) * 256 + 2 * (t & 127)) = dw[e];
-        __syncthreads();
-    }
-    solve_block_column(std::integral_constant<int, 5>{});
-    solve_block_column(std::integral_constant<int, 6>{});
-    solve_block_column(std::integral_constant<int, 7>{});
-    // store: register q of acc[cb][rn] is X(row = 16 NRW w + 16 rn + l15, col = 16 cb + l4 + 4 q); zeros beyond NCB
-    const unsigned lofs = (unsigned)(16 * NRW * w + l15) + (unsigned)l4 * (unsigned)tk.ldc;
-    const size_t ldc = (size_t)tk.ldc;
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const gf64_ptr col = AS_GLOBAL_F64(tk.C + (size_t)(16 * cb + 4 * q) * ldc);
-#pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) col[lofs + 16 * rn] = (cb < NCB) ? acc[cb < NCB ? cb : 0][rn][q] : 0.0;
-            if (NRW == 1 && tk.zpad) col[lofs + 64] = 0.0;      // rows 64.. of a short tile of the factor: padding
-        }
-    if (tk.wi != nullptr) {     // riders, reduced inside the wave as in tile_trsm_kernel (same order: same bits)
-        double p[NRW], q2[NRW];
-#pragma unroll
-        for (int rn = 0; rn < NRW; ++rn) p[rn] = q2[rn] = 0.0;
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#if DSMGP_TF_TAIL
-                const double z = sZ[16 * cb + l4 + 4 * q];
-#else
-                const double z = tk.zk[16 * cb + l4 + 4 * q];
-#endif
-#pragma unroll
-                for (int rn = 0; rn < NRW; ++rn) {
-                    p[rn] = fma(acc[cb][rn][q], z, p[rn]);
-                    q2[rn] = fma(acc[cb][rn][q], acc[cb][rn][q], q2[rn]);
-                }
-            }
-#pragma unroll
-        for (int rn = 0; rn < NRW; ++rn) {
-            p[rn] += __shfl_xor(p[rn], 16);
-            p[rn] += __shfl_xor(p[rn], 32);
-            q2[rn] += __shfl_xor(q2[rn], 16);
-            q2[rn] += __shfl_xor(q2[rn], 32);
-        }
-        if (l4 == 0) {
-#pragma unroll
-            for (int rn = 0; rn < NRW; ++rn) {
-                const int row = 16 * NRW * w + 16 * rn + l15;
-#if DSMGP_TF_TAIL
-                if (tk.sq == nullptr) tk.wi[row] = wpre[rn] - p[rn];
-                else {
-                    tk.wi[row] = wpre[rn] + p[rn];
-                    tk.sq[row] = spre[rn] + q2[rn];
-                }
-#else
-                if (tk.sq == nullptr) tk.wi[row] -= p[rn];
-                else {
-                    tk.wi[row] += p[rn];
-                    tk.sq[row] += q2[rn];
-                }
-#endif
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void tile_fused_kernel(const FusedTask* __restrict__ tasks, const KParam* __restrict__ kp,
-                                                            int D) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP + (DSMGP_TF_TAIL ? TB : 0)];
-    static_assert(2 * NRING * KC2 * LDP == 36 * 256, "the ring holds the 36 lower blocks of Dinv_k exactly");
-    static_assert(GRAM_FUSE_MAX_D * TB <= NRING * KC2 * LDP, "coordinate image of a tile must fit half the ring");
-    double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem);
-    double (*sB)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(smem + NRING * KC2 * LDP);
-    const FusedTask tk = tasks[blockIdx.x];
-    const bool half = tk.mrows != 0 && tk.mrows <= 64;
-    // valid columns of the tile: fewer than 128 only in the last block column of a leaf (padding columns: X = 0 exactly)
-    const int ncb = (tk.gnb + 15) >> 4;
-    if (ncb <= 1) {
-        if (half) tile_fused_body<1, 1>(tk, sA, sB, kp, D);
-        else tile_fused_body<2, 1>(tk, sA, sB, kp, D);
-    } else if (ncb <= 2) {
-        if (half) tile_fused_body<1, 2>(tk, sA, sB, kp, D);
-        else tile_fused_body<2, 2>(tk, sA, sB, kp, D);
-    } else if (ncb <= 4) {
-        if (half) tile_fused_body<1, 4>(tk, sA, sB, kp, D);
-        else tile_fused_body<2, 4>(tk, sA, sB, kp, D);
-    } else {
-        if (half) tile_fused_body<1, 8>(tk, sA, sB, kp, D);
-        else tile_fused_body<2, 8>(tk, sA, sB, kp, D);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Fused tile task, EIGHT waves (round 4, second half).  tile_fused_kernel runs two workgroups of four waves per CU -- two waves
-// per SIMD at 228-254 registers each -- and one wave cannot keep the f64 matrix pipe busy: it issues an MFMA about every 100
-// cycles where the pipe takes one every 64, and every phase change of a task (coordinates, kernel function, product, L_kk,
-// solve, store) leaves its SIMD to the one other wave.  At depth 4 the launches ran at 60 % of their matrix-pipe time.
-// Here a wave owns ONE 16-row block and all 128 columns (the 16-rows-per-wave form of tile_fused_body, acc[8][1]): 128 registers,
-// so two workgroups of eight waves share a CU -- FOUR waves per SIMD.  And because a wave stages, evaluates, solves and stores
-// its own 16 rows, the eight row blocks of a task need not come from one 128-row tile: a task is ANY eight 16-row blocks below
-// the same diagonal block -- the short last row tile of a leaf's factor and its routed test rows share tasks, nothing is padded
-// beyond 16 rows (executed / algorithmic rows of the depth-4 model 1.31 -> 1.08).  Same arithmetic per row as the
-// 16-rows-per-wave form: -k(row, col) first, the product accumulated on it chunk by chunk, block forward substitution against
-// L_kk with two accumulators, riders reduced inside the wave.
+// Fused tile task, EIGHT waves (round 4).  Until then the task was one 128 x 128 tile in a workgroup of four waves (32 rows a
+// wave, 16 for tiles of <= 64 data rows; 228-254 registers): two workgroups per CU, two waves per SIMD -- and one wave cannot
+// keep the f64 matrix pipe busy (it issues an MFMA about every 100 cycles where the pipe takes one every 64), while every phase
+// change of a task (coordinates, kernel function, product, L_kk, solve, store) left its SIMD to the one other wave: at depth 4
+// the launches ran at 60 % of their matrix-pipe time.  Here a wave owns ONE 16-row block and all 128 columns (acc[8][1]): 128
+// registers, so two workgroups of eight waves share a CU -- FOUR waves per SIMD.  And because a wave stages, evaluates, solves
+// and stores its own 16 rows, the eight row blocks of a task need not come from one 128-row tile: a task is ANY eight 16-row
+// blocks below the same diagonal block -- the short last row tile of a leaf's factor and its routed test rows share tasks,
+// nothing is padded beyond 16 rows (executed / algorithmic rows of the depth-4 model 1.31 -> 1.08; 221k tile tasks -> 191k).
+// Per row: -k(row, col) first, the product accumulated on it chunk by chunk, block forward substitution against L_kk with two
+// accumulators (a dependent f64 MFMA waits ~100 cycles for its predecessor where an independent one issues after 64), riders
+// reduced inside the wave.  Depth 4, same box: fused tile launches 36.9 -> 34.4 ms, step 0.0518 -> 0.0499 s; PoE (config 3)
+// 3.8 -> 3.7 ms; the five shallow steps of the headline model, all whole tiles, 7.4 -> 7.7 ms (profiles/r04_fused8_ab.log).
 struct RowBlock {
     const double* A;      // the 16 rows of the row panel (F[16 r .., 0:K] or rows of Vt), ld lda; nullptr = no block: the wave only stages
     double* C;            // where the solved 16 x 128 block goes, ld ldc
     const double* gx;     // coordinates of the rows, ld glda
-    double* wi;           // rider target as in FusedTask (w_i of train rows / mu sums of test rows), nullptr = none
+    double* wi;           // rider: train rows w_i -= X z_k (forward substitution); test rows (sq set) mu += X z_k.  nullptr = none
     double* sq;           // test rows: sum of squares of the solved row
     int lda, ldc, glda;
     int nvalid;           // rows that hold data (1..16); the others are written as zeros
@@ -632,7 +242,7 @@ __device__ __forceinline__ void tile_fused8_body(const FusedTask8* __restrict__ 
         }
         __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
     }
-    // product: ring and barrier protocol of gemm_mainloop_rowsplit (chunk c is computed from buffer c & 3 while chunk c + 3 is
+    // product: ring and barrier protocol of gemm_mainloop_v2 (chunk c is computed from buffer c & 3 while chunk c + 3 is
     // written and chunk c + 4 is in flight), one barrier per chunk; with four waves per SIMD the hardware interleaves the
     // waves' memory and matrix instructions, so the loop is written plainly
     if (nch > 0) {
@@ -678,7 +288,7 @@ __device__ __forceinline__ void tile_fused8_body(const FusedTask8* __restrict__ 
 #undef F8WRITE
 #undef F8LOAD
     // the ring is free: lower blocks of L_kk (off-diagonal ones from the factorised diagonal tile behind the B panel, the
-    // diagonal inverses from Dinv_k), block b at 256 b as in tile_fused_body; thread t moves the doubles 2 (t & 127), + 1 of
+    // diagonal inverses from Dinv_k), block b at 256 b (lower_block_base); thread t moves the doubles 2 (t & 127), + 1 of
     // block 4 e + (t >> 7) -- NCB = 8: blocks 0..19 now (all that block columns 0..4 need), 20..35 under their solve
     constexpr int NBLK = lower_block_base(NCB);
     constexpr int NE = (NBLK + 3) / 4, NE1 = (NCB == 8) ? 5 : NE;
@@ -761,7 +371,7 @@ __device__ __forceinline__ void tile_fused8_body(const FusedTask8* __restrict__ 
                 col[lofs] = (cb < NCB) ? acc[cb < NCB ? cb : 0][0][q] : 0.0;
             }
     }
-    if (riders) {       // reduced inside the wave in the order of tile_fused_body (same bits)
+    if (riders) {       // reduced inside the wave, columns ascending, then over the four lane groups
         double p = 0.0, q2 = 0.0;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
@@ -914,7 +524,7 @@ __device__ __forceinline__ void diag_finish_front(const TileTask& tt, double* S,
 //   P2  every wave, its blocks (I,K), I >= K > J: S(I,K) -= S(I,J) S(K,J)^T, both operands from the panel, accumulated on
 //       the registers; w_I -= L(I,J) z_J
 // 20 KB of LDS beside the update's 36 KB ring (they alias), registers for nine blocks: three workgroups per CU.
-// No inverse phase (the fused steps' tile tasks substitute against L_kk: tile_fused_body).
+// No inverse phase (the fused steps' tile tasks substitute against L_kk: tile_fused8_body).
 constexpr int DIAGR_PANEL = 8 * 256;                         // doubles: solved panel, block row I at 256 I (column-major, ld 16)
 constexpr int DIAGR_LDS_DOUBLES = DIAGR_PANEL + 256 + 2 * TB + 2;   // + L_JJ^-1 + rhs block + z + first bad pivot
 constexpr int DIAGR_LDS_BYTES = ((NRING * KC2 * LDP > DIAGR_LDS_DOUBLES ? NRING * KC2 * LDP : DIAGR_LDS_DOUBLES) + 16) * (int)sizeof(double);

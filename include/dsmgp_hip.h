@@ -51,7 +51,7 @@ typedef struct dsmgp_ctx dsmgp_ctx;
  * predict_trsm, predict_var, gradients, total_fit, total_predict, chol_reduce (split-K reduce launches of the
  * factorisation), alpha (the backward sweep alpha = L^-T z, run on first use after a fit: gradients, download_factor),
  * grad_inverse (L^-T by blocked triangular inversion), grad_contraction (tile_graddot_kernel), grad_traces,
- * chol_fused (the tile_fused_kernel launches of fused block steps: update + solve of the tiles below the diagonal blocks) */
+ * chol_fused (the tile_fused8_kernel launches of fused block steps: update + solve of the tiles below the diagonal blocks) */
 #define DSMGP_N_TIMINGS 19
 
 /* kernel ids are dense small integers (one hyper-vector each; finetune! gives every leaf its own) */
@@ -197,7 +197,7 @@ int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the
  * all its launches (2*K per lower-triangle element of every block column, unpadded sizes) and the
  * number of launches */
 int dsmgp_work(dsmgp_ctx* ctx, double* alg_flops_update, int32_t* n_update_launches);
-/* the same for the tile_fused_kernel launches of fused block steps (timing slot chol_fused): algorithmic flops of their
+/* the same for the tile_fused8_kernel launches of fused block steps (timing slot chol_fused): algorithmic flops of their
  * update part plus the triangular solves (c_k^2 per row below a diagonal block of c_k columns), and the number of launches.
  * dsmgp_work counts only the steps that run as update launches. */
 int dsmgp_work_fused(dsmgp_ctx* ctx, double* alg_flops_fused, int32_t* n_fused_launches);

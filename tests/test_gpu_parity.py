@@ -1324,7 +1324,7 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
     """Small-leaf regime: a table of 700 leaves of 130..700 rows -- last row tiles of every class (<= 32,
     <= 64, <= 96, whole), 10..150 routed test rows per leaf (short and whole test tiles, two tiles for some), a COPY and
     a PREFIX leaf -- has more diagonal blocks per step than the chip has CUs, so its block steps run fused
-    (diag_fused_reg_kernel + tile_fused_kernel: each tile written once, short tiles in the 16-rows-per-wave form); with
+    (diag_fused_reg_kernel + tile_fused8_kernel: each tile written once, short tiles in the 16-rows-per-wave form); with
     DSMGP_OPT_FUSED_STEPS = 0 the same table runs as update (short tiles in the column-split form) / packed diagonal
     block / panel solve launches.  Same arithmetic up to the order of one addition per entry: log-marginals 1e-12, the
     factor of sampled leaves 1e-11, moments 1e-9 (conditioning-limited); three leaves against the oracle at the
@@ -1375,7 +1375,7 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
     finally:
         ctx.set_option(hipabi.OPT_FUSED_STEPS, 1)
         ctx.set_profile(0)
-    assert a[4]["gram"] < 0.25 * b[4]["gram"]          # no Gram launch: the tasks of block column 0 start from the kernel function
+    assert a[4]["gram"] < 0.5 * b[4]["gram"]           # no Gram launch: the tasks of block column 0 start from the kernel function
     assert np.allclose(a[0], b[0], rtol=1e-12, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
     # the moments carry the conditioning of K_y (1e5..1e6 here, more for the additive ArdSE kernel): two summation orders
     # of the same arithmetic agree to ~ cond x 1e-16, an order of magnitude inside the north-star tolerance

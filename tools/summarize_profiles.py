@@ -61,7 +61,7 @@ def write_traffic(per_step):
         """tile_gemm dispatches of the last TIMED-kind step: the update launches run as tile_gemm_kernel_v2<false, 0, *>
         while per-launch timing is on (warm-up, timed steps, the breakdown step) and as <false, 2, *> in bench.py's untimed
         standalone fit/predict extra, so the last dispatches of that name are one whole joint fit (the shallow block steps
-        run as tile_fused_kernel: counted in launches_per_step, not in this kernel's dispatches)."""
+        run as tile_fused8_kernel: counted in launches_per_step, not in this kernel's dispatches)."""
         rows = [r for r in rows_of(d) if r["Counter_Name"] == counter and "tile_gemm_kernel_v2<false, 0," in r["Kernel_Name"]]
         per_fit = len(rows) // max(1, int(round(len(rows) / per_step)))
         return rows[-per_fit:]
