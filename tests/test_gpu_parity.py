@@ -1394,6 +1394,71 @@ def test_fused_steps_agree_with_the_classic_steps(ctx, kind):
         assert np.allclose(a[2][rptr[j]:rptr[j + 1]], vo, rtol=RTOL, atol=1e-10)
 
 
+def test_fused_tile_tasks_pack_ragged_row_blocks(ctx):
+    """The eight-wave fused tile task (round 4) packs ANY eight 16-row blocks below a diagonal block into one task: the last
+    rows of a leaf's factor and its routed test rows share tasks, blocks hold 1..16 valid rows, the last task of a leaf is
+    partly empty, the padding rows below the data are zeroed once per plan.  A table built from the edge cases -- leaf sizes
+    one below / at / one above the multiples of 16 and of 128 (17 .. 640 rows: one to five block steps, all of them fused by
+    the shallow rule), 0, 1, 15, 16, 17, 127, 128, 129 and 200 routed test rows, a leaf of ONE block (test blocks only), a
+    COPY leaf whose test rows ride on its source's factor -- against the classic steps (update / diagonal block / panel solve
+    launches) entry by entry, and every leaf against the oracle at the north-star tolerance."""
+    N, D = 40_000, 3
+    X, y, Xt = regression_data(N, D, n_test=256, seed=8642)
+    rng = np.random.default_rng(97)
+    edge_n = [17, 100, 127, 128, 129, 143, 144, 145, 159, 160, 161, 255, 256, 257, 271, 272, 273, 300, 383, 384, 385, 400, 511, 512, 513,
+              527, 528, 529, 600, 639, 640]
+    edge_t = [0, 1, 15, 16, 17, 100, 127, 128, 129, 200]
+    sizes = [edge_n[i % len(edge_n)] for i in range(62)]
+    ntest = [edge_t[(3 * i + i // len(edge_t)) % len(edge_t)] for i in range(62)]
+    obs = [np.sort(rng.choice(N, size=int(n), replace=False)) for n in sizes]
+    L = len(obs)
+    obs[40] = obs[7].copy()                                               # COPY of leaf 7 (145 rows), with test rows of its own
+    ntest[40], ntest[7] = 33, 0
+    op = np.zeros(L, dtype=np.int32)
+    src = np.full(L, -1, dtype=np.int32)
+    plen = np.zeros(L, dtype=np.int64)
+    op[40], src[40] = 1, 7
+    rptr = np.concatenate([[0], np.cumsum(ntest)])
+    ridx = np.concatenate([np.sort(rng.choice(Xt.shape[0], size=int(k), replace=False)) for k in ntest if k > 0])
+    hyp = [np.log(0.3), 0.0, np.log(0.1)]
+    means = [float(np.mean(y[o])) for o in obs]
+    means[40] = means[7]
+
+    def run(fused):
+        ctx.set_option(hipabi.OPT_FUSED_STEPS, 1 if fused else 0)
+        ctx.set_train(X, y)
+        ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, dtype=np.int32), means)
+        ctx.set_sharing(op, src, plen)
+        ctx.set_hyper(0, 0, hyp)
+        ctx.set_test(Xt, rptr, ridx)
+        mll, info, _ = ctx.fit()
+        assert np.all(info == 0)
+        ctx.predict_run()
+        mu, var = ctx.predict_fetch()
+        fa = [ctx.download_factor(j, obs[j].size) for j in range(L)]
+        return mll, mu, var, fa, ctx.work_fused()
+
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        ctx.set_option(hipabi.OPT_FUSED_STEPS, 1)
+    assert a[4][1] > 0 and b[4][1] == 0                   # the first run did launch fused tile tasks, the second none
+    assert np.allclose(a[0], b[0], rtol=1e-12, atol=0), float(np.max(np.abs(a[0] - b[0]) / np.abs(b[0])))
+    assert float(np.max(np.abs(a[1] - b[1])) / max(1.0, float(np.max(np.abs(b[1]))))) <= 1e-9
+    assert float(np.max(np.abs(a[2] - b[2]) / np.abs(b[2]))) <= 1e-9
+    for (Fa, aa), (Fb, ab) in zip(a[3], b[3]):
+        assert np.max(np.abs(Fa - Fb)) <= 1e-11 * np.max(np.abs(Fb))
+        assert np.max(np.abs(aa - ab)) <= 1e-8 * np.max(np.abs(ab))
+    for j in range(L):
+        g = ogp.GaussianProcess(X[obs[j]], y[obs[j]], means[j], ogp.IsoSE(hyp[0], hyp[1]), hyp[-1], True).update_cholesky()
+        assert abs(a[0][j] - g.mll()) <= RTOL * abs(g.mll()), j
+        if ntest[j]:
+            mo, vo = g.prediction(Xt[ridx[rptr[j]:rptr[j + 1]]])
+            assert np.allclose(a[1][rptr[j]:rptr[j + 1]], mo, rtol=RTOL, atol=1e-9), j
+            assert np.allclose(a[2][rptr[j]:rptr[j + 1]], vo, rtol=RTOL, atol=1e-10), j
+
+
 def test_set_sharing_after_set_test_drops_the_test_set(ctx):
     """dsmgp_set_sharing rebuilds the leaf plan, so a test set registered before it (whose task lists point
     into the old plan's arenas) must go with it -- the C ABI sequence set_leaves -> set_test -> set_sharing -> fit used to

@@ -3,6 +3,10 @@ buildDSMGP K=4 splits, V=3 sum children, M=500, N=500k, D=16, kernels [IsoSE, Is
 n up to ~89k (a 64 GB factor), 2.8 TB of factors in total.  One fit! + update! + predict, optionally one train! iteration.
 
     python tools/run_config5.py [--train] [--N 500000]
+
+A run of gpurun is limited to 20 minutes and a train! iteration of this model takes 231 s on one GPU, so the 20 iterations
+SURVEY 8(d) names are run as five calls of four: --save-hyper writes the hyper-vector after every optimiser step, --load-hyper
+starts the next call from it (exact: the reference's ADAM carries no state from one iteration to the next).
 """
 import argparse, json, os, sys, time
 import numpy as np
@@ -16,6 +20,8 @@ ap.add_argument("--M", type=int, default=500)
 ap.add_argument("--train", action="store_true")
 ap.add_argument("--iterations", type=int, default=1, help="train! iterations to time (with --train)")
 ap.add_argument("--host-only", action="store_true", help="build the tree and schedule only (no GPU)")
+ap.add_argument("--load-hyper", default=None, help=".npy hyper-vector to start train! from (instead of the random initialisation)")
+ap.add_argument("--save-hyper", default=None, help=".npy file that receives the hyper-vector after every optimiser step")
 args = ap.parse_args()
 
 t0 = time.perf_counter()
@@ -36,15 +42,21 @@ if args.train:                        # train! iterations (src/optimisers.jl:40-
         def apply(self, hyp, g):
             TimedADAM.stamps.append(time.perf_counter())
             print(f"# iteration {len(TimedADAM.stamps)} done at {TimedADAM.stamps[-1] - t0:.1f} s", flush=True)
-            return super().apply(hyp, g)
+            step = super().apply(hyp, g)
+            if args.save_hyper:
+                np.save(args.save_hyper, hyp + step)
+            return step
+    if args.load_hyper:
+        dsm.setparams(model, np.load(args.load_hyper))
     t0 = time.perf_counter()
-    _, hist = dsm.train(model, TimedADAM(), iterations=args.iterations, earlystop=10 ** 9)
+    _, hist = dsm.train(model, TimedADAM(), iterations=args.iterations, earlystop=10 ** 9, randinit=not args.load_hyper)
     t_end = time.perf_counter()
     st = [t0] + TimedADAM.stamps
     out["train_iteration_s"] = [round(b - a, 2) for a, b in zip(st[:-1], st[1:])]
     out["final_fit_s"] = round(t_end - st[-1], 2)
     out["train_total_s"] = round(t_end - t0, 2)
     out["mll_history"] = [float(v) for v in hist]
+    out["hyper_after"] = [float(v) for v in dsm.getparams(model)]
     print(f"# train: iterations {out['train_iteration_s']} s, final fit {out['final_fit_s']} s", flush=True)
     out["passes"] = getattr(model.ctx, "passes", None)
     g_ = getattr(model.ctx, "groups", None)     # (train() restores the plain streaming context when it is done)
