@@ -93,7 +93,7 @@ static_assert(lower_block_base(0) == 0 && lower_block_base(5) == 15 && lower_blo
 // gram_finish): the values the Gram launch would have written, negated.  The product is then accumulated ON it, so the
 // task starts with the kernel function -- under the memory latency of its first operand loads, with the accumulators not
 // yet live -- and the accumulators end as -(K - A B^T) = -C.
-template <int KIND, int NRW, int NCB = 8>
+template <int KIND, int NRW, int NCB = 8, bool EDGE = true>    // EDGE = false: every row and column of the wave's blocks holds data (no masks)
 __device__ __forceinline__ void rowsplit_gram_init(int gna, int gnb, const KParam& p, int D, d4 (&acc)[NCB][NRW], const double* sa,
                                                       const double* sb) {
     const int lane = threadIdx.x & 63;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void rowsplit_gram_init(int gna, int gnb, const KPara
             const int cidx = 16 * CG * cp + 16 * (j >> 2) + l4 + 4 * (j & 3);
 #pragma unroll
             for (int rn = 0; rn < NRW; ++rn) {
-                acc[CG * cp + (j >> 2)][rn][j & 3] = -gram_finish<KIND, true>(z[rn][j], p, rowbase + 16 * rn, cidx, gna, gnb, false);
+                acc[CG * cp + (j >> 2)][rn][j & 3] = -gram_finish<KIND, EDGE>(z[rn][j], p, rowbase + 16 * rn, cidx, gna, gnb, false);
             }
         }
     }
@@ -236,9 +236,15 @@ __device__ __forceinline__ void tile_fused8_body(const FusedTask8* __restrict__ 
         __syncthreads();
         if (active) {
             const int gna = 16 * w + rb.nvalid;     // rowsplit_gram_init counts rows from the top of the 128-row image
-            if (p.kind == 0) rowsplit_gram_init<0, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
-            else if (p.kind == 1) rowsplit_gram_init<1, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
-            else rowsplit_gram_init<2, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
+            if (rb.nvalid == 16 && gnb >= 16 * NCB) {       // no padding rows or columns in this wave's blocks (wave-uniform)
+                if (p.kind == 0) rowsplit_gram_init<0, 1, NCB, false>(gna, gnb, p, D, acc, sa, sb);
+                else if (p.kind == 1) rowsplit_gram_init<1, 1, NCB, false>(gna, gnb, p, D, acc, sa, sb);
+                else rowsplit_gram_init<2, 1, NCB, false>(gna, gnb, p, D, acc, sa, sb);
+            } else {
+                if (p.kind == 0) rowsplit_gram_init<0, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
+                else if (p.kind == 1) rowsplit_gram_init<1, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
+                else rowsplit_gram_init<2, 1, NCB>(gna, gnb, p, D, acc, sa, sb);
+            }
         }
         __syncthreads();    // the coordinates are no longer read: the ring takes the operand chunks
     }

@@ -2,7 +2,7 @@
 # per-launch log of a step with two library builds (same box): LIBA, LIBB = paths; BENCHARGS = extra bench.py arguments
 set -e
 cd "$GRAFT_REPO_ROOT"
-o=gpurun_out/r04c; mkdir -p $o
+o=gpurun_out/steplog_ab; mkdir -p $o
 pk=deepstructuredmixtures_amd
 cp $pk/libdsmgp_hip.so /tmp/lib_product.so
 trap 'cp /tmp/lib_product.so '"$pk"'/libdsmgp_hip.so' EXIT

@@ -1,4 +1,4 @@
-"""Per-step comparison of two DSMGP_STEPLOG files (tools/r04_steplog_ab.sh): update launches (slot 1) and the chain (slots 2, 3)."""
+"""Per-step comparison of two DSMGP_STEPLOG files (tools/steplog_ab.sh): update launches (slot 1) and the chain (slots 2, 3)."""
 import re, sys, collections
 
 def load(f):
