@@ -308,18 +308,39 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     td = None
+    exchange_backend = None
     if world > 1:
+        import datetime
         import torch.distributed as td
         ndev = torch.cuda.device_count()
         backend = os.environ.get("DSMGP_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on one GPU
-        if backend == "nccl":
-            assert ndev >= world, f"{world} ranks need {world} GPUs, {ndev} visible"
         local_rank = local_rank % max(1, ndev)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            td.init_process_group(backend, rank=rank, world_size=world)
+            # RCCL, proven by one tiny all-reduce before anything depends on it.  A node on which it does not come up (fewer
+            # GPUs than ranks, an IPC or driver problem: the same on every rank) still gets its run: the two small all-gathers
+            # of a step then travel over gloo, and the line says so (config.exchange).
+            try:
+                if ndev < world:
+                    raise RuntimeError(f"{world} ranks need {world} GPUs, {ndev} visible")
+                td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                      timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device="cuda")
+                td.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"RCCL all-reduce of ones over {world} ranks gave {probe.item()}")
+            except Exception as e:      # noqa: BLE001
+                print(f"# rank {rank}: RCCL process group not usable ({e}); falling back to gloo for the exchange", file=sys.stderr)
+                try:
+                    if td.is_initialized():
+                        td.destroy_process_group()
+                except Exception:       # noqa: BLE001
+                    pass
+                backend = "gloo"
+        if backend != "nccl":
+            td.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        exchange_backend = backend
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import deepstructuredmixtures_amd as dsm
@@ -514,13 +535,16 @@ def main():
                                    f"fit! (Gram+Cholesky+forward solve+mll) + update! + predict",
                        "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and of the aggregation's partial sums"
                                       + (f"; {n_sub} concurrent contexts per GPU" if n_sub > 1 else "")
-                                      + (f"; exchange: {model.shard.exchange}" if world > 1 else "")},
+                                      + (f"; exchange: {model.shard.exchange} over the {exchange_backend} process group"
+                                         if world > 1 else "")},
             "matrix_tflops_fit_predict": matrix_flops_total / ((cats.get("total_fit", 0.0) + cats.get("total_predict", 0.0))
                                                                / args.steps) / 1e12 if world == 1 else None,
             "device_seconds_per_step": {k: v / args.steps for k, v in cats.items() if v > 0},
             "root_mll": root[0],
             "model_build_s": model.build_seconds,
         }
+        if world > 1:
+            out["exchange_backend"] = exchange_backend      # "nccl" (= RCCL); "gloo" only if RCCL did not come up on this node
         if standalone is not None:
             out["standalone_fit_s"] = standalone["fit_s"]
             out["standalone_predict_s"] = standalone["predict_s"]

@@ -1096,6 +1096,17 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
     assert np.isfinite(j2["value"]) and j2["value"] > 0 and j2["unit"] == "s" and j2["metric"] == j1["metric"]
     assert abs(j2["root_mll"] - j1["root_mll"]) <= 1e-10 * abs(j1["root_mll"])
     assert "roofline" in j1 and "standalone_predict_s" in j1 and j1["roofline"]["bound"] == "mfma"
+    assert j2["exchange_backend"] == "gloo"
+    # the same launch as the driver's (no backend override): RCCL cannot come up with two ranks on this one GPU, and the run
+    # must say so and complete over gloo instead of dying -- on every rank alike
+    port = str(31000 + (os.getpid() * 7) % 2000)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j3 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j3["n_gpus"] == 2 and j3["exchange_backend"] == "gloo" and "falling back to gloo" in two.stderr
+    assert abs(j3["root_mll"] - j1["root_mll"]) <= 1e-10 * abs(j1["root_mll"])
 
 
 def test_rccl_allgather_entry_point(ctx):
