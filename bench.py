@@ -514,10 +514,18 @@ def main():
         t1 = time.perf_counter()
         mu_s, var_s = dsm.predict(model, Xt)
         t2 = time.perf_counter()
-        ctx.set_joint(True)
         assert np.allclose(mu_s, mu, rtol=1e-9, atol=1e-11) and np.allclose(var_s, var, rtol=1e-8, atol=1e-12)
-        standalone = {"fit_s": t1 - t0, "predict_s": t2 - t1,
-                      "note": "fit! + update! without a resident test set, then predict(model, Xt) running its own sweep"}
+        # ... and predict on rows the model has not seen (the same rows in reverse order: a new matrix to route, register and
+        # sweep; the answers must be the old ones reversed)
+        Xt2 = np.ascontiguousarray(Xt[::-1])
+        t3 = time.perf_counter()
+        mu_n, var_n = dsm.predict(model, Xt2)
+        t4 = time.perf_counter()
+        ctx.set_joint(True)
+        assert np.allclose(mu_n[::-1], mu, rtol=1e-9, atol=1e-11) and np.allclose(var_n[::-1], var, rtol=1e-8, atol=1e-12)
+        standalone = {"fit_s": t1 - t0, "predict_s": t2 - t1, "predict_new_rows_s": t4 - t3,
+                      "note": "fit! + update! without a resident test set, then predict(model, Xt) running its own sweep; "
+                              "predict_new_rows: predict(model, x) on a test matrix the model has not seen (routing, registration, sweep)"}
 
     if rank == 0:
         c = CONFIGS[args.config]
@@ -548,6 +556,7 @@ def main():
         if standalone is not None:
             out["standalone_fit_s"] = standalone["fit_s"]
             out["standalone_predict_s"] = standalone["predict_s"]
+            out["standalone_predict_new_rows_s"] = standalone["predict_new_rows_s"]
             out["standalone_note"] = standalone["note"]
         if roof is not None:
             out["roofline"] = roof

@@ -1457,6 +1457,16 @@ int ensure_phase(dsmgp_ctx* c) {
     return 0;
 }
 
+// Step lists of a fit! with the registered test rows riding along: built on first use (see dsmgp_set_test).
+int ensure_joint(dsmgp_ctx* c) {
+    if (c->joint_ready) return 0;
+    HostLog hl("ensure_joint: joint factor steps");
+    if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint, c->alg_flops_fused_joint)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->joint_ready = true;
+    return 0;
+}
+
 // dpos / dfin / ndfin: an update launch that carries its step's diagonal-block tasks (tile_gemm_kernel_v2's grid layout)
 void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */, bool pad = false,
                   int dpos = 0, const DiagFinishTask* dfin = nullptr, int ndfin = 0) {
@@ -1886,9 +1896,12 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         if (int rc = build_plan(c)) return rc;
     if (int rc = upload_hyper(c)) return rc;
     // With a resident test set the rows of K_tn ride through the same launches (build_factor_steps).
-    const bool joint = c->joint && c->test_ready && c->joint_ready;
-    if (!joint)
-        if (int rc = ensure_phase(c)) return rc;
+    const bool joint = c->joint && c->test_ready;
+    if (joint) {
+        if (int rc = ensure_joint(c)) return rc;
+    } else if (int rc = ensure_phase(c)) {
+        return rc;
+    }
     const int L = c->L;
     for (int i = 0; i < 6; ++i) c->timings[i] = 0.0;
     c->timings[11] = 0.0;
@@ -2234,12 +2247,14 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     }
     if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
     if (int rc = dev_upload(c, c->ptasks_slow, ptk_slow)) return rc;
-    // the same test rows as riders of the factorisation launches (used by fit while this test set is resident)
-    {
-        HostLog hl("set_test: joint factor steps");
-        if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint, c->alg_flops_fused_joint)) return rc;
-    }
-    c->joint_ready = true;
+    // The same test rows as riders of the factorisation launches (used by fit while this test set is resident).  With a device
+    // pool (the streaming context: the pool is a stack, plan < test < gradients, and a fit follows at once) the lists are built
+    // here; otherwise by the first fit that wants them (ensure_joint) -- predict(model, x) on rows the model has not seen
+    // registers them and runs its own sweep, and should not wait for task lists only a later fit! would use (0.067 s of the
+    // 0.088 s this call took at the headline model).
+    c->joint_ready = false;
+    if (c->pool_base)
+        if (int rc = ensure_joint(c)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->test_ready = true;
     c->vt_valid = false;
