@@ -78,6 +78,8 @@ SIGNATURES = {
     "dsmgp_tree_export": (C.c_int, [C.c_void_p, _ip, _ip, _ip, _dp, _dp, _lp, _dp, _lp, _lp, _dp]),
     "dsmgp_tree_means": (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp]),
     "dsmgp_tree_free": (C.c_int, [C.c_void_p]),
+    "dsmgp_tree_route": (C.c_int, [C.c_int64, C.POINTER(C.c_int8), _lp, _lp, _lp, _dp, C.c_int64, _lp, C.c_int64, _dp, C.c_int64,
+                                   C.c_int64, C.c_int64, _lp, _lp, C.c_int64, _lp]),
     "dsmgp_estimate_bytes": (C.c_int64, [C.c_int32, _lp, _lp, C.c_int32, C.c_int32]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
@@ -681,6 +683,29 @@ def overlap_main(obs_ptr, obs_idx, N):
     if rc != 0:
         raise DsmgpError(rc, "dsmgp_overlap_main: bad leaf table")
     return main, cm
+
+
+def tree_route(kind, first_child, n_child, split_dim, thr, leaf_id, n_leaves, xt, reach):
+    """CSR (route_ptr, route_idx) of the test rows every leaf predicts, from the flat tree arrays of tree._RouteIndex (host
+    routine of the library, no device; include/dsmgp_hip.h dsmgp_tree_route).  reach: the most leaves one row can reach."""
+    lib = load_library()
+    x = np.asarray(xt, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    if not (x.flags.c_contiguous or x.flags.f_contiguous):
+        x = np.ascontiguousarray(x)
+    rs, cs = x.strides[0] // 8, x.strides[1] // 8
+    ptr = np.zeros(int(n_leaves) + 1, dtype=np.int64)
+    idx = np.empty(int(x.shape[0]) * int(reach), dtype=np.int64)
+    nr = C.c_int64(0)
+    rc = lib.dsmgp_tree_route(int(kind.size), kind.ctypes.data_as(C.POINTER(C.c_int8)), first_child.ctypes.data_as(_lp),
+                              n_child.ctypes.data_as(_lp), split_dim.ctypes.data_as(_lp), thr.ctypes.data_as(_dp), int(thr.shape[1]),
+                              leaf_id.ctypes.data_as(_lp), int(n_leaves), x.ctypes.data_as(_dp), int(x.shape[0]), int(rs), int(cs),
+                              ptr.ctypes.data_as(_lp), idx.ctypes.data_as(_lp), int(idx.size), C.byref(nr))
+    if rc != 0:
+        raise ValueError("test point outside the region of a split node (reference loops forever here)" if rc == -1
+                         else f"dsmgp_tree_route failed ({rc})")
+    return ptr, idx[:nr.value].copy() if nr.value < idx.size else idx
 
 
 def tree_build(X, min_data, n_splits, n_sum_children, depth, bnoise, sum_root, n_kernels, seed, y=None):

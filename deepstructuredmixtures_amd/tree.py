@@ -559,11 +559,57 @@ def get_child(node, x):
     return idx
 
 
+class _RouteIndex:
+    """The tree as flat arrays in breadth-first order (the children of a node are consecutive): what the library's host
+    routine `dsmgp_tree_route` walks.  At depth 4 (5.6k split nodes, 18k leaves, 810k routed rows) the recursion over node
+    objects took 0.09-0.18 s per test matrix, four times the prediction sweep it feeds."""
+
+    def __init__(self, root):
+        nodes = [root]
+        kind, first, nchild, sdim, leaf, thr = [], [], [], [], [], []
+        i = 0
+        while i < len(nodes):
+            nd = nodes[i]
+            kind.append(0 if nd.kind == "gp" else 1 if nd.kind == "split" else 2)        # as dsmgp_tree_export numbers them
+            first.append(len(nodes))
+            nchild.append(len(nd.children))
+            leaf.append(nd.leaf if nd.kind == "gp" else -1)
+            sdim.append(nd.split[0][0] if nd.kind == "split" else 0)
+            thr.append([t for (_, t) in nd.split] if nd.kind == "split" else [])
+            nodes.extend(nd.children)
+            i += 1
+        self.kind = np.array(kind, dtype=np.int8)
+        self.first = np.array(first, dtype=np.int64)
+        self.nchild = np.array(nchild, dtype=np.int64)
+        self.sdim = np.array(sdim, dtype=np.int64)
+        self.leaf = np.array(leaf, dtype=np.int64)
+        self.thr = np.full((len(nodes), max(1, max(len(t) for t in thr))), np.inf)
+        for j, t in enumerate(thr):
+            self.thr[j, :len(t)] = t
+        reach = [1] * len(nodes)        # the most leaves one row can reach below a node: all children of a sum node, one of a split node
+        for j in range(len(nodes) - 1, -1, -1):
+            if kind[j]:
+                below = reach[first[j]:first[j] + nchild[j]]
+                reach[j] = sum(below) if kind[j] == 2 else max(below)
+        self.reach = reach[0]
+
+
 def route(root, xt):
     """Which test rows each leaf is asked to predict: CSR (route_ptr, route_idx) in leaf order.
 
     Sum nodes forward every row to every child, split nodes to exactly one child
-    (`src/common.jl:181-196,275-292`)."""
+    (`src/common.jl:181-196,275-292`).  Walked by the library's host routine on the flat arrays of the tree (`_RouteIndex`,
+    built on first use); `route_recursive` is the literal recursion it is tested against."""
+    from . import hipabi
+    n_leaves = len(get_leaves(root))
+    ri = getattr(root, "_route_index", None)
+    if ri is None:
+        ri = root._route_index = _RouteIndex(root)
+    return hipabi.tree_route(ri.kind, ri.first, ri.nchild, ri.sdim, ri.thr, ri.leaf, n_leaves, xt, ri.reach)
+
+
+def route_recursive(root, xt):
+    """`route` as the reference walks it: one recursion per node (`src/common.jl:181-196,275-292`)."""
     leaves = get_leaves(root)
     rows = [None] * len(leaves)
 

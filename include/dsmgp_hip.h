@@ -231,6 +231,22 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* ctx, int32_t blocks_per_cu, double* o
 int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx, int64_t N, int64_t* main_out,
                        int64_t* c_main_out);
 
+/* Host-only: which test rows each leaf is asked to predict (the routing of predict, src/common.jl:181-196,275-292: a sum node
+ * forwards its rows to every child, a split node to the first child k with x[d] <= s_k) -- the CSR that dsmgp_set_test takes.
+ * The tree as flat arrays with the children of node i at first_child[i] .. first_child[i] + n_child[i] - 1 (root = node 0):
+ * kind as in dsmgp_tree_export: 0 = region, i.e. leaf (leaf_id), 1 = split node (split_dim, ascending thresholds
+ * thr[i * thr_ld + 0 .. n_child[i] - 1]), 2 = sum node.
+ * x: element (row r, dimension d) at x[r * row_stride + d * col_stride].  route_ptr: n_leaves + 1 entries; route_idx: `capacity`
+ * entries for the rows of every leaf, ascending (a row reaches at most as many leaves as the tree has below sum nodes along one
+ * path: n_t times that bound always suffices).  DSMGP_E_ARG: malformed tree, or a row beyond the last threshold of a split node
+ * (the reference loops forever there); DSMGP_E_NOMEM: capacity too small -- route_ptr and *n_routes_out are valid, route_idx
+ * is not.  At depth 4 (18k leaves, 10k rows to 81 leaves each) the recursion over node objects took 0.09 s on the host, four
+ * times the prediction sweep it feeds. */
+int dsmgp_tree_route(int64_t n_nodes, const int8_t* kind, const int64_t* first_child, const int64_t* n_child,
+                     const int64_t* split_dim, const double* thr, int64_t thr_ld, const int64_t* leaf_id, int64_t n_leaves,
+                     const double* x, int64_t n_t, int64_t row_stride, int64_t col_stride, int64_t* route_ptr,
+                     int64_t* route_idx, int64_t capacity, int64_t* n_routes_out);
+
 /* ---- multi-GPU: the one exchange step of the path.  Leaves are independent, every rank (one process
  *      per GPU, one context each) fits and predicts its own shard; what crosses GPUs is one all-gather of per-leaf
  *      log-marginals after dsmgp_fit and one of the aggregation's partial sums after dsmgp_aggregate_partial, over RCCL

@@ -847,6 +847,50 @@ def test_host_only_entry_points_reject_bad_arguments():
     assert hipabi.estimate_bytes([128], [0], 3) == (128 * 128 + 128 * 128 + 128 * 7) * 8
 
 
+def test_native_routing_equals_the_recursion():
+    """`route` (the library's host routine `dsmgp_tree_route` on the flat arrays of the tree) against the literal recursion
+    of `src/common.jl:181-196,275-292`: complete and ragged trees (regions that stop early for want of data), a split root,
+    kernel vectors (sum nodes of GPs below the regions), one input dimension, row- and column-major test matrices, rows ON
+    a threshold, no rows at all; and the error codes of the entry point."""
+    cases = [dict(N=3000, D=3, K=3, V=4, M=40, depth=3), dict(N=700, D=2, K=2, V=3, M=60, depth=4),      # the second: ragged
+             dict(N=500, D=1, K=3, V=4, M=10, depth=2), dict(N=2000, D=5, K=1, V=5, M=100, depth=2)]
+    for i, c in enumerate(cases):
+        X, y, Xt = regression_data(c["N"], c["D"], n_test=333, seed=900 + i)
+        kern = [dsm.IsoSE(0.0, 0.0), dsm.IsoLinear(0.0)] if i == 0 else dsm.IsoSE(0.0, 0.0)
+        m = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=kern, seed=40 + i, fit_now=False, device=None)
+        ref = ptree.route_recursive(m.root, Xt)
+        for xt in (Xt, np.asfortranarray(Xt), Xt[:0]):
+            got = ptree.route(m.root, xt)
+            exp = ref if xt.shape[0] else ptree.route_recursive(m.root, xt)
+            assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and got[1].dtype == np.int64
+        if c["depth"] == 4:
+            assert len(set(np.bincount(ref[1], minlength=Xt.shape[0]))) > 1          # rows reach different numbers of leaves
+        # rows exactly on the thresholds of the first split node below the root go to the child on the low side
+        node = m.root.children[0] if m.root.kind == "sum" else m.root
+        d = node.split[0][0]
+        on = np.repeat(Xt[:1], len(node.split) - 1, axis=0)
+        on[:, d] = [t for (_, t) in node.split[:-1]]
+        a, b = ptree.route(m.root, on), ptree.route_recursive(m.root, on)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    lib = hipabi.load_library()
+    ri = m.root._route_index
+    lp, dp = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
+    ptr = np.zeros(len(ptree.get_leaves(m.root)) + 1, dtype=np.int64)
+    idx = np.zeros(4, dtype=np.int64)
+    nr = ctypes.c_int64(0)
+    x = np.ascontiguousarray(Xt)
+
+    def call(kind, capacity):
+        return lib.dsmgp_tree_route(int(kind.size), kind.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), ri.first.ctypes.data_as(lp),
+                                    ri.nchild.ctypes.data_as(lp), ri.sdim.ctypes.data_as(lp), ri.thr.ctypes.data_as(dp),
+                                    int(ri.thr.shape[1]), ri.leaf.ctypes.data_as(lp), ptr.size - 1, x.ctypes.data_as(dp), x.shape[0],
+                                    x.shape[1], 1, ptr.ctypes.data_as(lp), idx.ctypes.data_as(lp), capacity, ctypes.byref(nr))
+    assert call(ri.kind, 4) == -4 and nr.value == ref[1].size and np.array_equal(ptr, ref[0])    # too small: sizes come back
+    bad = ri.kind.copy()
+    bad[0] = 7
+    assert call(bad, 4) == -1                                                                    # malformed tree
+
+
 def test_overlap_main_counter_widths_threads_and_observation_table():
     """dsmgp_overlap_main counts each overlapping pair once, with 16-bit counters while every leaf is below 65,536
     observations and 32-bit ones above; candidate tables of the worker threads are merged by (larger product, lower
