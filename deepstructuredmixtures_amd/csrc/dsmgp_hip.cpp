@@ -432,6 +432,8 @@ struct dsmgp_ctx {
     int64_t* d_route_idx = nullptr;
     std::vector<int64_t> route_ptr;
     double* arenaVt = nullptr;
+    double* spareVt = nullptr;      // the K_tn arena of the test set a new registration replaces, kept for it (see dsmgp_set_test)
+    size_t spareVt_count = 0, arenaVt_count = 0;
     double* arenaXt = nullptr;
     double* arenaPV = nullptr;      // mu | var (route order, unpadded) | macc | sacc (padded accumulators of the sweep)
     size_t acc_off = 0, acc_count = 0;
@@ -440,6 +442,8 @@ struct dsmgp_ctx {
     DevBuf<GramTask> pgram0;        // ... of the joint fit when the Gram is fused: block column 0 only
     DevBuf<PredTask> ptasks;
     std::vector<int> pupd_off, pred_off, ptrsm_off;
+    DevBuf<FusedTask8> psweep8;     // the sweep's tasks in the block steps that run fused: update + solve of eight 16-row blocks each
+    std::vector<int> psweep8_off;
     DevBuf<TileTask> pupd, ptrsm;
     DevBuf<ReduceTask> pred;
     int psteps = 0;
@@ -589,7 +593,7 @@ void free_grad(dsmgp_ctx* c) {
     c->grad_ready = false;
 }
 
-void free_test(dsmgp_ctx* c);
+void free_test(dsmgp_ctx* c, bool keep_vt = false);
 void free_plan(dsmgp_ctx* c) {
     drop_graphs(c);
     if (c->pool_base) {      // stack order: everything above the plan goes with it
@@ -627,7 +631,7 @@ void free_plan(dsmgp_ctx* c) {
     c->fitted = false;
 }
 
-void free_test(dsmgp_ctx* c) {
+void free_test(dsmgp_ctx* c, bool keep_vt) {
     drop_graphs(c);
     if (c->pool_base) {      // the gradient arenas sit above (or would be clobbered below) the test arenas
         free_grad(c);
@@ -645,7 +649,17 @@ void free_test(dsmgp_ctx* c) {
     dev_free(c->d_agg_out);
     c->agg_part_cap = 0;
     c->agg_partial_ready = c->agg_done = c->agg_total = false;
+    // A registration that replaces another keeps the old K_tn arena for itself: releasing ~10 GB and asking the driver for them
+    // again took up to 0.6 s of a 0.06 s predict(model, x) on new rows (depth 4).  Every other caller lets both go.
+    arena_put(c, c->spareVt);
+    c->spareVt_count = 0;
+    if (keep_vt && c->arenaVt && !in_pool(c, c->arenaVt)) {
+        c->spareVt = c->arenaVt;
+        c->spareVt_count = c->arenaVt_count;
+        c->arenaVt = nullptr;
+    }
     arena_put(c, c->arenaVt);
+    c->arenaVt_count = 0;
     arena_put(c, c->arenaXt);
     arena_put(c, c->arenaPV);
     dev_free(c->pgram.p);
@@ -656,6 +670,7 @@ void free_test(dsmgp_ctx* c) {
     dev_free(c->pupd.p);
     dev_free(c->ptrsm.p);
     dev_free(c->pred.p);
+    dev_free(c->psweep8.p);
     arena_put(c, c->slabP);
     for (auto& ph : c->phaseJ) {
         dev_free(ph.upd.p);
@@ -2043,7 +2058,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     HostLog hl_total("set_test");
     if (!c->plan_ready)
         if (int rc = build_plan(c)) return rc;
-    free_test(c);
+    free_test(c, true);     // the K_tn arena of the set this one replaces is kept for it (spareVt)
     const int L = c->L;
     if (route_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "route_ptr[0] must be 0");
     const int64_t total = route_ptr[L];
@@ -2103,7 +2118,17 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         HIPCHK(c, hipMemcpy(c->d_row_ent, rent.data(), rent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_ent_leaf, eleaf.data(), eleaf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    if (int rc = arena_get(c, c->arenaVt, vTot)) return rc;
+    if (c->spareVt && c->spareVt_count >= vTot && c->spareVt_count <= 2 * vTot + (size_t(1) << 20)) {
+        c->arenaVt = c->spareVt;        // big enough and not wastefully so
+        c->arenaVt_count = c->spareVt_count;
+        c->spareVt = nullptr;
+        c->spareVt_count = 0;
+    } else {
+        arena_put(c, c->spareVt);
+        c->spareVt_count = 0;
+        if (int rc = arena_get(c, c->arenaVt, vTot)) return rc;
+        c->arenaVt_count = vTot;
+    }
     if (int rc = arena_get(c, c->arenaXt, xTot)) return rc;
     if (int rc = arena_get(c, c->arenaPV, pTot)) return rc;
     // padding rows of the K_tn tiles: zero once, the Gram kernel writes data rows only (gram_half_tile)
@@ -2137,7 +2162,15 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         HIPCHK(c, hipGetLastError());
     }
     // task lists
-    std::vector<GramTask> pg;
+    // In the block steps that a fit runs fused (many leaves, or shallow: build_plan) the sweep does too: one tile_fused8_kernel
+    // launch whose tasks evaluate K_tn themselves, update and solve eight 16-row blocks of test rows each and write them once
+    // -- the routed rows of a small leaf are a fraction of a 128-row tile (44 of 128 at depth 4), which the update / panel
+    // solve launches of the other steps execute in full.  A COPY leaf goes with its source's group, as in the factorisation.
+    auto fused_at = [&](int l, int k) {
+        const std::vector<char>& fs = c->fused_step[(int)c->leaf_group[l]];
+        return gram_fused(c) && k < (int)fs.size() && fs[(size_t)k] == STEP_FUSED;
+    };
+    std::vector<GramTask> pg, pg0;  // K_tn tiles the sweep reads from memory (classic steps); those of block column 0 for the joint fit
     std::vector<PredTask> ptk, ptk_slow;
     int nsteps = 0;
     for (int l = 0; l < L; ++l) {
@@ -2149,6 +2182,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
             ptk.push_back(PredTask{l, ti * TB});
             if (!d.zfused) ptk_slow.push_back(PredTask{l, ti * TB});
             for (int j = 0; j < lf.nb; ++j) {
+                if (fused_at(l, j)) continue;       // evaluated inside the fused tasks (sweep and joint fit alike)
                 GramTask g{};
                 g.xa = d.Xtg + (size_t)ti * TB;
                 g.xb = d.Xg + (size_t)j * TB;
@@ -2162,6 +2196,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                 g.diag = 0;
                 g.kid = lf.kid;
                 pg.push_back(g);
+                if (j == 0) pg0.push_back(g);
             }
         }
     }
@@ -2172,18 +2207,51 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     U.tail_split = c->tail_split;
     U.tail_rounds = c->tail_rounds;
     std::vector<TileTask> trsm;
+    std::vector<FusedTask8> sweep8;
+    std::vector<RowBlock> blocks8;
     c->pupd_off.assign(nsteps + 1, 0);
     c->pred_off.assign(nsteps + 1, 0);
     c->ptrsm_off.assign(nsteps + 1, 0);
+    c->psweep8_off.assign(nsteps + 1, 0);
     for (int k = 0; k < nsteps; ++k) {
         c->pupd_off[k] = (int)U.upd.size();
         c->pred_off[k] = (int)U.red.size();
         c->ptrsm_off[k] = (int)trsm.size();
+        c->psweep8_off[k] = (int)sweep8.size();
         std::vector<TileTask> tiles;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
             if (lf.nt == 0 || lf.nb <= k) continue;
             const LeafDev& d = c->h_leaves[l];
+            if (fused_at(l, k)) {
+                for (int r = 0; r < lf.nt; r += 16) {
+                    RowBlock b{};
+                    b.A = d.Vt + r;
+                    b.C = d.Vt + r + (size_t)k * TB * lf.ntpad;
+                    b.gx = d.Xtg + r;
+                    b.lda = b.ldc = b.glda = lf.ntpad;
+                    b.nvalid = std::min(16, lf.nt - r);
+                    b.wi = d.macc + r;                  // predictive mean and variance ride along
+                    b.sq = d.sacc + r;
+                    blocks8.push_back(b);
+                }
+                for (size_t b0 = 0; b0 < blocks8.size(); b0 += 8) {
+                    FusedTask8 f{};
+                    f.B = d.F + (size_t)k * TB;
+                    f.Dinv = d.Dinv + (size_t)k * TB * TB;
+                    f.zk = d.z + (size_t)k * TB;
+                    f.gxb = d.Xg + (size_t)k * TB;
+                    f.ldb = f.gldb = lf.npad;
+                    f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                    f.k1 = k * TB;
+                    f.kid = lf.kid;
+                    f.nblk = (int)std::min<size_t>(8, blocks8.size() - b0);
+                    for (int q = 0; q < f.nblk; ++q) f.rb[q] = blocks8[b0 + q];
+                    sweep8.push_back(f);
+                }
+                blocks8.clear();
+                continue;
+            }
             for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
                 double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
                 if (k > 0) {
@@ -2218,10 +2286,14 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
             }
         }
         U.add_step(tiles, k * TB);
+        std::vector<int> unused(sweep8.size());         // the tasks of a leaf share its B panel and L_kk: one XCD
+        xcd_permute(sweep8, unused, (size_t)c->psweep8_off[k], sweep8.size(), c->xcd_order);
     }
     c->pupd_off[nsteps] = (int)U.upd.size();
     c->pred_off[nsteps] = (int)U.red.size();
     c->ptrsm_off[nsteps] = (int)trsm.size();
+    c->psweep8_off[nsteps] = (int)sweep8.size();
+    if (int rc = dev_upload(c, c->psweep8, sweep8)) return rc;
     if (U.max_slabs)
         if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
     U.bind(c->slabP);
@@ -2229,22 +2301,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (int rc = dev_upload(c, c->pred, U.red)) return rc;
     if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
     if (int rc = dev_upload(c, c->pgram, pg)) return rc;
-    {
-        std::vector<GramTask> pg0;      // the tasks of block column 0, in the order pg was filled above
-        size_t q = 0;
-        for (int l = 0; l < L; ++l) {
-            const LeafHost& lf = c->leaves[l];
-            if (lf.nt == 0) continue;
-            // where step 0 runs fused, the tasks of block column 0 evaluate their K_tn tile themselves.  A COPY leaf rides
-            // with its source's phase (phase 0: a source is factorised in full)
-            const std::vector<char>& fs = c->fused_step[(int)c->leaf_group[l]];
-            const bool step0_fused = gram_fused(c) && !fs.empty() && fs[0] != STEP_CLASSIC;
-            for (int ti = 0; ti < lf.ntpad / TB; ++ti)
-                for (int j = 0; j < lf.nb; ++j, ++q)
-                    if (j == 0 && !step0_fused) pg0.push_back(pg[q]);
-        }
-        if (int rc = dev_upload(c, c->pgram0, pg0)) return rc;
-    }
+    if (int rc = dev_upload(c, c->pgram0, pg0)) return rc;
     if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
     if (int rc = dev_upload(c, c->ptasks_slow, ptk_slow)) return rc;
     // The same test rows as riders of the factorisation launches (used by fit while this test set is resident).  With a device
@@ -2273,17 +2330,25 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     HIPCHK(c, ev.init());
     const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
-    if (c->pgram.count) {
+    if (c->ptasks.count) {
         const bool standalone = !c->vt_valid;
         if (standalone) {
             if (int rc = ensure_dinv(c)) return rc;       // the panel solves of the sweep multiply with Dinv_k
             HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
-            // K_tn tiles                                  (src/gaussianprocess.jl:133)
-            pt.begin(6);
-            gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
-            pt.end();
+            // K_tn tiles of the classic steps                (src/gaussianprocess.jl:133)
+            if (c->pgram.count) {
+                pt.begin(6);
+                gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
+                pt.end();
+            }
             // V^T = K_tn L^-T, block column by block column (src/gaussianprocess.jl:120)
             for (int k = 0; k < c->psteps; ++k) {
+                const int n8 = c->psweep8_off[k + 1] - c->psweep8_off[k];
+                if (n8 > 0) {
+                    pt.begin(7);
+                    tile_fused8_kernel<<<n8, 512, 0, c->stream>>>(c->psweep8.p + c->psweep8_off[k], c->d_kp, c->D);
+                    pt.end();
+                }
                 const int nu = c->pupd_off[k + 1] - c->pupd_off[k];
                 if (nu > 0) {
                     pt.begin(7);

@@ -12,7 +12,7 @@ model, X, y, Xt, ptr, idx = bench.build_model(cfg, 0, 1, 0)
 dsm.fit(model)
 dsm.update(model)
 dsm.predict(model, Xt)                                     # first use: arenas, Dinv completion
-for rep in range(3):
+for rep in range(6):
     x = np.ascontiguousarray(Xt[::-1] if rep % 2 == 0 else Xt)
     t0 = time.perf_counter(); ptree.route_recursive(model.root, x); t1 = time.perf_counter()
     ptree.route(model.root, x); t2 = time.perf_counter()
