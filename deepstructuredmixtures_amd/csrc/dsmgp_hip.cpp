@@ -796,6 +796,28 @@ double predict_update_flops(int n, int nt, Depth depth) {
 // back: needs the coordinate image of a tile to fit the kernel's LDS ring.
 bool gram_fused(const dsmgp_ctx* c) { return c->fuse_gram && c->D <= GRAM_FUSE_MAX_D; }
 
+// The 16-row blocks of one leaf below the diagonal block of step k -> fused tile tasks of eight (tile_fused8_kernel): all of
+// them read the leaf's B panel F[k, 0:K], L_kk behind it and the coordinates of the block's columns.  Empties `blocks`.
+void push_fused8_tasks(std::vector<FusedTask8>& out, std::vector<RowBlock>& blocks, const LeafDev& d, const LeafHost& lf, int k) {
+    for (size_t b0 = 0; b0 < blocks.size(); b0 += 8) {
+        FusedTask8 f{};
+        f.B = d.F + (size_t)k * TB;
+        f.Dinv = d.Dinv + (size_t)k * TB * TB;
+        f.gxb = d.Xg + (size_t)k * TB;
+        f.ldb = f.gldb = lf.npad;
+        f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+        f.k1 = k * TB;
+        f.kid = lf.kid;
+        f.nblk = (int)std::min<size_t>(8, blocks.size() - b0);
+        for (int q = 0; q < f.nblk; ++q) {
+            f.rb[q] = blocks[b0 + q];
+            if (f.rb[q].wi != nullptr) f.zk = d.z + (size_t)k * TB;     // riders read z_k
+        }
+        out.push_back(f);
+    }
+    blocks.clear();
+}
+
 // Step lists of the batched left-looking factorisation.  phase[0]: leaves factorised in full (and, with
 // `with_test`, the test rows of those leaves and of the COPY leaves that alias them); phase[1]: PREFIX leaves.
 // with_test: the rows of K_tn (Vt) of every leaf are appended below its factor and advance through the same
@@ -1047,25 +1069,9 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                         trsm.push_back(s);
                     }
                 }
-                // eight-wave fused tile tasks: the leaf's 16-row blocks of this step, eight to a task (the last factor rows and
-                // the test rows share tasks; all of them read the same B panel, L_kk and column coordinates)
-                for (size_t b0 = 0; b0 < blocks8.size(); b0 += 8) {
-                    FusedTask8 f{};
-                    f.B = d.F + (size_t)k * TB;
-                    f.Dinv = d.Dinv + (size_t)k * TB * TB;
-                    f.gxb = d.Xg + (size_t)k * TB;
-                    f.ldb = f.gldb = ld;
-                    f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
-                    f.k1 = k * TB;
-                    f.kid = lf.kid;
-                    f.nblk = (int)std::min<size_t>(8, blocks8.size() - b0);
-                    for (int q = 0; q < f.nblk; ++q) {
-                        f.rb[q] = blocks8[b0 + q];
-                        if (f.rb[q].wi != nullptr) f.zk = d.z + (size_t)k * TB;
-                    }
-                    ftile8.push_back(f);
-                }
-                blocks8.clear();
+                // fused tile tasks: the leaf's 16-row blocks of this step, eight to a task (the last factor rows and the test
+                // rows share tasks)
+                push_fused8_tasks(ftile8, blocks8, d, lf, k);
             }
             // The lower-blocks-only form of a diagonal tile takes ~0.6 of a full tile (tools/bench_tile_sym.py).  It pays
             // where diagonal tiles are a large share of a launch (many small leaves: -6 % on the update launches of the
@@ -1280,7 +1286,10 @@ int build_plan(dsmgp_ctx* c) {
         }
         if (int rc = dev_upload(c, zrows, zr)) return rc;
         if (!zr.empty()) zero_pad_rows_kernel<<<(int)zr.size(), 256, 0, c->stream>>>(zrows.p);
-        HIPCHK(c, hipGetLastError());
+        const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
+        dev_free(zrows.p);          // before anything below can return
+        HIPCHK(c, e1);
+        HIPCHK(c, e2);
     }
 
     // Phases: PREFIX leaves run after their sources (phase 1), everything else in phase 0 (COPY leaves ride with their source).
@@ -1455,7 +1464,6 @@ int build_plan(dsmgp_ctx* c) {
         if (int rc = dev_upload(c, c->bwd, bwd)) return rc;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    dev_free(zrows.p);
     c->plan_ready = true;
     c->pool_mark_plan = c->pool_top;
     return 0;
@@ -2235,21 +2243,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                     b.sq = d.sacc + r;
                     blocks8.push_back(b);
                 }
-                for (size_t b0 = 0; b0 < blocks8.size(); b0 += 8) {
-                    FusedTask8 f{};
-                    f.B = d.F + (size_t)k * TB;
-                    f.Dinv = d.Dinv + (size_t)k * TB * TB;
-                    f.zk = d.z + (size_t)k * TB;
-                    f.gxb = d.Xg + (size_t)k * TB;
-                    f.ldb = f.gldb = lf.npad;
-                    f.gnb = std::max(0, std::min(TB, lf.n - k * TB));
-                    f.k1 = k * TB;
-                    f.kid = lf.kid;
-                    f.nblk = (int)std::min<size_t>(8, blocks8.size() - b0);
-                    for (int q = 0; q < f.nblk; ++q) f.rb[q] = blocks8[b0 + q];
-                    sweep8.push_back(f);
-                }
-                blocks8.clear();
+                push_fused8_tasks(sweep8, blocks8, d, lf, k);
                 continue;
             }
             for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
