@@ -438,7 +438,7 @@ struct dsmgp_ctx {
     double* arenaPV = nullptr;      // mu | var (route order, unpadded) | macc | sacc (padded accumulators of the sweep)
     size_t acc_off = 0, acc_count = 0;
     DevBuf<PredTask> ptasks_slow;   // test tiles of leaves whose z is not produced during the factorisation
-    DevBuf<GramTask> pgram;         // K_tn tiles of the standalone sweep (all of them)
+    DevBuf<GramTask> pgram;         // K_tn tiles the standalone sweep reads from memory (all of them only when D > 32)
     DevBuf<GramTask> pgram0;        // ... of the joint fit when the Gram is fused: block column 0 only
     DevBuf<PredTask> ptasks;
     std::vector<int> pupd_off, pred_off, ptrsm_off;
@@ -2178,7 +2178,8 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         const std::vector<char>& fs = c->fused_step[(int)c->leaf_group[l]];
         return gram_fused(c) && k < (int)fs.size() && fs[(size_t)k] == STEP_FUSED;
     };
-    std::vector<GramTask> pg, pg0;  // K_tn tiles the sweep reads from memory (classic steps); those of block column 0 for the joint fit
+    std::vector<GramTask> pg, pg0;  // K_tn tiles the sweep reads from memory (block column 0 of the classic steps; every column where the
+                                    // update tasks cannot evaluate them: D > 32); those of block column 0 for the joint fit
     std::vector<PredTask> ptk, ptk_slow;
     int nsteps = 0;
     for (int l = 0; l < L; ++l) {
@@ -2191,6 +2192,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
             if (!d.zfused) ptk_slow.push_back(PredTask{l, ti * TB});
             for (int j = 0; j < lf.nb; ++j) {
                 if (fused_at(l, j)) continue;       // evaluated inside the fused tasks (sweep and joint fit alike)
+                if (j > 0 && gram_fused(c)) continue;   // ... and inside the update tasks of the classic steps (TileTask.gram)
                 GramTask g{};
                 g.xa = d.Xtg + (size_t)ti * TB;
                 g.xb = d.Xg + (size_t)j * TB;
@@ -2260,6 +2262,16 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
                     u.k1 = k * TB;
                     u.update = 1;
                     u.mrows = tile_mrows(lf.nt - ti * TB);
+                    if (gram_fused(c)) {    // the task evaluates its K_tn tile itself, as in the joint fit: only block column 0 of
+                        u.gram = 1;         // K_tn ever exists in memory
+                        u.kid = lf.kid;
+                        u.gxa = d.Xtg + (size_t)ti * TB;
+                        u.gxb = d.Xg + (size_t)k * TB;
+                        u.glda = lf.ntpad;
+                        u.gldb = lf.npad;
+                        u.gna = std::max(0, std::min(TB, lf.nt - ti * TB));
+                        u.gnb = std::max(0, std::min(TB, lf.n - k * TB));
+                    }
                     tiles.push_back(u);
                 }
                 TileTask s{};
