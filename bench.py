@@ -3,6 +3,8 @@
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: starts its own N ranks under torch.distributed.run as a child process,
+                                         before anything in this process touches the GPU, and exits with the child's code)
 
 Workload (BASELINE.json configs[3], fits one GPU): buildDSMGP K=4 splits, V=3 sum children, M=200,
 N=100k, D=8, IsoSE, tree depth 2 (reference default) -> 144 leaf GPs, n ~ 1.5k-14k; n_t = N/10 test rows.
@@ -277,6 +279,80 @@ def bench_train(args, model, X, y, rank, world, td, torch):
         td.destroy_process_group()
 
 
+def spread(v):
+    """{min, median, max} of a series of per-step values."""
+    v = np.asarray(list(v), dtype=np.float64)
+    return {"min": float(v.min()), "median": float(np.median(v)), "max": float(v.max())} if v.size else None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, as
+    `python -m torch.distributed.run ... bench.py <same arguments>` in a child process, and exit with its code.  Decided before
+    this process imports torch or makes any GPU call (it never does: a process that has initialised the GPU must not exec or be
+    the parent of the job's device work); rank 0 of the child prints the JSON line on the stdout we hand down."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver supports dmabuf IPC only (RCCL between processes)
+    print(f"# bench.py --gpus {args.gpus} without a launcher: starting {args.gpus} ranks under torch.distributed.run "
+          f"(127.0.0.1:{port})", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def init_distributed(rank, world, local_rank, torch):
+    """Process group of an N > 1 run -> (torch.distributed, backend in use, local device index).
+
+    RCCL ("nccl") is what the run is meant to use; whether it comes up is a verdict the ranks must AGREE on before any of them
+    depends on it (round-4 advisor: decided per rank inside try/except, a partial failure left some ranks in nccl and the
+    others in gloo until the 300 s timeout).  So: (1) a gloo group first -- it exists on every rank whatever the GPUs do;
+    (2) every rank tries a nccl group beside it and proves it with one all-reduce; (3) the verdicts are MIN- and MAX-reduced
+    over gloo.  All yes: the default group is re-created as nccl.  All no (fewer GPUs than ranks, an IPC or driver problem:
+    the same everywhere): the run completes over gloo and its line says so (exchange_backend).  Mixed: every rank exits 3."""
+    import datetime
+    import torch.distributed as td
+    ndev = torch.cuda.device_count()
+    want = os.environ.get("DSMGP_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on one GPU
+    local_rank = local_rank % max(1, ndev)
+    torch.cuda.set_device(local_rank)
+    td.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    if want != "nccl":
+        return td, "gloo", local_rank
+    ok, why = 1, ""
+    if ndev < world:                                          # the same on every rank of the node: nobody opens a nccl group
+        ok, why = 0, f"{world} ranks need {world} GPUs, {ndev} visible"
+    else:
+        try:
+            g = td.new_group(backend="nccl", timeout=datetime.timedelta(seconds=90))
+            probe = torch.ones(1, device="cuda")
+            td.all_reduce(probe, group=g)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"RCCL all-reduce of ones over {world} ranks gave {probe.item()}")
+        except Exception as e:      # noqa: BLE001
+            ok, why = 0, str(e)
+    lo = torch.tensor([ok], dtype=torch.int32)
+    hi = torch.tensor([ok], dtype=torch.int32)
+    td.all_reduce(lo, op=td.ReduceOp.MIN)
+    td.all_reduce(hi, op=td.ReduceOp.MAX)
+    if int(lo.item()) != int(hi.item()):
+        print(f"# rank {rank}: the ranks disagree on RCCL (here: {'ok' if ok else why}); giving up on every rank", file=sys.stderr, flush=True)
+        os._exit(3)                                           # no destructor may wait for a half-built communicator
+    if int(lo.item()) == 0:
+        print(f"# rank {rank}: RCCL process group not usable ({why}); falling back to gloo for the exchange", file=sys.stderr)
+        return td, "gloo", local_rank
+    td.barrier()
+    td.destroy_process_group()
+    td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                          timeout=datetime.timedelta(seconds=300))
+    return td, "nccl", local_rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,45 +379,18 @@ def main():
                          "not a valid bench line)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and not args.simulate_shard:
+        self_launch(args)                       # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     import torch
     td = None
     exchange_backend = None
     if world > 1:
-        import datetime
-        import torch.distributed as td
-        ndev = torch.cuda.device_count()
-        backend = os.environ.get("DSMGP_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on one GPU
-        local_rank = local_rank % max(1, ndev)
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            # RCCL, proven by one tiny all-reduce before anything depends on it.  A node on which it does not come up (fewer
-            # GPUs than ranks, an IPC or driver problem: the same on every rank) still gets its run: the two small all-gathers
-            # of a step then travel over gloo, and the line says so (config.exchange).
-            try:
-                if ndev < world:
-                    raise RuntimeError(f"{world} ranks need {world} GPUs, {ndev} visible")
-                td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                      timeout=datetime.timedelta(seconds=300))
-                probe = torch.ones(1, device="cuda")
-                td.all_reduce(probe)
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"RCCL all-reduce of ones over {world} ranks gave {probe.item()}")
-            except Exception as e:      # noqa: BLE001
-                print(f"# rank {rank}: RCCL process group not usable ({e}); falling back to gloo for the exchange", file=sys.stderr)
-                try:
-                    if td.is_initialized():
-                        td.destroy_process_group()
-                except Exception:       # noqa: BLE001
-                    pass
-                backend = "gloo"
-        if backend != "nccl":
-            td.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-        exchange_backend = backend
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        td, exchange_backend, local_rank = init_distributed(rank, world, local_rank, torch)
 
     import deepstructuredmixtures_amd as dsm
     if args.simulate_shard:
@@ -427,22 +476,48 @@ def main():
         root[0] = dsm.update(model)
         return dsm.predict(model, Xt)
 
+    # f64-MFMA probe (register-only loop over the whole chip; also reports the shader clock it held) BEFORE warm-up and
+    # IMMEDIATELY AFTER the timed loop: with the clock sampled inside the steps it tells box from code when two runs differ
+    can_probe = hasattr(ctx, "probe_f64_mfma_detail") and not args.simulate_shard
+    probe_before = ctx.probe_f64_mfma_detail(8) if can_probe else None
+    t_warm = 0.1
     for _ in range(args.warmup):
+        tw = time.perf_counter()
         step()
+        t_warm = time.perf_counter() - tw
     sync_all()
+    # shader clock held INSIDE the steps: a one-wave kernel on a stream of its own sleeps through the first 80 % of a step (its
+    # update launches) and counts shader cycles per wall tick -- first and last five steps (dsmgp_clock_sample_*)
+    can_clock = hasattr(ctx, "clock_sample_start") and not args.no_profile
+    clock_ms = min(4000.0, max(1.0, 800.0 * t_warm))
     t0 = time.perf_counter()
-    upd_s, upd_launches, fused_launches, fit_s, pred_s = 0.0, 0, 0, 0.0, 0.0
+    upd_launches, fused_launches = 0, 0
     cats = {}
-    for _ in range(args.steps):
+    step_wall, step_upd, step_fused, step_fit_dev, step_pred_dev, step_clock = [], [], [], [], [], []
+    xs0, xn0 = model.shard.exchange_seconds, model.shard.exchanges
+    for i in range(args.steps):
+        sample = can_clock and (i < 5 or i >= args.steps - 5)
+        if sample:
+            ctx.clock_sample_start(clock_ms)
+        ts = time.perf_counter()
         mu, var = step()
+        step_wall.append(time.perf_counter() - ts)
         tm = ctx.timings()
         for k, v in tm.items():
             cats[k] = cats.get(k, 0.0) + v
+        step_upd.append(tm.get("chol_update", 0.0))
+        step_fused.append(tm.get("chol_fused", 0.0))
+        step_fit_dev.append(tm.get("total_fit", 0.0))
+        step_pred_dev.append(tm.get("total_predict", 0.0))
         fl, nl = ctx.work()
         upd_launches += nl
         fused_launches += ctx.work_fused()[1]
+        if sample:
+            step_clock.append(ctx.clock_sample_read()[0])
     sync_all()
     elapsed = time.perf_counter() - t0
+    probe_after = ctx.probe_f64_mfma_detail(8) if can_probe else None
+    xs1, xn1 = model.shard.exchange_seconds, model.shard.exchanges
     if not args.no_profile:   # one more, untimed, step with every category timed: the breakdown printed below
         timed = dict(cats)
         ctx.set_profile(2)
@@ -457,6 +532,16 @@ def main():
         elapsed = float(tmax.item())
     per_step = elapsed / args.steps
     assert args.simulate_shard or (np.all(np.isfinite(mu)) and np.all(var > 0))
+    ranks_info = None
+    if td is not None:          # what every rank did: an N-GPU line explains its own efficiency
+        n3 = np.array([lf.nobs for lf in model.leaves], dtype=np.float64) ** 3
+        loc = model.shard.local
+        mine = {"rank": rank, "n_leaves": int(len(loc)), "cholesky_flop_share": float(n3[loc].sum() / n3.sum()),
+                "largest_leaf": int(max([model.leaves[j].nobs for j in loc], default=0)),
+                "step_s": spread(step_wall), "fit_device_s": spread(step_fit_dev), "predict_device_s": spread(step_pred_dev),
+                "exchange_s_per_step": (xs1 - xs0) / args.steps, "exchanges_per_step": (xn1 - xn0) / args.steps}
+        ranks_info = [None] * world
+        td.all_gather_object(ranks_info, mine)
 
     # roofline of the dominant kernel on this rank: the f64-MFMA update launches (tile_gemm_kernel_v2) -- or, where the fused
     # block steps dominate (many small leaves), the fused tile launches (tile_fused8_kernel: update + solve)
@@ -496,11 +581,21 @@ def main():
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kname, "avg_launch_ms": avg_launch * 1e3, "launches_per_step": n_l // args.steps,
                 "alg_flops_per_step": fl_step}
+        if probe_after is not None:
+            # the same kernel against what THIS chip's matrix pipe delivered right after the timed loop (register-only f64 MFMA
+            # loop, 8 waves per SIMD), and the peak rescaled to the shader clock held inside the steps: 78.6 TFLOP/s is
+            # 256 CUs x 4 SIMDs x 32 flop per cycle at 2.4 GHz
+            roof["frac_of_probe"] = achieved / probe_after["tflops"]
+            if step_clock:
+                ghz = float(np.median(step_clock))
+                roof["clock_ghz_in_steps"] = ghz
+                roof["frac_at_held_clock"] = achieved / (F64_MATRIX_PEAK_TFLOPS * ghz / 2.4)
     nobs = np.array([lf.nobs for lf in model.leaves], dtype=np.float64)
     matrix_flops_total = float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2 * np.diff(ptr)))   # Cholesky + predict solves
 
-    # The drop-in call pattern of src/common.jl:304 -- fit! on a model that has never seen the test set, then
-    # predict(model, x) -- next to the joint step above (untimed extra; one GPU only).
+    # The drop-in call pattern of src/common.jl:304 -- fit!(model) + update!(model) on a model whose fit does not know the test
+    # set, then predict(model, x) running its own sweep -- as a second TIMED SERIES of the same --steps (one GPU only; the
+    # step above registers its test set before the first fit, dsm.resident_test, which has no reference counterpart).
     standalone = None
     if world == 1 and not args.simulate_shard and not CONFIGS[args.config].get("stream"):
         ctx.set_profile(0)      # also renames the update kernel's instantiation: these launches stay out of the profiler's
@@ -508,24 +603,35 @@ def main():
         ctx.set_joint(False)
         dsm.fit(model)          # untimed: the step lists of a fit without test rows are built on first use
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dsm.fit(model)
-        dsm.update(model)
-        t1 = time.perf_counter()
-        mu_s, var_s = dsm.predict(model, Xt)
-        t2 = time.perf_counter()
+        d_fit, d_pred, d_step = [], [], []
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            dsm.fit(model)
+            dsm.update(model)
+            t1 = time.perf_counter()
+            mu_s, var_s = dsm.predict(model, Xt)
+            t2 = time.perf_counter()
+            d_fit.append(t1 - t0)
+            d_pred.append(t2 - t1)
+            d_step.append(t2 - t0)
         assert np.allclose(mu_s, mu, rtol=1e-9, atol=1e-11) and np.allclose(var_s, var, rtol=1e-8, atol=1e-12)
-        # ... and predict on rows the model has not seen (the same rows in reverse order: a new matrix to route, register and
-        # sweep; the answers must be the old ones reversed)
+        # ... and predict on rows the model has not seen (the same rows in reverse order, then forward again, ...: every call a
+        # new matrix to route, register and sweep; the answers must be the old ones, reversed where the rows were)
         Xt2 = np.ascontiguousarray(Xt[::-1])
-        t3 = time.perf_counter()
-        mu_n, var_n = dsm.predict(model, Xt2)
-        t4 = time.perf_counter()
+        d_new = []
+        for q in range(max(2, min(args.steps, 6))):
+            xq = Xt2 if q % 2 == 0 else Xt
+            t3 = time.perf_counter()
+            mu_n, var_n = dsm.predict(model, xq)
+            d_new.append(time.perf_counter() - t3)
+            if q % 2 == 0:
+                mu_n, var_n = mu_n[::-1], var_n[::-1]
+            assert np.allclose(mu_n, mu, rtol=1e-9, atol=1e-11) and np.allclose(var_n, var, rtol=1e-8, atol=1e-12)
         ctx.set_joint(True)
-        assert np.allclose(mu_n[::-1], mu, rtol=1e-9, atol=1e-11) and np.allclose(var_n[::-1], var, rtol=1e-8, atol=1e-12)
-        standalone = {"fit_s": t1 - t0, "predict_s": t2 - t1, "predict_new_rows_s": t4 - t3,
-                      "note": "fit! + update! without a resident test set, then predict(model, Xt) running its own sweep; "
-                              "predict_new_rows: predict(model, x) on a test matrix the model has not seen (routing, registration, sweep)"}
+        standalone = {"fit_s": spread(d_fit), "predict_s": spread(d_pred), "step_s": spread(d_step), "predict_new_rows_s": spread(d_new),
+                      "note": f"{args.steps} timed repetitions of fit! + update! WITHOUT a resident test set, then predict(model, Xt) "
+                              "running its own sweep (the reference's call pattern, src/common.jl:304); predict_new_rows: "
+                              "predict(model, x) on a test matrix the model has not seen (routing, registration, sweep)"}
 
     if rank == 0:
         c = CONFIGS[args.config]
@@ -551,22 +657,33 @@ def main():
             "root_mll": root[0],
             "model_build_s": model.build_seconds,
         }
+        out["step_s"] = spread(step_wall)                   # per-step wall seconds of the timed region (value = their mean + syncs)
+        if not args.no_profile:
+            key = step_fused if fused_dominant else step_upd
+            out["dominant_launches_s_first5"] = [round(v, 6) for v in key[:5]]      # per step: device seconds of the roofline
+            out["dominant_launches_s_last5"] = [round(v, 6) for v in key[-5:]]      # kernel's launches (sustained-load droop)
+        if step_clock:
+            out["shader_clock_ghz_in_steps"] = {"first5": [round(v, 4) for v in step_clock[:min(5, args.steps)]],
+                                                "last5": [round(v, 4) for v in step_clock[-min(5, args.steps):]],
+                                                "sample_ms": clock_ms}
+        if probe_before is not None:
+            out["f64_mfma_probe"] = {"before_warmup": probe_before, "after_timed_loop": probe_after,
+                                     "note": "register-only v_mfma_f64_16x16x4 loop, 8 waves per SIMD, whole chip; clock_ghz = "
+                                             "shader clock held in the probe loop"}
         if world > 1:
             out["exchange_backend"] = exchange_backend      # "nccl" (= RCCL); "gloo" only if RCCL did not come up on this node
+            out["ranks"] = ranks_info
         if standalone is not None:
-            out["standalone_fit_s"] = standalone["fit_s"]
-            out["standalone_predict_s"] = standalone["predict_s"]
-            out["standalone_predict_new_rows_s"] = standalone["predict_new_rows_s"]
-            out["standalone_note"] = standalone["note"]
+            out["drop_in_s"] = standalone["step_s"]
+            out["standalone_fit_s"] = standalone["fit_s"]["median"]
+            out["standalone_predict_s"] = standalone["predict_s"]["median"]
+            out["standalone_predict_new_rows_s"] = standalone["predict_new_rows_s"]["median"]
+            out["drop_in"] = standalone
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, X, y, Xt, ptr, idx)
             out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / per_step
-        try:
-            out["f64_mfma_probe_tflops"] = ctx.probe_f64_mfma()
-        except Exception:
-            pass
         print(json.dumps(out))
     if td is not None:
         td.barrier()

@@ -97,9 +97,6 @@ struct StepLists {
     // there has no `diag` task in that step
     std::vector<int> dpos, dfin_off;                         // size nsteps / nsteps+1
     DevBuf<DiagFinishTask> dfin;
-    // the diagonal blocks of the fused steps: factorised WITHOUT their inverse (only L_kk and the 16x16 diagonal inverses exist
-    // after a fit); dinv_complete_kernel over this list produces the rest of Dinv_k for whoever needs it (ensure_dinv)
-    DevBuf<DiagTask> dinvc;
     int nsteps = 0;
 };
 
@@ -424,6 +421,10 @@ struct dsmgp_ctx {
     DevBuf<DiagTask> dinvc_prefix;  // copied blocks of PREFIX leaves whose source factorised them in a fused step: completed right
                                     // after the copy (the classic steps of the PREFIX phase solve against Dinv_k)
     DevBuf<DiagTask> dinvc_fwd;     // blocks of the leaves whose z comes from the forward sweep (COPY, PREFIX): completed before it
+    DevBuf<DiagTask> dinvc_all;     // every diagonal block a fused step factorises WITHOUT its inverse (only L_kk and the 16x16 diagonal
+                                    // inverses exist after a fit): dinv_complete_kernel over this list produces the rest of Dinv_k for
+                                    // whoever needs it (ensure_dinv).  Owned by the PLAN -- the list is the same with and without test
+                                    // rows riding along, and must outlive a test set that is replaced between a fit and its first use
 
     // prediction
     double* dXt = nullptr;
@@ -491,6 +492,9 @@ struct dsmgp_ctx {
     int comm_rank = 0, comm_world = 1;
     double* d_xchg = nullptr;       // send | recv staging
     size_t xchg_cap = 0;
+    hipStream_t side = nullptr;     // clock sampler (dsmgp_clock_sample_*): a one-wave kernel beside the context's own launches
+    unsigned long long* d_clock = nullptr;
+    bool clock_pending = false;
     double timings[DSMGP_N_TIMINGS] = {0};
     std::vector<hipEvent_t> event_pool;   // PhaseTimer's events, reused across calls
     double alg_flops_update = 0.0;  // algorithmic flops of the Cholesky update launches
@@ -535,6 +539,11 @@ void dev_free(T*& p) {
     if (p) (void)hipFree(p);
     p = nullptr;
 }
+template <class T>
+void dev_free(DevBuf<T>& b) {      // a freed list is an EMPTY list: nobody may launch over its old count
+    dev_free(b.p);
+    b.count = 0;
+}
 
 bool in_pool(const dsmgp_ctx* c, const void* p) {
     return c->pool_base && (const char*)p >= c->pool_base && (const char*)p < c->pool_base + c->pool_cap;
@@ -569,12 +578,12 @@ void drop_graphs(dsmgp_ctx* c) {
 
 // the task lists of the gradient pass (they depend on the set of active leaves); the L^-T arena stays
 void free_grad_lists(dsmgp_ctx* c) {
-    dev_free(c->gtrans.p);
-    dev_free(c->gupd.p);
-    dev_free(c->gtrsm.p);
-    dev_free(c->gred.p);
-    dev_free(c->gfrob.p);
-    dev_free(c->gdot.p);
+    dev_free(c->gtrans);
+    dev_free(c->gupd);
+    dev_free(c->gtrsm);
+    dev_free(c->gred);
+    dev_free(c->gfrob);
+    dev_free(c->gdot);
     dev_free(c->d_gpart);
     c->grad_ready = false;
 }
@@ -583,12 +592,12 @@ void free_grad(dsmgp_ctx* c) {
     arena_put(c, c->slabG);
     c->slabG_count = 0;
     arena_put(c, c->arenaX);
-    dev_free(c->gtrans.p);
-    dev_free(c->gupd.p);
-    dev_free(c->gtrsm.p);
-    dev_free(c->gred.p);
-    dev_free(c->gfrob.p);
-    dev_free(c->gdot.p);
+    dev_free(c->gtrans);
+    dev_free(c->gupd);
+    dev_free(c->gtrsm);
+    dev_free(c->gred);
+    dev_free(c->gfrob);
+    dev_free(c->gdot);
     dev_free(c->d_gpart);
     c->grad_ready = false;
 }
@@ -609,22 +618,22 @@ void free_plan(dsmgp_ctx* c) {
     dev_free(c->d_owner);
     dev_free(c->d_mll);
     dev_free(c->d_leaves);
-    dev_free(c->gram.p);
+    dev_free(c->gram);
     for (auto& ph : c->phase) {
-        dev_free(ph.upd.p);
-        dev_free(ph.trsm.p);
-        dev_free(ph.red.p);
-        dev_free(ph.diag.p);
-        dev_free(ph.fdiag.p);
-        dev_free(ph.ftile8.p);
-        dev_free(ph.dfin.p);
-        dev_free(ph.dinvc.p);
+        dev_free(ph.upd);
+        dev_free(ph.trsm);
+        dev_free(ph.red);
+        dev_free(ph.diag);
+        dev_free(ph.fdiag);
+        dev_free(ph.ftile8);
+        dev_free(ph.dfin);
     }
     arena_put(c, c->slabF);
-    dev_free(c->fwd.p);
-    dev_free(c->bwd.p);
-    dev_free(c->dinvc_prefix.p);
-    dev_free(c->dinvc_fwd.p);
+    dev_free(c->fwd);
+    dev_free(c->bwd);
+    dev_free(c->dinvc_prefix);
+    dev_free(c->dinvc_fwd);
+    dev_free(c->dinvc_all);
     free_grad(c);
     c->plan_ready = false;
     c->phase_ready = false;
@@ -662,25 +671,24 @@ void free_test(dsmgp_ctx* c, bool keep_vt) {
     c->arenaVt_count = 0;
     arena_put(c, c->arenaXt);
     arena_put(c, c->arenaPV);
-    dev_free(c->pgram.p);
-    dev_free(c->pgram0.p);
+    dev_free(c->pgram);
+    dev_free(c->pgram0);
     c->pgram0 = DevBuf<GramTask>{};
-    dev_free(c->ptasks.p);
-    dev_free(c->ptasks_slow.p);
-    dev_free(c->pupd.p);
-    dev_free(c->ptrsm.p);
-    dev_free(c->pred.p);
-    dev_free(c->psweep8.p);
+    dev_free(c->ptasks);
+    dev_free(c->ptasks_slow);
+    dev_free(c->pupd);
+    dev_free(c->ptrsm);
+    dev_free(c->pred);
+    dev_free(c->psweep8);
     arena_put(c, c->slabP);
     for (auto& ph : c->phaseJ) {
-        dev_free(ph.upd.p);
-        dev_free(ph.trsm.p);
-        dev_free(ph.red.p);
-        dev_free(ph.diag.p);
-        dev_free(ph.fdiag.p);
-        dev_free(ph.ftile8.p);
-        dev_free(ph.dfin.p);
-        dev_free(ph.dinvc.p);
+        dev_free(ph.upd);
+        dev_free(ph.trsm);
+        dev_free(ph.red);
+        dev_free(ph.diag);
+        dev_free(ph.fdiag);
+        dev_free(ph.ftile8);
+        dev_free(ph.dfin);
     }
     arena_put(c, c->slabJ);
     c->joint_ready = false;
@@ -850,7 +858,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         std::vector<RowBlock> blocks8;      // 16-row blocks of one leaf below the step's diagonal block: factor rows, then test rows
         std::vector<DiagFusedTask> fdiag;
         std::vector<DiagFinishTask> dfin;
-        std::vector<DiagTask> dinvc;
         S.dpos.assign(nsteps, 0);
         S.dfin_off.assign(nsteps + 1, 0);
         S.upd_off.assign(nsteps + 1, 0);
@@ -995,7 +1002,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
                             fg.glda = ld;
                             fg.kid = lf.kid;
                             fdiag.push_back(fg);
-                            dinvc.push_back(g);
                         } else if (fin) {
                             DiagFinishTask ft{};
                             ft.d = g;
@@ -1123,7 +1129,6 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         S.ftile8_off[nsteps] = (int)ftile8.size();
         S.dfin_off[nsteps] = (int)dfin.size();
         if (int rc = dev_upload(c, S.dfin, dfin)) return rc;
-        if (int rc = dev_upload(c, S.dinvc, dinvc)) return rc;
         if (int rc = dev_upload(c, S.trsm, trsm)) return rc;
         if (int rc = dev_upload(c, S.diag, diag)) return rc;
         if (int rc = dev_upload(c, S.fdiag, fdiag)) return rc;
@@ -1287,7 +1292,7 @@ int build_plan(dsmgp_ctx* c) {
         if (int rc = dev_upload(c, zrows, zr)) return rc;
         if (!zr.empty()) zero_pad_rows_kernel<<<(int)zr.size(), 256, 0, c->stream>>>(zrows.p);
         const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
-        dev_free(zrows.p);          // before anything below can return
+        dev_free(zrows);          // before anything below can return
         HIPCHK(c, e1);
         HIPCHK(c, e2);
     }
@@ -1385,6 +1390,16 @@ int build_plan(dsmgp_ctx* c) {
         }
         if (int rc = dev_upload(c, c->dinvc_prefix, pre)) return rc;
         if (int rc = dev_upload(c, c->dinvc_fwd, fw)) return rc;
+        // ... and on first use after it (ensure_dinv): every block an owner's fused step factorises (the copied blocks of a
+        // PREFIX leaf are in `pre`: completed inside every fit)
+        std::vector<DiagTask> all;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.owner != l) continue;
+            for (int k = lf.kb; k < lf.nb; ++k)
+                if (fused_in((int)c->leaf_group[l], k)) all.push_back(block_task(l, k));
+        }
+        if (int rc = dev_upload(c, c->dinvc_all, all)) return rc;
     }
     // The step lists of the factorisation are built on first use: those for the train rows alone by the first fit! without a
     // resident test set (ensure_phase), those with the test rows riding along by dsmgp_set_test -- a context that only ever
@@ -1632,10 +1647,8 @@ int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
 // standalone prediction sweep, the gradients and the sweeps for alpha multiply with.  Queued on the context's stream.
 int ensure_dinv(dsmgp_ctx* c) {
     if (c->dinv_complete) return 0;
-    StepLists* phases = c->last_fit_joint ? c->phaseJ : c->phase;
-    for (int ph = 0; ph < 2; ++ph)
-        if (phases[ph].dinvc.count)
-            dinv_complete_kernel<<<(int)phases[ph].dinvc.count, 256, DIAGP_LDS_BYTES, c->stream>>>(phases[ph].dinvc.p);
+    if (c->dinvc_all.count)
+        dinv_complete_kernel<<<(int)c->dinvc_all.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_all.p);
     HIPCHK(c, hipGetLastError());
     c->dinv_complete = true;
     return 0;
@@ -1720,6 +1733,11 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->d_l2);
     (void)dsmgp_comm_destroy(c);
     drop_graphs(c);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    dev_free(c->d_clock);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2053,7 +2071,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     c->predicted = false;
     c->vt_valid = joint;
     c->last_fit_joint = joint;
-    c->dinv_complete = phases[0].dinvc.count == 0 && phases[1].dinvc.count == 0;
+    c->dinv_complete = c->dinvc_all.count == 0;
     return 0;
 }
 
@@ -2917,7 +2935,7 @@ int dsmgp_kernel_matrix(dsmgp_ctx* c, int32_t kernel_id, const double* x1, int64
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(K_out, (size_t)n1 * sizeof(double), dK, (size_t)p1 * sizeof(double), (size_t)n1 * sizeof(double),
                           (size_t)n2, hipMemcpyDeviceToHost));
-    dev_free(dg.p);
+    dev_free(dg);
     dev_free(dx1);
     dev_free(dx2);
     dev_free(dK);
@@ -3085,6 +3103,34 @@ int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* c, int32_t blocks_per_cu, double* out
     return 0;
 }
 
+// Shader clock held under load: a one-wave kernel on a stream of its own that sleeps for `milliseconds` of wall time beside
+// whatever the context launches meanwhile and reports shader cycles per wall tick.  start returns at once; read waits for it.
+int dsmgp_clock_sample_start(dsmgp_ctx* c, double milliseconds) {
+    if (!c) return DSMGP_E_ARG;
+    if (!(milliseconds > 0.0) || milliseconds > 5000.0) return fail(c, DSMGP_E_ARG, "clock_sample_start: 0 < milliseconds <= 5000");
+    if (c->clock_pending) return fail(c, DSMGP_E_STATE, "clock_sample_start: a sample is already running (read it first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->side) HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    if (!c->d_clock) HIPCHK(c, hipMalloc(&c->d_clock, 2 * sizeof(unsigned long long)));
+    clock_sample_kernel<<<1, 64, 0, c->side>>>(c->d_clock, (unsigned long long)(milliseconds * 1e5));   // 100 MHz ticks
+    HIPCHK(c, hipGetLastError());
+    c->clock_pending = true;
+    return 0;
+}
+
+int dsmgp_clock_sample_read(dsmgp_ctx* c, double* ghz, double* milliseconds) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->clock_pending) return fail(c, DSMGP_E_STATE, "clock_sample_read before clock_sample_start");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->side));
+    c->clock_pending = false;
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(h, c->d_clock, sizeof(h), hipMemcpyDeviceToHost));
+    if (ghz) *ghz = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;      // cycles per 10 ns tick / 10 = GHz
+    if (milliseconds) *milliseconds = (double)h[1] * 1e-5;
+    return 0;
+}
+
 #ifdef DSMGP_DIAG
 // ---- diagnostic build only (libdsmgp_hip_diag.so, include/dsmgp_hip_diag.h): never part of the product library ----
 // Diagnostic: f64 MFMA and f64 VALU FMA alone and co-issued (two waves per SIMD).  out[3*mode + {0,1,2}] =
@@ -3207,7 +3253,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
-    dev_free(dr.p);
+    dev_free(dr);
     dev_free(slabs);
     *seconds_per_launch = ms * 1e-3 / reps;
     if (std::getenv("DSMGP_STAMPS")) {
@@ -3241,7 +3287,7 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
                      tot / loop / 10.0, (double)(last - first) * 0.01,
                      (pro + loop + epi) / ((double)(last - first) * std::min<double>(2.0 * c->ncu * 4.0, nw)));
     }
-    dev_free(dt.p);
+    dev_free(dt);
     dev_free(A);
     dev_free(B);
     dev_free(C);

@@ -538,7 +538,8 @@ struct Router {
         for (int64_t i = 0; i < n; ++i) {
             const double v = x[rows[i] * rs + d * cs];
             int64_t k = 0;
-            while (k < nc && th[k] < v) ++k;          // first k with v <= s_k (np.searchsorted(th, v, side = "left"))
+            while (k < nc && !(v <= th[k])) ++k;      // first k with v <= s_k (np.searchsorted(th, v, side = "left")); a NaN
+                                                      // coordinate satisfies no threshold: outside, as the recursion raises
             if (k >= nc) {
                 outside = true;
                 return;
@@ -556,9 +557,10 @@ struct Router {
 
 extern "C" int dsmgp_tree_route(int64_t n_nodes, const int8_t* kind, const int64_t* first_child, const int64_t* n_child,
                                 const int64_t* split_dim, const double* thr, int64_t thr_ld, const int64_t* leaf_id,
-                                int64_t n_leaves, const double* x, int64_t n_t, int64_t row_stride, int64_t col_stride,
-                                int64_t* route_ptr, int64_t* route_idx, int64_t capacity, int64_t* n_routes_out) {
-    if (n_nodes <= 0 || !kind || !first_child || !n_child || !split_dim || !thr || !leaf_id || n_leaves < 0 || n_t < 0 ||
+                                int64_t n_leaves, const double* x, int64_t n_t, int64_t D, int64_t row_stride,
+                                int64_t col_stride, int64_t* route_ptr, int64_t* route_idx, int64_t capacity,
+                                int64_t* n_routes_out) {
+    if (n_nodes <= 0 || !kind || !first_child || !n_child || !split_dim || !thr || !leaf_id || n_leaves < 0 || n_t < 0 || D <= 0 ||
         (n_t > 0 && !x) || !route_ptr || capacity < 0 || (capacity > 0 && !route_idx))
         return -1;      // DSMGP_E_ARG
     for (int64_t i = 0; i < n_nodes; ++i) {
@@ -566,7 +568,7 @@ extern "C" int dsmgp_tree_route(int64_t n_nodes, const int8_t* kind, const int64
         if (kind[i] == 0 ? (leaf_id[i] < 0 || leaf_id[i] >= n_leaves)
                          : (n_child[i] <= 0 || first_child[i] <= i || first_child[i] + n_child[i] > n_nodes))
             return -1;
-        if (kind[i] == 1 && (n_child[i] > thr_ld || split_dim[i] < 0)) return -1;
+        if (kind[i] == 1 && (n_child[i] > thr_ld || split_dim[i] < 0 || split_dim[i] >= D)) return -1;   // x has D columns
     }
     std::vector<int64_t> rows((size_t)n_t);
     for (int64_t i = 0; i < n_t; ++i) rows[(size_t)i] = i;

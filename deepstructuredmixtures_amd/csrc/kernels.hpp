@@ -2525,6 +2525,25 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned l
     }
 }
 
+// Shader clock held while other work is resident: one wave that sleeps for `ticks` of the 100 MHz wall counter and reports
+// how far the shader-clock counter (s_memtime) moved meanwhile.  Launched on a stream of its own beside the launches of a fit,
+// it costs one wave slot on one CU and no matrix-pipe or memory time.  The loop ends when the wall counter says so: every
+// launch drains.
+__global__ __launch_bounds__(64) void clock_sample_kernel(unsigned long long* out, unsigned long long ticks) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1;
+    do {
+        __builtin_amdgcn_s_sleep(127);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    } while (r1 - r0 < ticks);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+
 #ifdef DSMGP_DIAG
 // Co-issue probe: do the f64 matrix pipe and the f64 vector pipe run at the same time?  mode 0: every wave
 // issues MFMAs; mode 1: every wave issues v_fma_f64; mode 2: even waves MFMA, odd waves v_fma_f64 (two waves per

@@ -27,6 +27,8 @@ class Shard:
         self.world = int(world)
         self.local = np.flatnonzero(self.owner == self.rank)
         self.comm_ctx = None          # hipabi.Context whose RCCL communicator carries the exchanges (device_comm)
+        self.exchange_seconds = 0.0   # wall time this rank has spent inside the exchange collectives (waiting for the slowest
+        self.exchanges = 0            # rank included): bench.py prints it per rank, so an N-GPU line explains its own efficiency
         self.exchange = "none" if self.world == 1 else "torch"
 
     # ---- exchange through the library (RCCL on the context's stream) ----------------------------
@@ -113,8 +115,12 @@ class Shard:
         `count` = max leaves per rank slots of (mll, info) per rank; rank r's leaves, in leaf order, fill its first slots.
         With more than one rank the FIRST exchange of a communicator is cross-checked against the torch.distributed
         gather of `local_cols` (this rank's (n_local, 2) results); a mismatch on any rank drops the device path on all."""
+        import time
         counts = np.bincount(self.owner, minlength=self.world)
+        t0 = time.perf_counter()
         both = np.asarray(ctx.fit_exchange(int(max(1, counts.max()))))
+        self.exchange_seconds += time.perf_counter() - t0
+        self.exchanges += 1
         out = np.empty((self.owner.size, 2))
         for r in range(self.world):
             idx = np.flatnonzero(self.owner == r)
@@ -177,10 +183,19 @@ class Shard:
     # ---- exchange -------------------------------------------------------------------------------
     def _all_gather_padded(self, local, maxlen):
         """All-gather of one padded float64 vector per rank -> list of numpy arrays."""
+        import time
         import torch
         td = _pg()
         if td is None:
             raise RuntimeError("sharded model needs an initialised torch.distributed process group")
+        t0 = time.perf_counter()
+        try:
+            return self._all_gather_padded_timed(td, torch, local, maxlen)
+        finally:
+            self.exchange_seconds += time.perf_counter() - t0
+            self.exchanges += 1
+
+    def _all_gather_padded_timed(self, td, torch, local, maxlen):
         backend = td.get_backend()
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         buf = torch.zeros(maxlen, dtype=torch.float64, device=dev)

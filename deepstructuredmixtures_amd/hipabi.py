@@ -79,11 +79,13 @@ SIGNATURES = {
     "dsmgp_tree_means": (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp]),
     "dsmgp_tree_free": (C.c_int, [C.c_void_p]),
     "dsmgp_tree_route": (C.c_int, [C.c_int64, C.POINTER(C.c_int8), _lp, _lp, _lp, _dp, C.c_int64, _lp, C.c_int64, _dp, C.c_int64,
-                                   C.c_int64, C.c_int64, _lp, _lp, C.c_int64, _lp]),
+                                   C.c_int64, C.c_int64, C.c_int64, _lp, _lp, C.c_int64, _lp]),
     "dsmgp_estimate_bytes": (C.c_int64, [C.c_int32, _lp, _lp, C.c_int32, C.c_int32]),
     "dsmgp_memory": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_probe_f64_mfma": (C.c_int, [_ctx, _dp]),
     "dsmgp_probe_f64_mfma_detail": (C.c_int, [_ctx, C.c_int32, _dp]),
+    "dsmgp_clock_sample_start": (C.c_int, [_ctx, C.c_double]),
+    "dsmgp_clock_sample_read": (C.c_int, [_ctx, _dp, _dp]),
 }
 
 # include/dsmgp_hip_diag.h: only in libdsmgp_hip_diag.so (csrc/build.sh diag), used by tools/ for kernel tuning
@@ -430,6 +432,16 @@ class Context:
         self._chk(self.lib.dsmgp_probe_f64_mfma_detail(self.h, int(blocks_per_cu), out.ctypes.data_as(_dp)))
         return dict(zip(("tflops", "cycles_per_mfma", "clock_ghz", "waves_per_simd"), out.tolist()))
 
+    def clock_sample_start(self, milliseconds):
+        """Start a shader-clock sample of `milliseconds` beside whatever this context launches next (returns at once)."""
+        self._chk(self.lib.dsmgp_clock_sample_start(self.h, float(milliseconds)))
+
+    def clock_sample_read(self):
+        """(GHz held, milliseconds covered) of the sample started last; waits for it."""
+        g, ms = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self.lib.dsmgp_clock_sample_read(self.h, C.byref(g), C.byref(ms)))
+        return g.value, ms.value
+
     def probe_coissue(self):
         out = np.zeros(9)
         self._chk(self.lib.dsmgp_probe_coissue(self.h, out.ctypes.data_as(_dp)))
@@ -700,9 +712,12 @@ def tree_route(kind, first_child, n_child, split_dim, thr, leaf_id, n_leaves, xt
     nr = C.c_int64(0)
     rc = lib.dsmgp_tree_route(int(kind.size), kind.ctypes.data_as(C.POINTER(C.c_int8)), first_child.ctypes.data_as(_lp),
                               n_child.ctypes.data_as(_lp), split_dim.ctypes.data_as(_lp), thr.ctypes.data_as(_dp), int(thr.shape[1]),
-                              leaf_id.ctypes.data_as(_lp), int(n_leaves), x.ctypes.data_as(_dp), int(x.shape[0]), int(rs), int(cs),
+                              leaf_id.ctypes.data_as(_lp), int(n_leaves), x.ctypes.data_as(_dp), int(x.shape[0]), int(x.shape[1]),
+                              int(rs), int(cs),
                               ptr.ctypes.data_as(_lp), idx.ctypes.data_as(_lp), int(idx.size), C.byref(nr))
     if rc != 0:
+        if rc == -1 and split_dim.size and x.shape[1] <= int(split_dim.max()):
+            raise IndexError(f"test rows have {x.shape[1]} columns, the tree splits on dimension {int(split_dim.max())}")
         raise ValueError("test point outside the region of a split node (reference loops forever here)" if rc == -1
                          else f"dsmgp_tree_route failed ({rc})")
     return ptr, idx[:nr.value].copy() if nr.value < idx.size else idx

@@ -363,15 +363,30 @@ def prediction(gp, xtest):
 
 # ------------------------------------------------------------------------------------ fit
 
+_RANK_FAILED = -(1 << 30)      # info value of every leaf of a rank whose fit raised (LAPACK's info is >= 0 here)
+
+
 def _fit(model, tau):
     model._upload(tau)
     if model.shard.world > 1 and _ctx_type(model) is hipabi.Context:
         _ = model.ctx          # every rank, also one without leaves, joins the set-up of the device exchange (collective)
+    failure = None
     if len(model.shard.local) == 0:
         mll_loc, info_loc, sec = np.zeros(0), np.zeros(0, dtype=np.int32), 0.0
-    else:
-        model._push_hyper()
+    elif model.shard.world == 1 or model.shard.comm_ctx is not None:     # (the opt-in device exchange reads the fit's results
+        model._push_hyper()                                              # in HBM: nothing to send for a fit that raised)
         mll_loc, info_loc, sec = model.ctx.fit()
+    else:
+        # One of several ranks: whatever goes wrong HERE (out of memory, a HIP error, bad hyper-parameters on this shard) must not
+        # keep this rank out of the collective below while the others wait in it.  The failure travels as a sentinel in the info
+        # column -- every rank learns of it from the same gather and raises; nobody is left in a later collective alone.
+        try:
+            model._push_hyper()
+            mll_loc, info_loc, sec = model.ctx.fit()
+        except Exception as e:      # noqa: BLE001
+            failure = e
+            mll_loc = np.full(len(model.shard.local), np.nan)
+            info_loc, sec = np.full(len(model.shard.local), _RANK_FAILED, dtype=np.int32), 0.0
     cols = np.stack([mll_loc, info_loc.astype(np.float64)], axis=1)
     if model.shard.comm_ctx is not None:
         both = model.shard.fit_exchange(model.ctx, cols)     # device to device over RCCL, then one copy to the host
@@ -380,6 +395,12 @@ def _fit(model, tau):
     model.leaf_mll = np.ascontiguousarray(both[:, 0])
     model.leaf_info = both[:, 1].astype(np.int32)
     model.last_fit_seconds = sec
+    if failure is not None:
+        raise failure
+    lost = np.flatnonzero(model.leaf_info == _RANK_FAILED)
+    if lost.size:
+        raise RuntimeError(f"fit failed on rank {int(model.shard.owner[lost[0]])} (its {lost.size} leaves have no result); "
+                           "the error is in that rank's output")
     bad = np.flatnonzero(model.leaf_info != 0)
     if bad.size:
         raise np.linalg.LinAlgError(f"leaf {int(bad[0])}: leading minor of order {int(model.leaf_info[bad[0]])} "

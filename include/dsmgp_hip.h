@@ -224,6 +224,13 @@ int dsmgp_probe_f64_mfma(dsmgp_ctx* ctx, double* tflops);
  * out[3] = blocks_per_cu (256-thread workgroups per CU, i.e. waves per SIMD) */
 int dsmgp_probe_f64_mfma_detail(dsmgp_ctx* ctx, int32_t blocks_per_cu, double* out);
 
+/* Shader clock the chip holds under load (bench.py prints it beside the roofline: the f64 matrix peak scales with it).
+ * start: a one-wave kernel on a stream of its own sleeps for `milliseconds` (<= 5000) of wall time beside whatever the context
+ * launches meanwhile and counts shader cycles; returns at once.  read: waits for it; ghz = shader cycles per nanosecond over
+ * the `milliseconds` it actually covered.  One sample at a time per context. */
+int dsmgp_clock_sample_start(dsmgp_ctx* ctx, double milliseconds);
+int dsmgp_clock_sample_read(dsmgp_ctx* ctx, double* ghz, double* milliseconds);
+
 /* Host-only (no device): per leaf j the "main" leaf of the sharing schedule of src/fit.jl:78-86,
  * main[j] = argmax_i D[i,j] D[j,i] over the overlap matrix D of src/fit.jl:12-39 (first maximum, 0 if leaf j overlaps
  * no other leaf), and c_main[j] = number of observations leaf j shares with it -- computed from an inverted index
@@ -236,15 +243,15 @@ int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx
  * The tree as flat arrays with the children of node i at first_child[i] .. first_child[i] + n_child[i] - 1 (root = node 0):
  * kind as in dsmgp_tree_export: 0 = region, i.e. leaf (leaf_id), 1 = split node (split_dim, ascending thresholds
  * thr[i * thr_ld + 0 .. n_child[i] - 1]), 2 = sum node.
- * x: element (row r, dimension d) at x[r * row_stride + d * col_stride].  route_ptr: n_leaves + 1 entries; route_idx: `capacity`
+ * x: n_t rows of D columns, element (row r, dimension d) at x[r * row_stride + d * col_stride].  route_ptr: n_leaves + 1 entries; route_idx: `capacity`
  * entries for the rows of every leaf, ascending (a row reaches at most as many leaves as the tree has below sum nodes along one
- * path: n_t times that bound always suffices).  DSMGP_E_ARG: malformed tree, or a row beyond the last threshold of a split node
- * (the reference loops forever there); DSMGP_E_NOMEM: capacity too small -- route_ptr and *n_routes_out are valid, route_idx
+ * path: n_t times that bound always suffices).  DSMGP_E_ARG: malformed tree, a split dimension >= D, or a row
+ * beyond the last threshold of a split node (the reference loops forever there; a NaN coordinate is beyond every threshold); DSMGP_E_NOMEM: capacity too small -- route_ptr and *n_routes_out are valid, route_idx
  * is not.  At depth 4 (18k leaves, 10k rows to 81 leaves each) the recursion over node objects took 0.09 s on the host, four
  * times the prediction sweep it feeds. */
 int dsmgp_tree_route(int64_t n_nodes, const int8_t* kind, const int64_t* first_child, const int64_t* n_child,
                      const int64_t* split_dim, const double* thr, int64_t thr_ld, const int64_t* leaf_id, int64_t n_leaves,
-                     const double* x, int64_t n_t, int64_t row_stride, int64_t col_stride, int64_t* route_ptr,
+                     const double* x, int64_t n_t, int64_t D, int64_t row_stride, int64_t col_stride, int64_t* route_ptr,
                      int64_t* route_idx, int64_t capacity, int64_t* n_routes_out);
 
 /* ---- multi-GPU: the one exchange step of the path.  Leaves are independent, every rank (one process

@@ -880,15 +880,27 @@ def test_native_routing_equals_the_recursion():
     nr = ctypes.c_int64(0)
     x = np.ascontiguousarray(Xt)
 
-    def call(kind, capacity):
+    def call(kind, capacity, ncols=x.shape[1]):
         return lib.dsmgp_tree_route(int(kind.size), kind.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), ri.first.ctypes.data_as(lp),
                                     ri.nchild.ctypes.data_as(lp), ri.sdim.ctypes.data_as(lp), ri.thr.ctypes.data_as(dp),
                                     int(ri.thr.shape[1]), ri.leaf.ctypes.data_as(lp), ptr.size - 1, x.ctypes.data_as(dp), x.shape[0],
-                                    x.shape[1], 1, ptr.ctypes.data_as(lp), idx.ctypes.data_as(lp), capacity, ctypes.byref(nr))
+                                    ncols, x.shape[1], 1, ptr.ctypes.data_as(lp), idx.ctypes.data_as(lp), capacity, ctypes.byref(nr))
     assert call(ri.kind, 4) == -4 and nr.value == ref[1].size and np.array_equal(ptr, ref[0])    # too small: sizes come back
     bad = ri.kind.copy()
     bad[0] = 7
     assert call(bad, 4) == -1                                                                    # malformed tree
+    # a test matrix with fewer columns than the tree splits on is refused before any row is read (round-4 advisor: the walk
+    # indexed x[row, split_dim] unchecked), through the ABI and through `route`; the numpy recursion raises IndexError there
+    assert int(ri.sdim.max()) >= 1 and call(ri.kind, 4, ncols=int(ri.sdim.max())) == -1
+    with pytest.raises(IndexError):
+        ptree.route(m.root, Xt[:, :int(ri.sdim.max())])
+    # a NaN coordinate satisfies no threshold: outside the region, as in the recursion (not silently the first child)
+    xn = Xt[:5].copy()
+    xn[2, int(ri.sdim[ri.kind == 1][0])] = np.nan
+    with pytest.raises(ValueError):
+        ptree.route(m.root, xn)
+    with pytest.raises(ValueError):
+        ptree.route_recursive(m.root, xn)
 
 
 def test_overlap_main_counter_widths_threads_and_observation_table():
@@ -940,3 +952,69 @@ def test_overlap_main_counter_widths_threads_and_observation_table():
     p3, i3 = ptree.obs_table(shuffled)
     assert not np.shares_memory(i3, m.leaves[5].obs) and np.array_equal(i3, np.concatenate([lf.obs for lf in shuffled]))
     assert ptree.obs_table([])[1].size == 0
+
+
+_FAILING_RANK_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as td
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import deepstructuredmixtures_amd as dsm
+from oracle_context import OraclePartialContext
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+td.init_process_group("gloo", rank=rank, world_size=world)
+z = np.load(os.path.join({root!r}, "tests", "golden", "tree_small.npz"))
+
+
+class Flaky(OraclePartialContext):
+    mode = None                 # "info": rank 1 reports a leading minor that is not positive definite; "raise": its fit raises
+    def fit(self):
+        mll, info, sec = super().fit()
+        if rank == 1 and self.mode == "info":
+            info = info.copy(); info[0] = 3
+        if rank == 1 and self.mode == "raise":
+            raise MemoryError("device out of memory on this rank only")
+        return mll, info, sec
+
+
+ctx = Flaky()
+m = dsm.buildDSMGP(z["X"], z["y"], 2, 4, M=20, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=3,
+                   fit_now=False, ctx=ctx, shard_world=(rank, world))
+assert 0 < len(m.shard.local) < m.L
+# (1) info != 0 on rank 1's shard only: EVERY rank raises LinAlgError naming the same leaf ...
+ctx.mode = "info"
+try:
+    dsm.fit(m)
+    raise SystemExit("no error on rank %d" % rank)
+except np.linalg.LinAlgError as e:
+    bad = int(m.shard.owner.tolist().index(1))
+    assert ("leaf %d:" % bad) in str(e) and "order 3" in str(e), str(e)
+# (2) ... an exception inside rank 1's fit: rank 1 re-raises it, the others learn of it from the same gather
+ctx.mode = "raise"
+try:
+    dsm.fit(m)
+    raise SystemExit("no error on rank %d" % rank)
+except MemoryError:
+    assert rank == 1
+except RuntimeError as e:
+    assert rank == 0 and "rank 1" in str(e), str(e)
+# (3) ... and nobody is out of step afterwards: the next fit + predict run their collectives and give the reference result
+ctx.mode = None
+dsm.fit(m)
+assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=1e-10, atol=1e-9)
+dsm.update(m)
+mu, var = dsm.predict(m, z["Xt"])
+assert np.allclose(mu, z["mu"], rtol=1e-9, atol=1e-10) and np.allclose(var, z["var"], rtol=1e-8, atol=1e-10)
+assert m.shard.exchanges >= 4 and m.shard.exchange_seconds > 0.0
+td.barrier(); td.destroy_process_group()
+print("rank", rank, "ok", len(m.shard.local))
+"""
+
+
+def test_failure_on_one_rank_reaches_every_rank_and_nobody_hangs(tmp_path):
+    """VERDICT r4 #5c: a fit that fails on ONE rank's shard -- LAPACK info != 0 there, or an exception inside its device call --
+    must fail on every rank (all of them leave the same gather with the same knowledge) and leave the ranks in step for the
+    next collective.  Leaves are independent (`src/fit.jl:88-119`); what crosses ranks is `src/common.jl:323-334`'s per-leaf mll."""
+    script = tmp_path / "worker.py"
+    script.write_text(_FAILING_RANK_WORKER.format(root=ROOT))
+    _run_two_ranks(script, 29741)

@@ -52,7 +52,7 @@ int main() {
             std::vector<int64_t> rp(rcount + 1), ri((size_t)nq * (size_t)rcount + 1);
             int64_t nr = 0;
             rc = dsmgp_tree_route(nn, k2.data(), first.data(), nch.data(), sd2.data(), th2.data(), width, leaf.data(), rcount,
-                                  xq.data(), nq, c.D, 1, rp.data(), ri.data(), (int64_t)ri.size(), &nr);
+                                  xq.data(), nq, c.D, c.D, 1, rp.data(), ri.data(), (int64_t)ri.size(), &nr);
             printf("   route rc %d routes %ld (%.1f per row)\n", rc, (long)nr, (double)nr / nq);
         }
         dsmgp_tree_free(t);
