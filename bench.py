@@ -29,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r04_update_kernel_traffic.json"
+TRAFFIC_FILE = "r05_update_kernel_traffic.json"
 
 
 def source_stamp():

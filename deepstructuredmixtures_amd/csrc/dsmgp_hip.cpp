@@ -57,12 +57,19 @@ struct HostLog {
     const char* what;
     std::chrono::steady_clock::time_point t0;
     explicit HostLog(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
-    ~HostLog() {
-        static const bool on = std::getenv("DSMGP_HOSTLOG") != nullptr;
-        if (on)
-            std::fprintf(stderr, "hostlog %-28s %.3f s\n", what,
-                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    void lap(const char* next) {      // close the running phase, open the next
+        done();
+        what = next;
+        t0 = std::chrono::steady_clock::now();
     }
+    void done() {
+        static const bool on = std::getenv("DSMGP_HOSTLOG") != nullptr;
+        if (on && what)
+            std::fprintf(stderr, "hostlog %-28s %.4f s\n", what,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        what = nullptr;
+    }
+    ~HostLog() { done(); }
 };
 
 enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
@@ -2084,7 +2091,9 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     HostLog hl_total("set_test");
     if (!c->plan_ready)
         if (int rc = build_plan(c)) return rc;
+    HostLog hl("set_test: free old");
     free_test(c, true);     // the K_tn arena of the set this one replaces is kept for it (spareVt)
+    hl.lap("set_test: validate");
     const int L = c->L;
     if (route_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "route_ptr[0] must be 0");
     const int64_t total = route_ptr[L];
@@ -2117,6 +2126,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (!c->pool_base && need + (size_t(1) << 30) > freeB)
         return fail(c, DSMGP_E_NOMEM, "test set needs " + std::to_string(need >> 20) + " MiB, device has " +
                                           std::to_string(freeB >> 20) + " MiB free");
+    hl.lap("set_test: uploads + row index");
     HIPCHK(c, hipMalloc(&c->dXt, (size_t)n_t * c->D * sizeof(double)));
     HIPCHK(c, hipMemcpy(c->dXt, Xt, (size_t)n_t * c->D * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_route_ptr, (L + 1) * sizeof(int64_t)));
@@ -2144,6 +2154,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         HIPCHK(c, hipMemcpy(c->d_row_ent, rent.data(), rent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_ent_leaf, eleaf.data(), eleaf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    hl.lap("set_test: arenas");
     if (c->spareVt && c->spareVt_count >= vTot && c->spareVt_count <= 2 * vTot + (size_t(1) << 20)) {
         c->arenaVt = c->spareVt;        // big enough and not wastefully so
         c->arenaVt_count = c->spareVt_count;
@@ -2187,6 +2198,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
         }
         HIPCHK(c, hipGetLastError());
     }
+    hl.lap("set_test: task lists (host)");
     // task lists
     // In the block steps that a fit runs fused (many leaves, or shallow: build_plan) the sweep does too: one tile_fused8_kernel
     // launch whose tasks evaluate K_tn themselves, update and solve eight 16-row blocks of test rows each and write them once
@@ -2317,6 +2329,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     c->pred_off[nsteps] = (int)U.red.size();
     c->ptrsm_off[nsteps] = (int)trsm.size();
     c->psweep8_off[nsteps] = (int)sweep8.size();
+    hl.lap("set_test: task uploads");
     if (int rc = dev_upload(c, c->psweep8, sweep8)) return rc;
     if (U.max_slabs)
         if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
@@ -2336,6 +2349,7 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     c->joint_ready = false;
     if (c->pool_base)
         if (int rc = ensure_joint(c)) return rc;
+    hl.lap("set_test: final sync");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->test_ready = true;
     c->vt_valid = false;

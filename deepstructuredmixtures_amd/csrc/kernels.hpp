@@ -32,6 +32,11 @@ typedef const d2 __attribute__((address_space(1)))* gd2_cptr;
 typedef double __attribute__((address_space(1)))* gf64_ptr;
 #define AS_GLOBAL_D2(p) (reinterpret_cast<gd2_cptr>(reinterpret_cast<uintptr_t>(p)))
 #define AS_GLOBAL_F64(p) (reinterpret_cast<gf64_ptr>(reinterpret_cast<uintptr_t>(p)))
+// the hyper-parameter tables (KParam.l2 / nh) are written by the host between launches only and indexed wave-uniformly: in the
+// constant address space the compiler reads them with scalar loads (a flat load per dimension kept an address pair and a result
+// pair of VECTOR registers alive across the loop over the dimensions of the additive ArdSE kernel)
+typedef const double __attribute__((address_space(4)))* cf64_ptr;
+#define AS_CONST_F64(p) (reinterpret_cast<cf64_ptr>(reinterpret_cast<uintptr_t>(p)))
 
 // ---------------------------------------------------------------------------------------------
 // kernel-function parameters (one per kernel id), derived on the host from the log-scale vector

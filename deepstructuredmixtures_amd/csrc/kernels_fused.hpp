@@ -117,7 +117,7 @@ __device__ __forceinline__ void rowsplit_gram_init(int gna, int gnb, const KPara
             for (int i = 0; i < NRW; ++i) a[i] = pa[d * TB + 16 * i];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) b[j] = pb[d * TB + 16 * (j >> 2) + 4 * (j & 3)];
-            gram_accumulate<KIND, NRW, NJ>(z, a, b, (KIND == 1) ? p.nh[d] : 0.0);
+            gram_accumulate<KIND, NRW, NJ>(z, a, b, (KIND == 1) ? AS_CONST_F64(p.nh)[d] : 0.0);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -434,48 +434,81 @@ __global__ __launch_bounds__(256) void zero_pad_rows_kernel(const ZeroRowsTask* 
 
 // Gram values of a wave's 9 lower blocks of the diagonal tile, S = k - product in place (syrk_gram_epilogue without the
 // store), then the blocks go into the packed image of chol_diag_packed_body
+#ifndef DSMGP_SYRK_GRAM_GROUP
+#define DSMGP_SYRK_GRAM_GROUP 2         // blocks whose kernel-function sums are in flight at once (round 4: 3 -- with 68 B of scratch)
+#endif
 template <int SHAPE, int KIND>
 __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KParam& p, int D, d4 (&acc)[9], const int (&blk)[6],
                                                   const double* sa) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
+    constexpr int G = (KIND == 0) ? DSMGP_SYRK_GRAM_GROUP : 1;
+    int rbk[9], cbk[9];         // block row / column of accumulator i (the layout syrk_mainloop leaves)
 #pragma unroll
-    for (int g3 = 0; g3 < 3; ++g3) {
-        int rb[3], cb[3];
+    for (int i = 0; i < 9; ++i) {
+        const int g3 = i / 3, j = i % 3;
+        rbk[i] = (SHAPE == 0) ? blk[g3] : blk[2 * g3 + (j > 0 ? 1 : 0)];
+        cbk[i] = (SHAPE == 0) ? blk[3 + j] : blk[2 * g3 + (j > 1 ? 1 : 0)];
+    }
+    if constexpr (KIND != 0) {
+        // ArdSE / IsoLinear: one block, two of its entries at a time (the exp per dimension of the additive kernel and the
+        // unrolled dot product each wanted one register more than the task has at four)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (SHAPE == 0) {
-                rb[j] = blk[g3];
-                cb[j] = blk[3 + j];
-            } else {
-                rb[j] = blk[2 * g3 + (j > 0 ? 1 : 0)];
-                cb[j] = blk[2 * g3 + (j > 1 ? 1 : 0)];
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int r0 = 0; r0 < 4; r0 += 2) {
+                double z[1][2] = {{0.0, 0.0}};
+#pragma unroll 1
+                for (int d = 0; d < D; ++d) {
+                    const double nhd = (KIND == 1) ? AS_CONST_F64(p.nh)[d] : 0.0;
+                    double a[1], b[2];
+                    a[0] = sa[d * TB + 16 * rbk[i] + l15];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) b[r] = sa[d * TB + 16 * cbk[i] + l4 + 4 * (r0 + r)];
+                    gram_accumulate<KIND, 1, 2>(z, a, b, nhd);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int row = 16 * rbk[i] + l15, col = 16 * cbk[i] + l4 + 4 * (r0 + r);
+                    const double kv = gram_finish<KIND>(z[0][r], p, row, col, tk.gna, tk.gnb, true);
+                    acc[i][r0 + r] = kv - acc[i][r0 + r];
+                }
             }
+    } else {
+        // IsoSE: G blocks at a time -- their 4 G exponentials overlap (one block at a time: diagonal blocks of a depth-4 fit
+        // 10.12 -> 10.31 ms; three: 68 bytes of scratch per lane at three workgroups per CU)
+#pragma unroll
+        for (int i0 = 0; i0 < 9; i0 += G) {
+            constexpr int GG = G;
+            double z[GG][1][4];
+#pragma unroll
+            for (int j = 0; j < GG; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[j][0][r] = 0.0;
+            for (int d = 0; d < D; ++d) {
+#pragma unroll
+                for (int j = 0; j < GG; ++j) {
+                    if (i0 + j < 9) {
+                        double a[1], b[4];
+                        a[0] = sa[d * TB + 16 * rbk[i0 + j < 9 ? i0 + j : 8] + l15];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) b[r] = sa[d * TB + 16 * cbk[i0 + j < 9 ? i0 + j : 8] + l4 + 4 * r];
+                        gram_accumulate<KIND, 1, 4>(z[j], a, b, 0.0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < GG; ++j)
+                if (i0 + j < 9) {
+                    const int i = i0 + j < 9 ? i0 + j : 8;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * rbk[i] + l15, col = 16 * cbk[i] + l4 + 4 * r;
+                        const double kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
+                        acc[i][r] = kv - acc[i][r];
+                    }
+                }
         }
-        double z[3][1][4];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[j][0][r] = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double nhd = (KIND == 1) ? p.nh[d] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double a[1], b[4];
-                a[0] = sa[d * TB + 16 * rb[j] + l15];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = sa[d * TB + 16 * cb[j] + l4 + 4 * r];
-                gram_accumulate<KIND, 1, 4>(z[j], a, b, nhd);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * rb[j] + l15, col = 16 * cb[j] + l4 + 4 * r;
-                const double kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
-                acc[3 * g3 + j][r] = kv - acc[3 * g3 + j][r];
-            }
     }
 }
 

@@ -10,7 +10,7 @@ rm -rf $out && mkdir -p $out
 PMC1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
 PMC2="FETCH_SIZE"
 PMC3="WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 run() {   # run <name> <bench args...>: the three PMC passes FIRST; for the headline run the traffic figure they give is written
           # to profiles/ (on this box) before the stats pass, so that the bench line of the stats pass -- the line that gets
           # committed -- quotes the traffic measured beside it (tools/summarize_profiles.py --traffic-only)

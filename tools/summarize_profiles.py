@@ -32,7 +32,7 @@ def newest(pattern):
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 base = args[0] if len(args) > 0 else "gpurun_out/prof_round"
-tag = args[1] if len(args) > 1 else "r04"
+tag = args[1] if len(args) > 1 else "r05"
 TRAFFIC_ONLY = "--traffic-only" in sys.argv      # on the GPU box, between the PMC passes and the stats pass (tools/profile_round.sh)
 os.makedirs("profiles", exist_ok=True)
 
