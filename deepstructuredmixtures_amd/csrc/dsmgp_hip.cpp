@@ -49,7 +49,8 @@ struct LeafHost {
 template <class T>
 struct DevBuf {
     T* p = nullptr;
-    size_t count = 0;
+    size_t count = 0;       // entries in use (what a launch may cover)
+    size_t cap = 0;         // entries allocated: a list that is replaced keeps its allocation while the new one fits (dev_upload)
 };
 
 // DSMGP_HOSTLOG=1: wall time of the host-side phases of plan building to stderr (diagnostic)
@@ -440,8 +441,13 @@ struct dsmgp_ctx {
     int64_t* d_route_idx = nullptr;
     std::vector<int64_t> route_ptr;
     double* arenaVt = nullptr;
-    double* spareVt = nullptr;      // the K_tn arena of the test set a new registration replaces, kept for it (see dsmgp_set_test)
-    size_t spareVt_count = 0, arenaVt_count = 0;
+    size_t arenaVt_count = 0;       // doubles allocated for the K_tn arena: a test set that replaces another takes it over while it
+                                    // fits (releasing ~10 GB and asking the driver for them again took up to 0.6 s of a 0.06 s predict)
+    // capacities of the test set's other buffers (dev_grow: kept across registrations, freed with the context / the plan)
+    size_t cap_dXt = 0, cap_route_ptr = 0, cap_route_idx = 0, cap_row_ptr = 0, cap_row_ent = 0, cap_ent_leaf = 0, cap_agg_coef = 0,
+           cap_agg_group = 0, cap_agg_out = 0, cap_Xt = 0, cap_PV = 0, cap_slabP = 0;
+    DevBuf<SweepSeg> psegs;         // (leaf, block step) pairs of the sweep's fused steps: build_sweep8_kernel makes the tasks
+    DevBuf<ZeroRange> pzero;        // K_tn rows that must start as zeros (leaves whose sweep has classic steps)
     double* arenaXt = nullptr;
     double* arenaPV = nullptr;      // mu | var (route order, unpadded) | macc | sacc (padded accumulators of the sweep)
     size_t acc_off = 0, acc_count = 0;
@@ -499,6 +505,16 @@ struct dsmgp_ctx {
     int comm_rank = 0, comm_world = 1;
     double* d_xchg = nullptr;       // send | recv staging
     size_t xchg_cap = 0;
+    // the model's tree as flat arrays in HBM (dsmgp_set_tree): the routing of predict runs on the device (dsmgp_set_test_routed)
+    RouteTree rtree{};
+    int64_t rtree_nodes = 0;
+    int rtree_max_leaf = -1;        // largest local leaf index a region names (checked against the leaf table at routing time)
+    bool rtree_ready = false;
+    // routing workspace, kept across registrations: row counts | leaf counts | outside flag, bitmap, word prefixes
+    int32_t* rws_counts = nullptr;
+    size_t rws_counts_cap = 0;
+    uint32_t* rws_bits = nullptr;
+    size_t rws_bits_cap = 0;
     hipStream_t side = nullptr;     // clock sampler (dsmgp_clock_sample_*): a one-wave kernel beside the context's own launches
     unsigned long long* d_clock = nullptr;
     bool clock_pending = false;
@@ -528,15 +544,28 @@ int fail(dsmgp_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// `count` entries for a task list: the allocation is kept while the new list fits (a test set that replaces another, a
+// gradient mask that changes: hipFree + hipMalloc per list and registration were 3-4 ms of a 16 ms predict at depth 4)
+template <class T>
+int dev_reserve(dsmgp_ctx* ctx, DevBuf<T>& buf, size_t count) {
+    buf.count = 0;
+    if (count > buf.cap || (count && !buf.p)) {
+        if (buf.p) {
+            HIPCHK(ctx, hipFree(buf.p));
+            buf.p = nullptr;
+        }
+        buf.cap = 0;
+        const size_t want = count + count / 8;
+        HIPCHK(ctx, hipMalloc(&buf.p, want * sizeof(T)));
+        buf.cap = want;
+    }
+    buf.count = count;
+    return 0;
+}
 template <class T>
 int dev_upload(dsmgp_ctx* ctx, DevBuf<T>& buf, const std::vector<T>& host) {
-    if (buf.p) {
-        HIPCHK(ctx, hipFree(buf.p));
-        buf.p = nullptr;
-    }
-    buf.count = host.size();
+    if (int rc = dev_reserve(ctx, buf, host.size())) return rc;
     if (host.empty()) return 0;
-    HIPCHK(ctx, hipMalloc(&buf.p, host.size() * sizeof(T)));
     HIPCHK(ctx, hipMemcpy(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
@@ -550,6 +579,30 @@ template <class T>
 void dev_free(DevBuf<T>& b) {      // a freed list is an EMPTY list: nobody may launch over its old count
     dev_free(b.p);
     b.count = 0;
+    b.cap = 0;
+}
+template <class T>
+void dev_drop(DevBuf<T>& b, bool keep) {    // keep: the list is emptied, its allocation stays for the list that replaces it
+    if (keep) b.count = 0;
+    else dev_free(b);
+}
+// a plain device array that grows on demand and otherwise stays (the buffers of a registered test set)
+template <class T>
+int dev_grow(dsmgp_ctx* ctx, T*& p, size_t& cap, size_t need) {
+    if (p && need <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(1, need + need / 8);
+    HIPCHK(ctx, hipMalloc(&p, want * sizeof(T)));
+    cap = want;
+    return 0;
+}
+template <class T>
+void dev_drop(T*& p, size_t& cap, bool keep) {
+    if (keep) return;
+    dev_free(p);
+    cap = 0;
 }
 
 bool in_pool(const dsmgp_ctx* c, const void* p) {
@@ -609,7 +662,19 @@ void free_grad(dsmgp_ctx* c) {
     c->grad_ready = false;
 }
 
-void free_test(dsmgp_ctx* c, bool keep_vt = false);
+void free_tree(dsmgp_ctx* c) {
+    dev_free(const_cast<int8_t*&>(c->rtree.kind));
+    dev_free(const_cast<int32_t*&>(c->rtree.first));
+    dev_free(const_cast<int32_t*&>(c->rtree.nchild));
+    dev_free(const_cast<int32_t*&>(c->rtree.sdim));
+    dev_free(const_cast<int32_t*&>(c->rtree.leaf));
+    dev_free(const_cast<double*&>(c->rtree.thr));
+    c->rtree_ready = false;
+    c->rtree_nodes = 0;
+    c->rtree_max_leaf = -1;
+}
+
+void free_test(dsmgp_ctx* c, bool keep = false);
 void free_plan(dsmgp_ctx* c) {
     drop_graphs(c);
     if (c->pool_base) {      // stack order: everything above the plan goes with it
@@ -647,55 +712,52 @@ void free_plan(dsmgp_ctx* c) {
     c->fitted = false;
 }
 
-void free_test(dsmgp_ctx* c, bool keep_vt) {
+// keep: a registration that replaces another -- every buffer of the old test set stays allocated for the new one (they are
+// emptied, not freed).  With a device pool the arenas are carved out of the pool's stack and go with its top.
+void free_test(dsmgp_ctx* c, bool keep) {
     drop_graphs(c);
     if (c->pool_base) {      // the gradient arenas sit above (or would be clobbered below) the test arenas
         free_grad(c);
         c->pool_top = c->pool_mark_plan;
+        keep = false;
     }
-    dev_free(c->dXt);
-    dev_free(c->d_route_ptr);
-    dev_free(c->d_route_idx);
-    dev_free(c->d_row_ptr);
-    dev_free(c->d_row_ent);
-    dev_free(c->d_ent_leaf);
-    dev_free(c->d_agg_part);
-    dev_free(c->d_agg_coef);
-    dev_free(c->d_agg_group);
-    dev_free(c->d_agg_out);
-    c->agg_part_cap = 0;
+    dev_drop(c->dXt, c->cap_dXt, keep);
+    dev_drop(c->d_route_ptr, c->cap_route_ptr, keep);
+    dev_drop(c->d_route_idx, c->cap_route_idx, keep);
+    dev_drop(c->d_row_ptr, c->cap_row_ptr, keep);
+    dev_drop(c->d_row_ent, c->cap_row_ent, keep);
+    dev_drop(c->d_ent_leaf, c->cap_ent_leaf, keep);
+    dev_drop(c->d_agg_part, c->agg_part_cap, keep);
+    dev_drop(c->d_agg_coef, c->cap_agg_coef, keep);
+    dev_drop(c->d_agg_group, c->cap_agg_group, keep);
+    dev_drop(c->d_agg_out, c->cap_agg_out, keep);
     c->agg_partial_ready = c->agg_done = c->agg_total = false;
-    // A registration that replaces another keeps the old K_tn arena for itself: releasing ~10 GB and asking the driver for them
-    // again took up to 0.6 s of a 0.06 s predict(model, x) on new rows (depth 4).  Every other caller lets both go.
-    arena_put(c, c->spareVt);
-    c->spareVt_count = 0;
-    if (keep_vt && c->arenaVt && !in_pool(c, c->arenaVt)) {
-        c->spareVt = c->arenaVt;
-        c->spareVt_count = c->arenaVt_count;
-        c->arenaVt = nullptr;
+    if (!keep) {
+        arena_put(c, c->arenaVt);
+        c->arenaVt_count = 0;
+        arena_put(c, c->arenaXt);
+        arena_put(c, c->arenaPV);
+        arena_put(c, c->slabP);
+        c->cap_Xt = c->cap_PV = c->cap_slabP = 0;
     }
-    arena_put(c, c->arenaVt);
-    c->arenaVt_count = 0;
-    arena_put(c, c->arenaXt);
-    arena_put(c, c->arenaPV);
-    dev_free(c->pgram);
-    dev_free(c->pgram0);
-    c->pgram0 = DevBuf<GramTask>{};
-    dev_free(c->ptasks);
-    dev_free(c->ptasks_slow);
-    dev_free(c->pupd);
-    dev_free(c->ptrsm);
-    dev_free(c->pred);
-    dev_free(c->psweep8);
-    arena_put(c, c->slabP);
+    dev_drop(c->pgram, keep);
+    dev_drop(c->pgram0, keep);
+    dev_drop(c->ptasks, keep);
+    dev_drop(c->ptasks_slow, keep);
+    dev_drop(c->pupd, keep);
+    dev_drop(c->ptrsm, keep);
+    dev_drop(c->pred, keep);
+    dev_drop(c->psweep8, keep);
+    dev_drop(c->psegs, keep);
+    dev_drop(c->pzero, keep);
     for (auto& ph : c->phaseJ) {
-        dev_free(ph.upd);
-        dev_free(ph.trsm);
-        dev_free(ph.red);
-        dev_free(ph.diag);
-        dev_free(ph.fdiag);
-        dev_free(ph.ftile8);
-        dev_free(ph.dfin);
+        dev_drop(ph.upd, keep);
+        dev_drop(ph.trsm, keep);
+        dev_drop(ph.red, keep);
+        dev_drop(ph.diag, keep);
+        dev_drop(ph.fdiag, keep);
+        dev_drop(ph.ftile8, keep);
+        dev_drop(ph.dfin, keep);
     }
     arena_put(c, c->slabJ);
     c->joint_ready = false;
@@ -1745,6 +1807,9 @@ int dsmgp_destroy(dsmgp_ctx* c) {
         (void)hipStreamDestroy(c->side);
     }
     dev_free(c->d_clock);
+    free_tree(c);
+    dev_free(c->rws_counts);
+    dev_free(c->rws_bits);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1824,6 +1889,7 @@ int dsmgp_set_train(dsmgp_ctx* c, const double* X, const double* y, int64_t N, i
     HIPCHK(c, hipSetDevice(c->device));
     free_plan(c);
     free_test(c);
+    free_tree(c);
     dev_free(c->dX);
     dev_free(c->dy);
     c->N = N;
@@ -1845,6 +1911,7 @@ int dsmgp_set_leaves(dsmgp_ctx* c, int32_t L, const int64_t* obs_ptr, const int6
     HIPCHK(c, hipSetDevice(c->device));
     free_plan(c);
     free_test(c);
+    free_tree(c);           // its regions name indices of the OLD leaf table
     if (obs_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "obs_ptr[0] must be 0");
     c->leaves.assign(L, LeafHost{});
     c->grad_active.clear();         // a new leaf table: gradients of every leaf again
@@ -2083,93 +2150,56 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
 }
 
 // -------------------------------------------------------------------------------------------------
-int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* route_ptr, const int64_t* route_idx) {
-    if (!c) return DSMGP_E_ARG;
-    if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_test before set_leaves");
-    if (!Xt || n_t <= 0 || !route_ptr) return fail(c, DSMGP_E_ARG, "set_test: bad arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    HostLog hl_total("set_test");
-    if (!c->plan_ready)
-        if (int rc = build_plan(c)) return rc;
-    HostLog hl("set_test: free old");
-    free_test(c, true);     // the K_tn arena of the set this one replaces is kept for it (spareVt)
-    hl.lap("set_test: validate");
+}  // extern "C"
+
+namespace {
+// Second half of a test-set registration, common to dsmgp_set_test (routes from the host) and dsmgp_set_test_routed (routes
+// made on the device): per-leaf sizes from c->route_ptr, the K_tn arena, the gathered test rows, the task lists of the sweep.
+// The first half has put the rows (dXt), the CSR (d_route_ptr / d_route_idx) and the per-row entry index (d_row_ptr / d_row_ent /
+// d_ent_leaf) into HBM and the per-leaf row offsets into c->route_ptr.
+int register_test(dsmgp_ctx* c, HostLog& hl) {
     const int L = c->L;
-    if (route_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "route_ptr[0] must be 0");
-    const int64_t total = route_ptr[L];
-    if (total > 0 && !route_idx) return fail(c, DSMGP_E_ARG, "route_idx is NULL");
-    for (int l = 0; l < L; ++l)
-        if (route_ptr[l + 1] < route_ptr[l]) return fail(c, DSMGP_E_ARG, "route_ptr must be non-decreasing");
-    for (int64_t i = 0; i < total; ++i)
-        if (route_idx[i] < 0 || route_idx[i] >= n_t) return fail(c, DSMGP_E_ARG, "route index out of range");
-    c->n_t = n_t;
-    c->route_total = total;
-    c->route_ptr.assign(route_ptr, route_ptr + L + 1);
+    const int64_t n_t = c->n_t, total = c->route_total;
+    const int64_t* rp = c->route_ptr.data();
+    hl.lap("set_test: sizes");
     size_t vTot = 0, xTot = 0;
     size_t accTot = 0;
-    for (int l = 0; l < L; ++l) accTot += (size_t)round_up((int)(route_ptr[l + 1] - route_ptr[l]), TB);
+    for (int l = 0; l < L; ++l) accTot += (size_t)round_up((int)(rp[l + 1] - rp[l]), TB);
     const size_t pTot = 2 * (size_t)total + 2 * accTot + 2 * TB;
     for (int l = 0; l < L; ++l) {
         LeafHost& lf = c->leaves[l];
-        lf.nt = (int)(route_ptr[l + 1] - route_ptr[l]);
+        lf.nt = (int)(rp[l + 1] - rp[l]);
         lf.ntpad = round_up(lf.nt, TB);
-        lf.route_off = route_ptr[l];
+        lf.route_off = rp[l];
         lf.vt_off = vTot;
         vTot += (size_t)lf.ntpad * lf.npad;
         lf.xt_off = xTot;
         xTot += (size_t)lf.ntpad * c->D;
-        lf.pv_off = (size_t)route_ptr[l];   // mu / var of all leaves are contiguous in route order (unpadded)
+        lf.pv_off = (size_t)rp[l];   // mu / var of all leaves are contiguous in route order (unpadded)
     }
     size_t freeB = 0, totalB = 0;
     HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
     const size_t need = (vTot + xTot + pTot) * sizeof(double) + (size_t)n_t * c->D * sizeof(double);
+    if (!c->pool_base) freeB += (c->arenaVt_count + c->cap_Xt + c->cap_PV) * sizeof(double);   // taken over or released first (arena_fit)
     if (!c->pool_base && need + (size_t(1) << 30) > freeB)
         return fail(c, DSMGP_E_NOMEM, "test set needs " + std::to_string(need >> 20) + " MiB, device has " +
                                           std::to_string(freeB >> 20) + " MiB free");
-    hl.lap("set_test: uploads + row index");
-    HIPCHK(c, hipMalloc(&c->dXt, (size_t)n_t * c->D * sizeof(double)));
-    HIPCHK(c, hipMemcpy(c->dXt, Xt, (size_t)n_t * c->D * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMalloc(&c->d_route_ptr, (L + 1) * sizeof(int64_t)));
-    HIPCHK(c, hipMemcpy(c->d_route_ptr, route_ptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMalloc(&c->d_route_idx, std::max<int64_t>(1, total) * sizeof(int64_t)));
-    if (total) HIPCHK(c, hipMemcpy(c->d_route_idx, route_idx, total * sizeof(int64_t), hipMemcpyHostToDevice));
-    {
-        // per test row, the (leaf, row) entries that carry its moments, in ascending entry order (= leaf order):
-        // the index agg_partial_kernel walks
-        if (total > (int64_t)INT32_MAX) return fail(c, DSMGP_E_ARG, "set_test: more than 2^31 routed rows");
-        std::vector<int64_t> rptr((size_t)n_t + 1, 0);
-        for (int64_t i = 0; i < total; ++i) rptr[route_idx[i] + 1]++;
-        for (int64_t r = 0; r < n_t; ++r) rptr[r + 1] += rptr[r];
-        std::vector<int32_t> rent((size_t)std::max<int64_t>(1, total)), eleaf((size_t)std::max<int64_t>(1, total));
-        std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
-        for (int l = 0; l < L; ++l)
-            for (int64_t i = route_ptr[l]; i < route_ptr[l + 1]; ++i) {
-                rent[fill[route_idx[i]]++] = (int32_t)i;
-                eleaf[i] = l;
-            }
-        HIPCHK(c, hipMalloc(&c->d_row_ptr, ((size_t)n_t + 1) * sizeof(int64_t)));
-        HIPCHK(c, hipMalloc(&c->d_row_ent, rent.size() * sizeof(int32_t)));
-        HIPCHK(c, hipMalloc(&c->d_ent_leaf, eleaf.size() * sizeof(int32_t)));
-        HIPCHK(c, hipMemcpy(c->d_row_ptr, rptr.data(), rptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_row_ent, rent.data(), rent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_ent_leaf, eleaf.data(), eleaf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
     hl.lap("set_test: arenas");
-    if (c->spareVt && c->spareVt_count >= vTot && c->spareVt_count <= 2 * vTot + (size_t(1) << 20)) {
-        c->arenaVt = c->spareVt;        // big enough and not wastefully so
-        c->arenaVt_count = c->spareVt_count;
-        c->spareVt = nullptr;
-        c->spareVt_count = 0;
-    } else {
-        arena_put(c, c->spareVt);
-        c->spareVt_count = 0;
-        if (int rc = arena_get(c, c->arenaVt, vTot)) return rc;
-        c->arenaVt_count = vTot;
-    }
-    if (int rc = arena_get(c, c->arenaXt, xTot)) return rc;
-    if (int rc = arena_get(c, c->arenaPV, pTot)) return rc;
-    // padding rows of the K_tn tiles: zero once, the Gram kernel writes data rows only (gram_half_tile)
-    if (vTot) HIPCHK(c, hipMemsetAsync(c->arenaVt, 0, vTot * sizeof(double), c->stream));
+    // every arena of the test set this one replaces is taken over while it fits (and is not wastefully large: at most twice what
+    // is needed); with a device pool they are carved out of the pool's stack
+    auto arena_fit = [&](double*& p, size_t& cap, size_t need_) -> int {
+        if (c->pool_base) return arena_get(c, p, need_);
+        if (p && cap >= need_ && cap <= 2 * need_ + (size_t(1) << 20)) return 0;
+        arena_put(c, p);
+        cap = 0;
+        const size_t want = need_ + need_ / 8;
+        if (int rc = arena_get(c, p, want)) return rc;
+        cap = want;
+        return 0;
+    };
+    if (int rc = arena_fit(c->arenaVt, c->arenaVt_count, vTot)) return rc;
+    if (int rc = arena_fit(c->arenaXt, c->cap_Xt, xTot)) return rc;
+    if (int rc = arena_fit(c->arenaPV, c->cap_PV, pTot)) return rc;
     int maxpad = 0;
     size_t accOff = 0;
     c->acc_off = 2 * (size_t)total;
@@ -2247,37 +2277,65 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     U.tail_split = c->tail_split;
     U.tail_rounds = c->tail_rounds;
     std::vector<TileTask> trsm;
-    std::vector<FusedTask8> sweep8;
-    std::vector<RowBlock> blocks8;
     c->pupd_off.assign(nsteps + 1, 0);
     c->pred_off.assign(nsteps + 1, 0);
     c->ptrsm_off.assign(nsteps + 1, 0);
     c->psweep8_off.assign(nsteps + 1, 0);
+    // Fused steps: the tasks are made on the device (build_sweep8_kernel) from one SweepSeg per (leaf, step); the host counts them
+    // per step -- a leaf of nt routed rows has ceil(ceil(nt / 16) / 8) tasks in each of its fused steps -- and says where each
+    // pair's tasks start.  Classic steps: the leaves that have them, per step (few: the largest leaves of a many-leaf model,
+    // all leaves beyond the shallow steps of a model with few).
+    std::vector<SweepSeg> segs;
+    std::vector<std::vector<int>> classic((size_t)nsteps);
+    std::vector<ZeroRange> zr;
+    {
+        std::vector<int> cnt8((size_t)nsteps, 0);
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.nt == 0) continue;
+            const int nt8 = ((lf.nt + 15) / 16 + 7) / 8;
+            bool any_classic = false;
+            for (int k = 0; k < lf.nb; ++k) {
+                if (fused_at(l, k)) {
+                    cnt8[(size_t)k] += nt8;
+                } else {
+                    classic[(size_t)k].push_back(l);
+                    any_classic = true;
+                }
+            }
+            // the update / panel-solve tiles of the classic steps read and write whole 128-row tiles: the rows beyond the routed
+            // ones must be zeros (the Gram kernel writes data rows only, gram_half_tile).  Fused tasks touch the 16-row blocks
+            // that hold data and nothing else: a leaf without classic steps needs no zeros (at depth 4: 9.6 GB not cleared)
+            if (any_classic) zr.push_back(ZeroRange{c->h_leaves[l].Vt, (size_t)lf.ntpad * (size_t)lf.npad});
+        }
+        for (int k = 0; k < nsteps; ++k) c->psweep8_off[(size_t)k + 1] = c->psweep8_off[(size_t)k] + cnt8[(size_t)k];
+        std::vector<int> cursor((size_t)nsteps, 0);
+        segs.reserve((size_t)L * 4);
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.nt == 0) continue;
+            const int nt8 = ((lf.nt + 15) / 16 + 7) / 8;
+            for (int k = 0; k < lf.nb; ++k)
+                if (fused_at(l, k)) {
+                    SweepSeg sg{};
+                    sg.leaf = l;
+                    sg.k = k;
+                    sg.src0 = cursor[(size_t)k];
+                    sg.begin = c->psweep8_off[(size_t)k];
+                    sg.n = cnt8[(size_t)k];
+                    segs.push_back(sg);
+                    cursor[(size_t)k] += nt8;
+                }
+        }
+    }
     for (int k = 0; k < nsteps; ++k) {
         c->pupd_off[k] = (int)U.upd.size();
         c->pred_off[k] = (int)U.red.size();
         c->ptrsm_off[k] = (int)trsm.size();
-        c->psweep8_off[k] = (int)sweep8.size();
         std::vector<TileTask> tiles;
-        for (int l = 0; l < L; ++l) {
+        for (int l : classic[(size_t)k]) {
             const LeafHost& lf = c->leaves[l];
-            if (lf.nt == 0 || lf.nb <= k) continue;
             const LeafDev& d = c->h_leaves[l];
-            if (fused_at(l, k)) {
-                for (int r = 0; r < lf.nt; r += 16) {
-                    RowBlock b{};
-                    b.A = d.Vt + r;
-                    b.C = d.Vt + r + (size_t)k * TB * lf.ntpad;
-                    b.gx = d.Xtg + r;
-                    b.lda = b.ldc = b.glda = lf.ntpad;
-                    b.nvalid = std::min(16, lf.nt - r);
-                    b.wi = d.macc + r;                  // predictive mean and variance ride along
-                    b.sq = d.sacc + r;
-                    blocks8.push_back(b);
-                }
-                push_fused8_tasks(sweep8, blocks8, d, lf, k);
-                continue;
-            }
             for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
                 double* tile = d.Vt + (size_t)ti * TB + (size_t)k * TB * lf.ntpad;
                 if (k > 0) {
@@ -2322,17 +2380,28 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
             }
         }
         U.add_step(tiles, k * TB);
-        std::vector<int> unused(sweep8.size());         // the tasks of a leaf share its B panel and L_kk: one XCD
-        xcd_permute(sweep8, unused, (size_t)c->psweep8_off[k], sweep8.size(), c->xcd_order);
     }
     c->pupd_off[nsteps] = (int)U.upd.size();
     c->pred_off[nsteps] = (int)U.red.size();
     c->ptrsm_off[nsteps] = (int)trsm.size();
-    c->psweep8_off[nsteps] = (int)sweep8.size();
     hl.lap("set_test: task uploads");
-    if (int rc = dev_upload(c, c->psweep8, sweep8)) return rc;
-    if (U.max_slabs)
-        if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
+    if (int rc = dev_upload(c, c->psegs, segs)) return rc;
+    if (int rc = dev_reserve(c, c->psweep8, (size_t)c->psweep8_off[(size_t)nsteps])) return rc;
+    if (!segs.empty())
+        build_sweep8_kernel<<<(unsigned)((segs.size() + 127) / 128), 128, 0, c->stream>>>(c->psegs.p, (int)segs.size(), c->d_leaves, c->psweep8.p,
+                                                                                        c->xcd_order ? 1 : 0);
+    if (int rc = dev_upload(c, c->pzero, zr)) return rc;
+    if (!zr.empty()) zero_ranges_kernel<<<dim3(128, (unsigned)zr.size()), 256, 0, c->stream>>>(c->pzero.p);
+    HIPCHK(c, hipGetLastError());
+    if (U.max_slabs) {
+        if (c->pool_base) {
+            if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
+        } else if (!c->slabP || c->cap_slabP < U.max_slabs * TB * TB) {
+            arena_put(c, c->slabP);
+            if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
+            c->cap_slabP = U.max_slabs * TB * TB;
+        }
+    }
     U.bind(c->slabP);
     if (int rc = dev_upload(c, c->pupd, U.upd)) return rc;
     if (int rc = dev_upload(c, c->pred, U.red)) return rc;
@@ -2355,6 +2424,195 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     c->vt_valid = false;
     return 0;
 }
+}  // namespace
+
+extern "C" {
+
+int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* route_ptr, const int64_t* route_idx) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_test before set_leaves");
+    if (!Xt || n_t <= 0 || !route_ptr) return fail(c, DSMGP_E_ARG, "set_test: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HostLog hl_total("set_test");
+    if (!c->plan_ready)
+        if (int rc = build_plan(c)) return rc;
+    HostLog hl("set_test: free old");
+    free_test(c, true);     // the K_tn arena of the set this one replaces is kept for it (spareVt)
+    hl.lap("set_test: validate");
+    const int L = c->L;
+    if (route_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "route_ptr[0] must be 0");
+    const int64_t total = route_ptr[L];
+    if (total > 0 && !route_idx) return fail(c, DSMGP_E_ARG, "route_idx is NULL");
+    for (int l = 0; l < L; ++l)
+        if (route_ptr[l + 1] < route_ptr[l]) return fail(c, DSMGP_E_ARG, "route_ptr must be non-decreasing");
+    for (int64_t i = 0; i < total; ++i)
+        if (route_idx[i] < 0 || route_idx[i] >= n_t) return fail(c, DSMGP_E_ARG, "route index out of range");
+    c->n_t = n_t;
+    c->route_total = total;
+    c->route_ptr.assign(route_ptr, route_ptr + L + 1);
+    hl.lap("set_test: uploads + row index");
+    if (int rc = dev_grow(c, c->dXt, c->cap_dXt, (size_t)n_t * c->D)) return rc;
+    HIPCHK(c, hipMemcpy(c->dXt, Xt, (size_t)n_t * c->D * sizeof(double), hipMemcpyHostToDevice));
+    if (int rc = dev_grow(c, c->d_route_ptr, c->cap_route_ptr, (size_t)L + 1)) return rc;
+    HIPCHK(c, hipMemcpy(c->d_route_ptr, route_ptr, (L + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (int rc = dev_grow(c, c->d_route_idx, c->cap_route_idx, (size_t)total)) return rc;
+    if (total) HIPCHK(c, hipMemcpy(c->d_route_idx, route_idx, total * sizeof(int64_t), hipMemcpyHostToDevice));
+    {
+        // per test row, the (leaf, row) entries that carry its moments, in ascending entry order (= leaf order):
+        // the index agg_partial_kernel walks
+        if (total > (int64_t)INT32_MAX) return fail(c, DSMGP_E_ARG, "set_test: more than 2^31 routed rows");
+        std::vector<int64_t> rptr((size_t)n_t + 1, 0);
+        for (int64_t i = 0; i < total; ++i) rptr[route_idx[i] + 1]++;
+        for (int64_t r = 0; r < n_t; ++r) rptr[r + 1] += rptr[r];
+        std::vector<int32_t> rent((size_t)std::max<int64_t>(1, total)), eleaf((size_t)std::max<int64_t>(1, total));
+        std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+        for (int l = 0; l < L; ++l)
+            for (int64_t i = route_ptr[l]; i < route_ptr[l + 1]; ++i) {
+                rent[fill[route_idx[i]]++] = (int32_t)i;
+                eleaf[i] = l;
+            }
+        if (int rc = dev_grow(c, c->d_row_ptr, c->cap_row_ptr, (size_t)n_t + 1)) return rc;
+        if (int rc = dev_grow(c, c->d_row_ent, c->cap_row_ent, rent.size())) return rc;
+        if (int rc = dev_grow(c, c->d_ent_leaf, c->cap_ent_leaf, eleaf.size())) return rc;
+        HIPCHK(c, hipMemcpy(c->d_row_ptr, rptr.data(), rptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_row_ent, rent.data(), rent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_ent_leaf, eleaf.data(), eleaf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return register_test(c, hl);
+}
+
+
+// ---- routing on the device --------------------------------------------------------------------------------------------------
+int dsmgp_set_tree(dsmgp_ctx* c, int64_t n_nodes, const int8_t* kind, const int64_t* first_child, const int64_t* n_child,
+                   const int64_t* split_dim, const double* thr, int64_t thr_ld, const int64_t* leaf_id) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_tree before set_leaves");
+    if (n_nodes <= 0 || n_nodes > (int64_t)INT32_MAX || !kind || !first_child || !n_child || !split_dim || !thr || !leaf_id || thr_ld <= 0)
+        return fail(c, DSMGP_E_ARG, "set_tree: bad arguments");
+    std::vector<int32_t> first((size_t)n_nodes), nch((size_t)n_nodes), sdim((size_t)n_nodes), leaf((size_t)n_nodes), need((size_t)n_nodes, 0);
+    int max_leaf = -1;
+    for (int64_t i = 0; i < n_nodes; ++i) {
+        if (kind[i] < 0 || kind[i] > 2) return fail(c, DSMGP_E_ARG, "set_tree: unknown node kind");
+        if (kind[i] == 0) {
+            if (leaf_id[i] < -1 || leaf_id[i] >= c->L) return fail(c, DSMGP_E_ARG, "set_tree: a region names a leaf outside the leaf table");
+            max_leaf = std::max(max_leaf, (int)leaf_id[i]);
+        } else if (n_child[i] <= 0 || first_child[i] <= i || first_child[i] + n_child[i] > n_nodes) {
+            return fail(c, DSMGP_E_ARG, "set_tree: children must follow their parent, consecutively");
+        }
+        if (kind[i] == 1 && (n_child[i] > thr_ld || split_dim[i] < 0 || split_dim[i] >= c->D))
+            return fail(c, DSMGP_E_ARG, "set_tree: a split node needs a threshold per child and a split dimension below D");
+        first[(size_t)i] = (int32_t)first_child[i];
+        nch[(size_t)i] = (int32_t)n_child[i];
+        sdim[(size_t)i] = (int32_t)split_dim[i];
+        leaf[(size_t)i] = kind[i] == 0 ? (int32_t)leaf_id[i] : -1;
+    }
+    // pending nodes of a row's depth-first walk (route_walk_row's stack)
+    const int stack_need = route_stack_need(n_nodes, kind, first.data(), nch.data(), need.data());
+    if (stack_need > ROUTE_STACK)
+        return fail(c, DSMGP_E_ARG, "set_tree: the tree needs " + std::to_string(stack_need) + " pending nodes per row, the walk holds " +
+                                        std::to_string(ROUTE_STACK));
+    HIPCHK(c, hipSetDevice(c->device));
+    free_tree(c);
+    auto up = [&](auto*& dst, const auto* src, size_t n) -> int {
+        using T = std::remove_cv_t<std::remove_pointer_t<std::remove_reference_t<decltype(dst)>>>;
+        T* p = nullptr;
+        HIPCHK(c, hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
+        dst = p;
+        HIPCHK(c, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (int rc = up(c->rtree.kind, kind, (size_t)n_nodes)) return rc;
+    if (int rc = up(c->rtree.first, first.data(), (size_t)n_nodes)) return rc;
+    if (int rc = up(c->rtree.nchild, nch.data(), (size_t)n_nodes)) return rc;
+    if (int rc = up(c->rtree.sdim, sdim.data(), (size_t)n_nodes)) return rc;
+    if (int rc = up(c->rtree.leaf, leaf.data(), (size_t)n_nodes)) return rc;
+    if (int rc = up(c->rtree.thr, thr, (size_t)n_nodes * (size_t)thr_ld)) return rc;
+    c->rtree.thr_ld = (int)thr_ld;
+    c->rtree_nodes = n_nodes;
+    c->rtree_max_leaf = max_leaf;
+    c->rtree_ready = true;
+    return 0;
+}
+
+int dsmgp_set_test_routed(dsmgp_ctx* c, const double* Xt, int64_t n_t) {
+    if (!c) return DSMGP_E_ARG;
+    if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_test before set_leaves");
+    if (!c->rtree_ready) return fail(c, DSMGP_E_STATE, "set_test_routed before set_tree");
+    if (!Xt || n_t <= 0) return fail(c, DSMGP_E_ARG, "set_test_routed: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HostLog hl_total("set_test_routed");
+    if (!c->plan_ready)
+        if (int rc = build_plan(c)) return rc;
+    HostLog hl("set_test: free old");
+    free_test(c, true);
+    hl.lap("set_test: route on the device");
+    const int L = c->L;
+    const int64_t wpl = (n_t + 31) / 32;
+    const size_t nbits = (size_t)L * (size_t)wpl;
+    if (nbits * 8 > (size_t(8) << 30)) return fail(c, DSMGP_E_NOMEM, "set_test_routed: routing bitmap above 8 GiB; route on the host (dsmgp_set_test)");
+    const size_t ncounts = (size_t)n_t + (size_t)L + 1;
+    if (ncounts > c->rws_counts_cap) {
+        dev_free(c->rws_counts);
+        c->rws_counts_cap = ncounts + ncounts / 4;
+        HIPCHK(c, hipMalloc(&c->rws_counts, c->rws_counts_cap * sizeof(int32_t)));
+    }
+    if (2 * nbits > c->rws_bits_cap) {
+        dev_free(c->rws_bits);
+        c->rws_bits_cap = 2 * nbits + nbits / 2;
+        HIPCHK(c, hipMalloc(&c->rws_bits, c->rws_bits_cap * sizeof(uint32_t)));
+    }
+    int32_t* row_cnt = c->rws_counts;
+    int32_t* leaf_cnt = row_cnt + n_t;
+    int* outside = reinterpret_cast<int*>(leaf_cnt + L);
+    uint32_t* bitmap = c->rws_bits;
+    uint32_t* wprefix = bitmap + nbits;
+    if (int rc = dev_grow(c, c->dXt, c->cap_dXt, (size_t)n_t * c->D)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dXt, Xt, (size_t)n_t * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (int rc = dev_grow(c, c->d_route_ptr, c->cap_route_ptr, (size_t)L + 1)) return rc;
+    if (int rc = dev_grow(c, c->d_row_ptr, c->cap_row_ptr, (size_t)n_t + 1)) return rc;
+    HIPCHK(c, hipMemsetAsync(bitmap, 0, nbits * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(outside, 0, sizeof(int), c->stream));
+    const unsigned gr = (unsigned)((n_t + 255) / 256);
+    route_walk_kernel<false><<<gr, 256, 0, c->stream>>>(c->rtree, c->dXt, n_t, row_cnt, bitmap, wpl, outside, nullptr, nullptr, nullptr, nullptr);
+    scan_counts_kernel<<<1, 1024, 0, c->stream>>>(row_cnt, n_t, c->d_row_ptr);
+    route_rank_kernel<<<L, 256, 0, c->stream>>>(bitmap, wpl, wprefix, leaf_cnt);
+    scan_counts_kernel<<<1, 1024, 0, c->stream>>>(leaf_cnt, (int64_t)L, c->d_route_ptr);
+    HIPCHK(c, hipGetLastError());
+    c->route_ptr.assign((size_t)L + 1, 0);
+    int flag = 0;
+    HIPCHK(c, hipMemcpyAsync(c->route_ptr.data(), c->d_route_ptr, ((size_t)L + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&flag, outside, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (flag != 0) {
+        free_test(c);
+        return fail(c, DSMGP_E_ARG, "set_test_routed: a test row lies outside the region of a split node (the reference loops forever there)");
+    }
+    const int64_t total = c->route_ptr[(size_t)L];
+    if (total > (int64_t)INT32_MAX) {
+        free_test(c);
+        return fail(c, DSMGP_E_ARG, "set_test: more than 2^31 routed rows");
+    }
+    c->n_t = n_t;
+    c->route_total = total;
+    if (int rc = dev_grow(c, c->d_route_idx, c->cap_route_idx, (size_t)total)) return rc;
+    if (int rc = dev_grow(c, c->d_row_ent, c->cap_row_ent, (size_t)total)) return rc;
+    if (int rc = dev_grow(c, c->d_ent_leaf, c->cap_ent_leaf, (size_t)total)) return rc;
+    route_fill_kernel<<<L, 256, 0, c->stream>>>(bitmap, wpl, wprefix, c->d_route_ptr, c->d_route_idx, c->d_ent_leaf);
+    route_walk_kernel<true><<<gr, 256, 0, c->stream>>>(c->rtree, c->dXt, n_t, nullptr, bitmap, wpl, nullptr, c->d_row_ptr, c->d_route_ptr, wprefix,
+                                                       c->d_row_ent);
+    HIPCHK(c, hipGetLastError());
+    return register_test(c, hl);
+}
+
+int dsmgp_routes(dsmgp_ctx* c, int64_t* route_ptr, int64_t* route_idx) {
+    if (!c) return DSMGP_E_ARG;
+    if (!c->test_ready) return fail(c, DSMGP_E_STATE, "routes before set_test");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (route_ptr) std::memcpy(route_ptr, c->route_ptr.data(), ((size_t)c->L + 1) * sizeof(int64_t));
+    if (route_idx && c->route_total)
+        HIPCHK(c, hipMemcpy(route_idx, c->d_route_idx, (size_t)c->route_total * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     if (!c) return DSMGP_E_ARG;
@@ -2363,11 +2621,13 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 6; i < 10; ++i) c->timings[i] = 0.0;
     c->timings[12] = 0.0;
+    HostLog hl("predict_run: events");
     PhaseTimer pt(c);
     EventPair ev;
     HIPCHK(c, ev.init());
     const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
+    hl.lap("predict_run: enqueue");
     if (c->ptasks.count) {
         const bool standalone = !c->vt_valid;
         if (standalone) {
@@ -2417,7 +2677,9 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(t1, c->stream));
+    hl.lap("predict_run: wait");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    hl.done();
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
     pt.collect();
@@ -2469,13 +2731,9 @@ int dsmgp_aggregate_partial(dsmgp_ctx* c, int32_t family, const double* leaf_coe
     const int G = family == AGG_RBCM ? n_groups : 0;
     const int W = agg_width(family, G);
     const size_t need = (size_t)W * (size_t)c->n_t;
-    if (need > c->agg_part_cap) {
-        dev_free(c->d_agg_part);
-        HIPCHK(c, hipMalloc(&c->d_agg_part, need * sizeof(double)));
-        c->agg_part_cap = need;
-    }
-    if (!c->d_agg_coef) HIPCHK(c, hipMalloc(&c->d_agg_coef, (size_t)L * sizeof(double)));
-    if (!c->d_agg_group) HIPCHK(c, hipMalloc(&c->d_agg_group, (size_t)L * sizeof(int32_t)));
+    if (int rc = dev_grow(c, c->d_agg_part, c->agg_part_cap, need)) return rc;
+    if (int rc = dev_grow(c, c->d_agg_coef, c->cap_agg_coef, (size_t)L)) return rc;
+    if (int rc = dev_grow(c, c->d_agg_group, c->cap_agg_group, (size_t)L)) return rc;
     if (leaf_coef) HIPCHK(c, hipMemcpyAsync(c->d_agg_coef, leaf_coef, (size_t)L * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (family == AGG_RBCM)
         HIPCHK(c, hipMemcpyAsync(c->d_agg_group, leaf_group, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -2514,7 +2772,7 @@ int dsmgp_aggregate_finish(dsmgp_ctx* c, const double* partial_in, int32_t plain
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nt = (size_t)c->n_t;
     const size_t nblk = (nt + 255) / 256;
-    if (!c->d_agg_out) HIPCHK(c, hipMalloc(&c->d_agg_out, (3 * nt + 3 * nblk + 8) * sizeof(double)));
+    if (int rc = dev_grow(c, c->d_agg_out, c->cap_agg_out, 3 * nt + 3 * nblk + 8)) return rc;
     if (partial_in)   // sums over all ranks / contexts, added by the caller
         HIPCHK(c, hipMemcpyAsync(c->d_agg_part, partial_in, (size_t)c->agg_W * nt * sizeof(double), hipMemcpyHostToDevice, c->stream));
     agg_finish_kernel<<<(unsigned)nblk, 256, 0, c->stream>>>(c->d_agg_part, c->n_t, c->agg_family, c->agg_G, plain ? 1 : 0,

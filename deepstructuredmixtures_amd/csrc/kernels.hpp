@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "route_walk.hpp"
 
 namespace dsmgp {
 
@@ -2174,6 +2175,117 @@ __global__ void gather_test_kernel(const LeafDev* __restrict__ leaves, const int
     const int64_t g = valid ? route_idx[route_ptr[leaf0 + blockIdx.y] + r] : 0;
     double* xg = const_cast<double*>(lf.Xtg);
     for (int d = 0; d < D; ++d) xg[r + (size_t)d * lf.ntpad] = valid ? Xt[g + (size_t)d * n_t] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Routing of test rows on the device (src/common.jl:101-122,181-196,275-292: a sum node forwards a row to every child, a split
+// node to the first child k with x[d] <= s_k): predict(model, x) on rows the model has not seen spent more host time walking
+// the tree and building index lists than the device spent on the prediction sweep (depth 4: 16 + 32 ms around 16 ms).
+// The tree is a few hundred KB of flat arrays (dsmgp_set_tree); one thread per test row walks it depth-first, children in
+// order -- leaves are numbered depth-first, so a row meets its leaves in ascending leaf order.  Two walks and a bitmap make the
+// result independent of thread timing (no sort, no order-dependent atomics):
+//   walk 1   per row: number of leaves reached; bit (leaf, row) set in a bitmap of L x ceil(n_t / 32) words
+//   scan     row_ptr (entries of every row, for the aggregation)
+//   rank     per leaf: running bit counts of its bitmap words, its row count; scan -> route_ptr
+//   fill     per leaf: the set bits in order = its rows ascending -> route_idx, ent_leaf
+//   walk 2   per row, i-th leaf reached: entry position = route_ptr[leaf] + bits below the row's in that leaf's bitmap -> row_ent
+// Equal, entry by entry, to what dsmgp_set_test builds on the host from dsmgp_tree_route's lists.
+template <bool FILL>
+__global__ __launch_bounds__(256) void route_walk_kernel(RouteTree t, const double* __restrict__ x, int64_t n_t,
+                                                         int32_t* __restrict__ row_cnt, uint32_t* __restrict__ bitmap, int64_t wpl,
+                                                         int* __restrict__ outside, const int64_t* __restrict__ row_ptr,
+                                                         const int64_t* __restrict__ route_ptr, const uint32_t* __restrict__ wprefix,
+                                                         int32_t* __restrict__ row_ent) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_t) return;
+    const uint32_t bit = 1u << (r & 31);
+    const int64_t w = r >> 5;
+    const int64_t base = FILL ? row_ptr[r] : 0;
+    const int cnt = route_walk_row(t, x, 1, n_t, r, [&](int l, int i) {      // (route_walk.hpp: the walk the host routine runs too)
+        const size_t o = (size_t)l * (size_t)wpl + (size_t)w;
+        if (FILL) row_ent[base + i] = (int32_t)(route_ptr[l] + (int64_t)wprefix[o] + (int64_t)__popc(bitmap[o] & (bit - 1u)));
+        else atomicOr(&bitmap[o], bit);
+    });
+    if (!FILL) {
+        if (cnt < 0) atomicExch(outside, 1);
+        row_cnt[r] = cnt < 0 ? 0 : cnt;
+    }
+}
+
+// out[0] = 0, out[i + 1] = in[0] + ... + in[i]: one workgroup walks the array in chunks of 1024 with a running carry (the arrays
+// here are the per-row and per-leaf counts: 10^4 .. 10^6 entries, microseconds)
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+    __shared__ int64_t buf[1024];
+    __shared__ int64_t carry;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        carry = 0;
+        out[0] = 0;
+    }
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+        const int64_t i = i0 + t;
+        buf[t] = i < n ? (int64_t)in[i] : 0;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            const int64_t v = t >= s ? buf[t - s] : 0;
+            __syncthreads();
+            buf[t] += v;
+            __syncthreads();
+        }
+        if (i < n) out[i + 1] = carry + buf[t];
+        __syncthreads();
+        if (t == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+}
+
+// per leaf (one workgroup): wprefix[w] = set bits in the leaf's bitmap words before word w; leaf_cnt = all of them
+__global__ __launch_bounds__(256) void route_rank_kernel(const uint32_t* __restrict__ bitmap, int64_t wpl, uint32_t* __restrict__ wprefix,
+                                                         int32_t* __restrict__ leaf_cnt) {
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t carry;
+    const int t = threadIdx.x;
+    const size_t o = (size_t)blockIdx.x * (size_t)wpl;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int64_t w0 = 0; w0 < wpl; w0 += 256) {
+        const int64_t w = w0 + t;
+        const uint32_t c = w < wpl ? (uint32_t)__popc(bitmap[o + w]) : 0u;
+        buf[t] = c;
+        __syncthreads();
+        for (int s = 1; s < 256; s <<= 1) {
+            const uint32_t v = t >= s ? buf[t - s] : 0u;
+            __syncthreads();
+            buf[t] += v;
+            __syncthreads();
+        }
+        if (w < wpl) wprefix[o + w] = carry + buf[t] - c;
+        __syncthreads();
+        if (t == 255) carry += buf[255];
+        __syncthreads();
+    }
+    if (t == 0) leaf_cnt[blockIdx.x] = (int32_t)carry;
+}
+
+// per leaf (one workgroup): its rows, ascending, into the CSR; the leaf of every entry for the aggregation
+__global__ __launch_bounds__(256) void route_fill_kernel(const uint32_t* __restrict__ bitmap, int64_t wpl, const uint32_t* __restrict__ wprefix,
+                                                         const int64_t* __restrict__ route_ptr, int64_t* __restrict__ route_idx,
+                                                         int32_t* __restrict__ ent_leaf) {
+    const int l = blockIdx.x;
+    const size_t o = (size_t)l * (size_t)wpl;
+    const int64_t p0 = route_ptr[l];
+    for (int64_t w = threadIdx.x; w < wpl; w += blockDim.x) {
+        uint32_t bits = bitmap[o + w];
+        int64_t pos = p0 + (int64_t)wprefix[o + w];
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            route_idx[pos] = w * 32 + b;
+            ent_leaf[pos] = l;
+            ++pos;
+        }
+    }
 }
 
 // mll = -(y.alpha + 2 sum log L_ii + n log 2pi)/2   (src/gaussianprocess.jl:163), with y.alpha evaluated as z.z

@@ -420,6 +420,75 @@ __global__ __launch_bounds__(512, 4) void tile_fused8_kernel(const FusedTask8* _
     else tile_fused8_body<8>(task, smem, kp, D);
 }
 
+// The fused tile tasks of the standalone prediction sweep, made on the device.  predict(model, x) on rows the model has not seen
+// registers a new test set per call, and at depth 4 the host spent 20 ms writing 64k of these 576-byte tasks (37 MB, then a
+// copy for the XCD order, then the upload) in front of a 16 ms sweep.  Everything in a task follows from the leaf table in HBM
+// (LeafDev) and the leaf's row count: the host only decides which (leaf, block step) pairs run fused and where their tasks
+// start in the step's list (SweepSeg: 32 bytes per pair); one thread per pair writes the pair's tasks, straight to the
+// position xcd_permute would have moved them to (tasks of a leaf share its B panel and L_kk: they sit 8 apart, on one XCD).
+struct SweepSeg {
+    int leaf, k;          // leaf (index in the context's table) and block step
+    int src0;             // natural index, within the step's task range, of the pair's first task
+    int begin, n;         // the step's range in the task list
+    int pad[3];
+};
+static_assert(sizeof(SweepSeg) == 32, "SweepSeg layout");
+__host__ __device__ inline int xcd_slot(int src, int n, bool enable) {      // where xcd_permute (dsmgp_hip.cpp) puts natural index src
+    if (!enable || n < 16) return src;
+    const int q = n / 8, r = n % 8;
+    const int big = r * (q + 1);
+    const int x = src < big ? src / (q + 1) : r + (src - big) / q;
+    const int j = src < big ? src - x * (q + 1) : (src - big) - (x - r) * q;
+    return x + 8 * j;
+}
+__global__ __launch_bounds__(128) void build_sweep8_kernel(const SweepSeg* __restrict__ segs, int nseg, const LeafDev* __restrict__ leaves,
+                                                           FusedTask8* __restrict__ out, int xcd) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const SweepSeg sg = segs[s];
+    const LeafDev lf = leaves[sg.leaf];
+    const int k = sg.k;
+    const int nblk = (lf.nt + 15) >> 4, ntask = (nblk + 7) >> 3;
+    for (int t = 0; t < ntask; ++t) {
+        FusedTask8 f{};
+        f.B = lf.F + (size_t)k * TB;
+        f.Dinv = lf.Dinv + (size_t)k * TB * TB;
+        f.zk = lf.z + (size_t)k * TB;                   // every block of the sweep carries the riders (mean and variance sums)
+        f.gxb = lf.Xg + (size_t)k * TB;
+        f.ldb = f.gldb = lf.npad;
+        f.gnb = max(0, min(TB, lf.n - k * TB));
+        f.k1 = k * TB;
+        f.kid = lf.kid;
+        f.nblk = min(8, nblk - 8 * t);
+        for (int q = 0; q < f.nblk; ++q) {
+            const int r = 16 * (8 * t + q);
+            RowBlock& b = f.rb[q];
+            b.A = lf.Vt + r;
+            b.C = lf.Vt + r + (size_t)k * TB * lf.ntpad;
+            b.gx = lf.Xtg + r;
+            b.lda = b.ldc = b.glda = lf.ntpad;
+            b.nvalid = min(16, lf.nt - r);
+            b.wi = lf.macc + r;
+            b.sq = lf.sacc + r;
+        }
+        out[sg.begin + xcd_slot(sg.src0 + t, sg.n, xcd != 0)] = f;
+    }
+}
+
+// p[0 .. count) <- 0 for a list of ranges (the K_tn rows of the leaves whose sweep has classic steps: register_test)
+struct ZeroRange {
+    double* p;
+    size_t count;
+};
+__global__ __launch_bounds__(256) void zero_ranges_kernel(const ZeroRange* __restrict__ ranges) {
+    const ZeroRange zr = ranges[blockIdx.y];
+    const d2 zero = {0.0, 0.0};
+    d2* q = reinterpret_cast<d2*>(zr.p);                // arenas and leaf offsets are multiples of 128 doubles
+    const size_t n2 = zr.count / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) q[i] = zero;
+    if ((zr.count & 1) && blockIdx.x == 0 && threadIdx.x == 0) zr.p[zr.count - 1] = 0.0;
+}
+
 // Rows [r0, 128) of a block row of a factor over `ncols` columns <- 0 (build_plan: the padding rows below a leaf's last data rows)
 struct ZeroRowsTask {
     double* p;

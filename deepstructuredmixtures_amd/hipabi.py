@@ -44,6 +44,9 @@ SIGNATURES = {
     "dsmgp_set_hyper": (C.c_int, [_ctx, C.c_int32, C.c_int32, _dp, C.c_int32]),
     "dsmgp_fit": (C.c_int, [_ctx, _dp, _ip, _dp]),
     "dsmgp_set_test": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp]),
+    "dsmgp_set_tree": (C.c_int, [_ctx, C.c_int64, C.POINTER(C.c_int8), _lp, _lp, _lp, _dp, C.c_int64, _lp]),
+    "dsmgp_set_test_routed": (C.c_int, [_ctx, _dp, C.c_int64]),
+    "dsmgp_routes": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_predict_run": (C.c_int, [_ctx, _dp]),
     "dsmgp_predict_fetch": (C.c_int, [_ctx, _dp, _dp]),
     "dsmgp_predict_leaves": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp, _dp, _dp]),
@@ -238,6 +241,36 @@ class Context:
         self._chk(self.lib.dsmgp_set_test(self.h, px, Xt.shape[0], p0, p1))
         self.route_total = int(route_ptr[-1])
         self.n_t = int(Xt.shape[0])
+
+    def set_tree(self, kind, first_child, n_child, split_dim, thr, leaf_local):
+        """The model's tree as flat arrays (tree._RouteIndex) with `leaf_local` = index of every region in THIS context's leaf
+        table (-1: held by another rank): what `set_test_routed` walks on the device."""
+        kind = np.ascontiguousarray(kind, dtype=np.int8)
+        first_child, p1 = _i64(first_child)
+        n_child, p2 = _i64(n_child)
+        split_dim, p3 = _i64(split_dim)
+        thr = np.ascontiguousarray(thr, dtype=np.float64)
+        leaf_local, p5 = _i64(leaf_local)
+        self._chk(self.lib.dsmgp_set_tree(self.h, int(kind.size), kind.ctypes.data_as(C.POINTER(C.c_int8)), p1, p2, p3,
+                                          thr.ctypes.data_as(_dp), int(thr.shape[1]), p5))
+
+    def set_test_routed(self, Xt):
+        """`set_test` with the routing of predict done on the device (needs `set_tree`)."""
+        Xt, px = _f64_fortran(Xt)
+        self._chk(self.lib.dsmgp_set_test_routed(self.h, px, Xt.shape[0]))
+        self.n_t = int(Xt.shape[0])
+        ptr = np.zeros(self.L + 1, dtype=np.int64)
+        self._chk(self.lib.dsmgp_routes(self.h, ptr.ctypes.data_as(_lp), None))
+        self.route_total = int(ptr[-1])
+        return ptr
+
+    def routes(self):
+        """(route_ptr, route_idx) of the registered test set."""
+        ptr = np.zeros(self.L + 1, dtype=np.int64)
+        self._chk(self.lib.dsmgp_routes(self.h, ptr.ctypes.data_as(_lp), None))
+        idx = np.zeros(max(1, int(ptr[-1])), dtype=np.int64)
+        self._chk(self.lib.dsmgp_routes(self.h, ptr.ctypes.data_as(_lp), idx.ctypes.data_as(_lp)))
+        return ptr, idx[:int(ptr[-1])]
 
     def predict_run(self):
         sec = C.c_double(0.0)

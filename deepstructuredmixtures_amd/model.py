@@ -14,7 +14,7 @@ import numpy as np
 from . import hipabi
 from .kernels import IsoSE, ConstMean, KIND_ISO_SE, KIND_ARD_SE, KIND_ISO_LINEAR
 from .tree import (DSMGPConfig, GPSumNode, build_tree, get_leaves, get_overlap, obs_table, share_schedule, share_decisions,
-                   share_census, route, route_all, get_child, ordered_nodes, SHARE_COPY, SHARE_FULL, SHARE_PREFIX)
+                   share_census, route, route_all, route_index, get_child, ordered_nodes, SHARE_COPY, SHARE_FULL, SHARE_PREFIX)
 from . import dist as _dist
 
 EPS = 1e-8  # `const ϵ` of src/DeepStructuredMixtures.jl:27
@@ -153,6 +153,7 @@ class Model:
         self._uploaded = False
         self._schedule = None
         self._route_cache = None
+        self._device_routing = False  # the context holds the tree (dsmgp_set_tree): predict routes its rows on the device
         self._tindex = None
         self.share_op = None          # per leaf: what the last fit did (SHARE_FULL / COPY / PREFIX)
         self.share_branch = None      # per leaf: the arm of the reference's fit! (tree.BRANCH_*)
@@ -253,6 +254,24 @@ class Model:
         self._uploaded = True
         self._schedule = key
         self._route_cache = None      # set_leaves dropped the device-side test set
+        self._register_tree(loc)
+
+    def _register_tree(self, loc):
+        """The routing of `predict` (`src/common.jl:101-122,181-196,275-292`) on the device: hand the context the tree as flat
+        arrays, with every region's index in THIS rank's leaf table (-1: held elsewhere).  DSMGP models on a plain context;
+        anything else (and a tree deeper than the device walk's stack) keeps routing on the host."""
+        self._device_routing = False
+        if self.family != "dsmgp" or self.root.kind == "gp" or not hasattr(self.ctx, "set_tree"):
+            return
+        ri = route_index(self.root)
+        g2l = np.full(self.L, -1, dtype=np.int64)
+        g2l[np.asarray(loc, dtype=np.int64)] = np.arange(len(loc))
+        leaf_local = np.where(ri.leaf >= 0, g2l[np.maximum(ri.leaf, 0)], -1)
+        try:
+            self.ctx.set_tree(ri.kind, ri.first, ri.nchild, ri.sdim, ri.thr, leaf_local)
+            self._device_routing = True
+        except hipabi.DsmgpError:
+            pass
 
 
 class DSMGP(Model):
@@ -797,12 +816,15 @@ def finetune(model, optim=None, *, iterations=1000, lam=0.5, tau=0.05, verbose=F
 
 # ------------------------------------------------------------------------------------ predict
 
-def _routing(model, xt):
+def _routing(model, xt, host_routes=True):
     """Routes of one test set, cached on the model: which rows each leaf predicts (CSR over all leaves and over
-    this rank's leaves) and, filled lazily by the aggregation, the child masks of every split node."""
+    this rank's leaves) and, filled lazily by the aggregation, the child masks of every split node.  With
+    host_routes=False only the cache entry is made: the context routes the rows itself (`set_test_routed`)."""
     key = (xt.shape, hash(xt.tobytes()))
     rc = model._route_cache
     if rc is None or rc["key"] != key:
+        rc = model._route_cache = dict(key=key, ptr=None, idx=None, lptr=None, lidx=None, masks={}, uploaded=False)
+    if host_routes and rc["ptr"] is None:
         ptr, idx = route(model.root, xt) if model.family == "dsmgp" else route_all(model.root, xt.shape[0])
         loc = np.asarray(model.shard.local, dtype=np.int64)
         if loc.size == ptr.size - 1 and np.array_equal(loc, np.arange(loc.size)):
@@ -812,8 +834,21 @@ def _routing(model, xt):
             lptr = np.zeros(loc.size + 1, dtype=np.int64)
             np.cumsum(cnt, out=lptr[1:])
             lidx = idx[np.repeat(ptr[loc] - lptr[:-1], cnt) + np.arange(lptr[-1])] if loc.size else np.zeros(0, np.int64)
-        rc = model._route_cache = dict(key=key, ptr=ptr, idx=idx, lptr=lptr, lidx=lidx, masks={}, uploaded=False)
+        rc.update(ptr=ptr, idx=idx, lptr=lptr, lidx=lidx)
     return rc
+
+
+def _register_rows(model, xt, rc):
+    """The test rows -> the context (once per test matrix): routed on the device where the context holds the tree."""
+    if rc["uploaded"]:
+        return
+    if model._device_routing:
+        model.ctx.set_test_routed(xt)
+    else:
+        if rc["ptr"] is None:
+            _routing(model, xt)
+        model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
+    rc["uploaded"] = True
 
 
 def _leaf_moments(model, xt, rc):
@@ -822,7 +857,7 @@ def _leaf_moments(model, xt, rc):
     if len(model.shard.local) == 0:
         return model.shard.gather_ragged_pair(np.zeros(0), np.zeros(0), counts)
     if not rc["uploaded"]:
-        model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
+        model.ctx.set_test(xt, rc["lptr"], rc["lidx"])      # (the per-(leaf, row) moments come back aligned with THESE lists)
         rc["uploaded"] = True
     model.last_predict_seconds = model.ctx.predict_run()
     mu_l, var_l = model.ctx.predict_fetch()
@@ -839,10 +874,9 @@ def resident_test(model, xtest, tau=0.05):
     if xt.ndim == 1:
         xt = xt.reshape(-1, 1)
     model._upload(tau)
-    rc = _routing(model, xt)
-    if not rc["uploaded"] and len(model.shard.local):
-        model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
-        rc["uploaded"] = True
+    rc = _routing(model, xt, host_routes=not model._device_routing)
+    if len(model.shard.local):
+        _register_rows(model, xt, rc)
 
 
 def predict(model, xtest):
@@ -856,10 +890,11 @@ def predict(model, xtest):
     xt = np.asfortranarray(xtest, dtype=np.float64)
     if xt.ndim == 1:
         xt = xt.reshape(-1, 1)
-    rc = _routing(model, xt)
     model._scores_on_device = False
     if hasattr(_ctx_type(model), "aggregate_partial"):       # decided by the model's construction: the same on every rank
-        return _predict_device(model, xt, rc)
+        # (a rank that holds leaves and whose context holds the tree routes its rows on the device: no host lists at all)
+        return _predict_device(model, xt, _routing(model, xt, host_routes=not model._device_routing))
+    rc = _routing(model, xt)
     mu, var = _leaf_moments(model, xt, rc)
     if model.family == "dsmgp":
         return _aggregate_dsmgp_flat(model, xt.shape[0], rc, mu, var)
@@ -917,9 +952,7 @@ def _predict_device(model, xt, rc):
     loc = model.shard.local
     have = len(loc) > 0
     if have:
-        if not rc["uploaded"]:
-            model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
-            rc["uploaded"] = True
+        _register_rows(model, xt, rc)
         model.last_predict_seconds = model.ctx.predict_run()
     single = model.shard.world == 1 and isinstance(model.ctx, hipabi.Context) and model.shard.comm_ctx is None
     if single:      # one context holds every leaf: partial sums, finish and (later) scores never leave the device

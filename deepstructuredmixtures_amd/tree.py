@@ -595,6 +595,14 @@ class _RouteIndex:
         self.reach = reach[0]
 
 
+def route_index(root):
+    """The flat arrays of the tree (`_RouteIndex`), built on first use and kept on the root."""
+    ri = getattr(root, "_route_index", None)
+    if ri is None:
+        ri = root._route_index = _RouteIndex(root)
+    return ri
+
+
 def route(root, xt):
     """Which test rows each leaf is asked to predict: CSR (route_ptr, route_idx) in leaf order.
 
@@ -602,9 +610,7 @@ def route(root, xt):
     (`src/common.jl:181-196,275-292`).  Walked by the library's host routine on the flat arrays of the tree (`_RouteIndex`,
     built on first use); `route_recursive` is the literal recursion it is tested against."""
     from . import hipabi
-    ri = getattr(root, "_route_index", None)
-    if ri is None:
-        ri = root._route_index = _RouteIndex(root)
+    ri = route_index(root)
     return hipabi.tree_route(ri.kind, ri.first, ri.nchild, ri.sdim, ri.thr, ri.leaf, ri.n_leaves, xt, ri.reach)
 
 

@@ -101,6 +101,18 @@ int dsmgp_fit(dsmgp_ctx* ctx, double* mll_out /* L */, int32_t* info_out /* L */
 int dsmgp_set_joint(dsmgp_ctx* ctx, int32_t on);
 int dsmgp_set_test(dsmgp_ctx* ctx, const double* Xt /* n_t x D */, int64_t n_t,
                    const int64_t* route_ptr /* L+1 */, const int64_t* route_idx);
+/* predict(model, x) on rows the model has not seen (the reference's normal call, src/common.jl:304-307, src/plot.jl:40): the routing
+ * of src/common.jl:101-122,181-196,275-292 on the device.  dsmgp_set_tree registers the model's tree once per leaf table (flat
+ * arrays as dsmgp_tree_route takes them; leaf_id = index in THIS context's leaf table, -1 = a region another rank holds; a new
+ * leaf table or new training data drop it).  dsmgp_set_test_routed(Xt, n_t) then is dsmgp_set_test with the routes made on the
+ * device: one thread per row walks the tree, a bitmap per leaf turns the visits into the same CSR (rows ascending per leaf) and the
+ * same per-row entry index the host path builds -- entry by entry -- and only the L + 1 per-leaf offsets come back to the host
+ * (they size the K_tn arena and the sweep's task lists).  DSMGP_E_ARG: a row outside the region of a split node (NaN included).
+ * dsmgp_routes fetches the CSR of the registered test set (route_ptr: L + 1; route_idx: route_ptr[L] entries, may be NULL). */
+int dsmgp_set_tree(dsmgp_ctx* ctx, int64_t n_nodes, const int8_t* kind, const int64_t* first_child, const int64_t* n_child,
+                   const int64_t* split_dim, const double* thr, int64_t thr_ld, const int64_t* leaf_id);
+int dsmgp_set_test_routed(dsmgp_ctx* ctx, const double* Xt /* n_t x D */, int64_t n_t);
+int dsmgp_routes(dsmgp_ctx* ctx, int64_t* route_ptr /* L+1 */, int64_t* route_idx /* or NULL */);
 int dsmgp_predict_run(dsmgp_ctx* ctx, double* seconds);   /* device work only, inputs resident */
 int dsmgp_predict_fetch(dsmgp_ctx* ctx, double* mu_out, double* var_out);
 int dsmgp_predict_leaves(dsmgp_ctx* ctx, const double* Xt, int64_t n_t, const int64_t* route_ptr,

@@ -969,7 +969,7 @@ def test_device_aggregation_and_scores(family):
     assert np.allclose(mu, mo, rtol=RTOL, atol=1e-9), float(np.max(np.abs(mu - mo)))
     assert np.allclose(var, vo, rtol=RTOL, atol=1e-10), float(np.max(np.abs(var - vo) / vo))
     # host rules on the same moments
-    rc = m._route_cache
+    rc = pmodel._routing(m, np.asfortranarray(Xt))           # the host's lists (the context routed the rows itself: same CSR)
     mu_l, var_l = m.ctx.predict_fetch()
     if m.family == "dsmgp":
         mh, vh = pmodel._aggregate_dsmgp_flat(m, Xt.shape[0], rc, mu_l, var_l)
@@ -1872,3 +1872,66 @@ def test_test_set_replaced_between_a_joint_fit_and_its_first_use(ctx):
         assert np.max(np.abs(g[l] - go)) <= 1e-7 * max(1.0, float(np.max(np.abs(go)))), (l, g[l], go)
     ctx.predict_run()
     check_prediction(Xb)
+
+
+def test_device_routing_equals_the_host_routing_entry_by_entry():
+    """predict(model, x) on rows the model has not seen routes them on the device (dsmgp_set_tree + dsmgp_set_test_routed:
+    `src/common.jl:101-122,181-196,275-292` as one thread per row, the walk of csrc/route_walk.hpp that the host routine
+    dsmgp_tree_route runs too).  The CSR it leaves in HBM must be the host routine's, entry by entry -- complete and ragged
+    trees, kernel vectors, one input dimension, rows exactly ON thresholds, +-Inf coordinates -- and the prediction built on it
+    must equal, to the bit, the prediction of the host-routed registration (same entry index, same summation order).
+    A row outside every region (NaN) is refused; a shard that holds half of the leaves gets exactly its half."""
+    cases = [dict(N=3000, D=3, K=3, V=4, M=40, depth=3), dict(N=700, D=2, K=2, V=3, M=60, depth=4),
+             dict(N=500, D=1, K=3, V=4, M=10, depth=2), dict(N=2000, D=5, K=1, V=5, M=100, depth=2)]
+    for i, c in enumerate(cases):
+        X, y, Xt = regression_data(c["N"], c["D"], n_test=333, seed=900 + i)
+        kern = [dsm.IsoSE(np.log(0.4), 0.0), dsm.IsoLinear(0.0)] if i == 0 else dsm.IsoSE(np.log(0.4), 0.0)
+        m = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=kern, logNoise=np.log(0.2), seed=40 + i)
+        assert m._device_routing
+        node = m.root.children[0] if m.root.kind == "sum" else m.root
+        d = node.split[0][0]
+        on = np.repeat(Xt[:1], len(node.split) - 1, axis=0)
+        on[:, d] = [t for (_, t) in node.split[:-1]]                       # rows ON the thresholds: the child on the low side
+        inf = Xt[:2].copy()
+        inf[0, d], inf[1, d] = -np.inf, np.inf                             # the first child has no lower test, the last bound is +Inf
+        for xt in (Xt, np.vstack([Xt[:50], on, inf]), Xt[:1]):
+            hp, hi = ptree.route(m.root, xt)
+            dp = m.ctx.set_test_routed(xt)
+            gp_, gi = m.ctx.routes()
+            assert np.array_equal(dp, hp) and np.array_equal(gp_, hp) and np.array_equal(gi, hi)
+        dsm.update(m)
+        mu_d, var_d = dsm.predict(m, Xt)
+        m._device_routing, m._route_cache = False, None
+        mu_h, var_h = dsm.predict(m, Xt)
+        assert np.array_equal(mu_d, mu_h) and np.array_equal(var_d, var_h)
+        m._device_routing, m._route_cache = True, None
+        bad = Xt[:5].copy()
+        bad[3, d] = np.nan
+        with pytest.raises(hipabi.DsmgpError) as e:
+            dsm.predict(m, bad)
+        assert "outside" in str(e.value)
+        mu_again, _ = dsm.predict(m, Xt)                                   # the refused registration left nothing behind
+        assert np.array_equal(mu_again, mu_d)
+    # half of the leaves (what one of two ranks holds): regions of the other half carry -1 and are skipped
+    ri = ptree.route_index(m.root)
+    loc = np.arange(0, m.L, 2)
+    lv = [m.leaves[j] for j in loc]
+    ptr, idx = ptree.obs_table(lv)
+    c2 = hipabi.Context(0)
+    c2.set_train(X, y)
+    c2.set_leaves(ptr, idx, [lf.kernelid for lf in lv], [lf.mean.m for lf in lv])
+    g2l = np.full(m.L, -1, dtype=np.int64)
+    g2l[loc] = np.arange(loc.size)
+    c2.set_tree(ri.kind, ri.first, ri.nchild, ri.sdim, ri.thr, np.where(ri.leaf >= 0, g2l[np.maximum(ri.leaf, 0)], -1))
+    c2.set_test_routed(Xt)
+    p2, i2 = c2.routes()
+    hp, hi = ptree.route(m.root, Xt)
+    assert np.array_equal(np.diff(p2), np.diff(hp)[loc])
+    assert np.array_equal(i2, np.concatenate([hi[hp[j]:hp[j + 1]] for j in loc]))
+    with pytest.raises(hipabi.DsmgpError):                                 # a region naming a leaf beyond the table
+        c2.set_tree(ri.kind, ri.first, ri.nchild, ri.sdim, ri.thr, np.where(ri.leaf >= 0, ri.leaf, -1))
+    c2.set_leaves(ptr, idx, [lf.kernelid for lf in lv], [lf.mean.m for lf in lv])   # a new leaf table drops the tree
+    with pytest.raises(hipabi.DsmgpError) as e:
+        c2.set_test_routed(Xt)
+    assert "set_tree" in str(e.value)
+    c2.close()

@@ -872,6 +872,11 @@ def test_native_routing_equals_the_recursion():
         on[:, d] = [t for (_, t) in node.split[:-1]]
         a, b = ptree.route(m.root, on), ptree.route_recursive(m.root, on)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # +-Inf coordinates: the first child has no lower test, the last threshold of a split is its upper bound (+Inf at the root)
+        inf = np.repeat(Xt[:1], 2, axis=0)
+        inf[0, d], inf[1, d] = -np.inf, np.inf
+        a, b = ptree.route(m.root, inf), ptree.route_recursive(m.root, inf)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     lib = hipabi.load_library()
     ri = m.root._route_index
     lp, dp = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
