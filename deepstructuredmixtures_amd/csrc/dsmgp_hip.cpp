@@ -498,7 +498,7 @@ struct dsmgp_ctx {
     int gstride = 2;                // doubles per contraction task in d_gpart
     std::vector<int> grad_src;      // per leaf: the leaf whose contraction it shares (COPY leaf with the same mean), or -1
     double* d_gpart = nullptr;      // partial results: frob | graddot pairs | per-leaf dots
-    size_t gpart_count = 0;
+    size_t gpart_count = 0, gpart_cap = 0;
 
     // multi-GPU exchange over RCCL (dsmgp_comm_*, dsmgp_allgather): librccl.so is loaded on first use
     void* comm = nullptr;           // ncclComm_t
@@ -636,15 +636,16 @@ void drop_graphs(dsmgp_ctx* c) {
         }
 }
 
-// the task lists of the gradient pass (they depend on the set of active leaves); the L^-T arena stays
+// the task lists of the gradient pass (they depend on the set of active leaves): emptied, their allocations and the L^-T arena
+// stay -- finetune! changes the mask L times per iteration (src/finetuning.jl:34-57), and the lists that replace these fit into
+// the same buffers (dev_upload) instead of a hipFree + hipMalloc per list and pass
 void free_grad_lists(dsmgp_ctx* c) {
-    dev_free(c->gtrans);
-    dev_free(c->gupd);
-    dev_free(c->gtrsm);
-    dev_free(c->gred);
-    dev_free(c->gfrob);
-    dev_free(c->gdot);
-    dev_free(c->d_gpart);
+    dev_drop(c->gtrans, true);
+    dev_drop(c->gupd, true);
+    dev_drop(c->gtrsm, true);
+    dev_drop(c->gred, true);
+    dev_drop(c->gfrob, true);
+    dev_drop(c->gdot, true);
     c->grad_ready = false;
 }
 
@@ -659,6 +660,7 @@ void free_grad(dsmgp_ctx* c) {
     dev_free(c->gfrob);
     dev_free(c->gdot);
     dev_free(c->d_gpart);
+    c->gpart_cap = 0;
     c->grad_ready = false;
 }
 
@@ -3026,7 +3028,7 @@ int build_grad_plan(dsmgp_ctx* c) {
         return fail(c, DSMGP_E_ARG, "ArdSE length-scale gradients need D <= " + std::to_string(GRADDOT_STAGE_D));
     c->gstride = any_ard ? 2 + c->D : 2;
     c->gpart_count = frob.size() + (size_t)c->gstride * gd.size() + 2 * (size_t)L;
-    HIPCHK(c, hipMalloc(&c->d_gpart, std::max<size_t>(1, c->gpart_count) * sizeof(double)));
+    if (int rc = dev_grow(c, c->d_gpart, c->gpart_cap, c->gpart_count)) return rc;
     c->grad_ready = true;
     return 0;
 }

@@ -558,7 +558,10 @@ def updategradients(model, active=None):
     [dl..., ds, dnoise] (`src/gaussianprocess.jl:212-214`), computed on the device for the local leaves and
     gathered.  Also stored on the leaves (kernel.dl / kernel.ds / dnoise) like the reference does.
     `active` (one flag per leaf, default all): only those leaves' gradients are computed, the other rows are zero --
-    what `finetune!` needs, whose pass for leaf j weights leaf l's gradient by the overlap D[j, l] (`src/optimize.jl:101`)."""
+    what `finetune!` needs, whose pass for leaf j weights leaf l's gradient by the overlap D[j, l] (`src/optimize.jl:101`).
+    The gradients stored on the leaves (kernel.dl / kernel.ds / dnoise) are ZERO outside the active set, where the reference
+    stores every leaf's gradient on every pass (they are multiplied by D[j, l] = 0 there and never read otherwise); the
+    streaming context ignores the mask and computes all of them."""
     target = model.model if isinstance(model, GaussianProcess) else model
     stride = max(lf.kernel.nparams() + 1 for lf in target.leaves)
     if len(target.shard.local) and (active is not None or getattr(target, "_grad_masked", False)):

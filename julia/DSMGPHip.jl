@@ -16,7 +16,9 @@
 #   update_cholesky!(gp)            src/gaussianprocess.jl:82-108   one-leaf session (a GP that is not a leaf of an attached model)
 #   mll(gp)                         src/gaussianprocess.jl:163      per-leaf value returned by dsmgp_fit
 #   prediction(gp, xtest)           src/gaussianprocess.jl:131-137  dsmgp_predict_leaves on the GP's session
-#   predict(model, x)               src/common.jl:294-307  routing kept, ONE dsmgp_predict_run + dsmgp_aggregate
+#   predict(model, x)               src/common.jl:294-307  DSMGP: rows routed on the device (dsmgp_set_tree once per attach!,
+#                                                          dsmgp_set_test_routed per test set), ONE dsmgp_predict_run +
+#                                                          dsmgp_aggregate; PoE family: every row to every expert
 #   updategradients!(spn)           src/fit.jl:306-311     dsmgp_gradients, results written to kernel.∂ℓ/∂σ and gp.∂ϵ
 #   ∇mll(gp)                        src/gaussianprocess.jl:185-190  reads those fields (no second updategradients!)
 #   setparams!(spn, hyp)            src/optimize.jl:188-198 unchanged on the host; fit! pushes the vectors (dsmgp_set_hyper)
@@ -134,8 +136,43 @@ function attach!(root::Union{GPSumNode,GPSplitNode}; device::Integer = 0)
     s = newsession(device)
     s.leaves = getLeaves(root)
     upload!(s, [l.dist for l in s.leaves], [l.obs for l in s.leaves], [l.kernelid for l in s.leaves])
+    settree!(s, root)
     SESSIONS[root] = s
     return s
+end
+
+"The tree as the flat arrays dsmgp_set_tree takes (breadth-first, the children of a node consecutive, 0-based indices): kind
+0 region / 1 split / 2 sum, first child, number of children, split dimension, ascending thresholds (column i of a thr_ld x
+n_nodes matrix = node i, the last one its upper bound), leaf index of a region in the session's leaf table.  After it the
+routing of predict (getchild, src/common.jl:101-122, walked per node in :181-196,275-292) runs on the device."
+function settree!(s::Session, root)
+    nodes = Any[root]
+    kind = Int8[]; first = Int64[]; nchild = Int64[]; sdim = Int64[]; leaf = Int64[]; thr = Vector{Float64}[]
+    leafidx = Dict(l.id => i - 1 for (i, l) in enumerate(s.leaves))
+    i = 1
+    while i <= length(nodes)
+        nd = nodes[i]
+        if nd isa GPNode
+            push!(kind, Int8(0)); push!(first, 0); push!(nchild, 0); push!(sdim, 0); push!(leaf, leafidx[nd.id]); push!(thr, Float64[])
+        else
+            ch = children(nd)
+            push!(kind, nd isa GPSplitNode ? Int8(1) : Int8(2))
+            push!(first, length(nodes))            # 0-based index of the first child: it is appended next
+            push!(nchild, length(ch)); push!(leaf, -1)
+            push!(sdim, nd isa GPSplitNode ? nd.split[1][1] - 1 : 0)
+            push!(thr, nd isa GPSplitNode ? Float64[t for (_, t) in nd.split] : Float64[])
+            append!(nodes, ch)
+        end
+        i += 1
+    end
+    ld = max(1, maximum(length, thr))
+    T = fill(Inf, ld, length(nodes))
+    for (j, t) in enumerate(thr)
+        T[1:length(t), j] = t
+    end
+    GC.@preserve kind first nchild sdim T leaf chk(s, ccall(sym(:dsmgp_set_tree), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Int8}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Int64}),
+        s.h, length(nodes), kind, first, nchild, sdim, T, ld, leaf))
 end
 function detach!(root)
     s = pop!(SESSIONS, root, nothing)
@@ -349,6 +386,18 @@ function settest!(s::Session, x::Matrix{Float64}, rows::Dict{Symbol,Vector{Int}}
     s.testptr = ptr
 end
 
+"Register the test rows of a DSMGP and let the device route them (dsmgp_set_test_routed: one thread per row walks the tree
+handed over by settree!); only the per-leaf row offsets come back."
+function settestrouted!(s::Session, x::Matrix{Float64})
+    key = hash((size(x), x, :routed))
+    key == s.testkey && return
+    GC.@preserve x chk(s, ccall(sym(:dsmgp_set_test_routed), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), s.h, x, size(x, 1)))
+    ptr = Vector{Int64}(undef, length(s.leaves) + 1)
+    GC.@preserve ptr chk(s, ccall(sym(:dsmgp_routes), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), s.h, ptr, C_NULL))
+    s.testkey = key
+    s.testptr = ptr
+end
+
 function aggregate(s::Session, family::Int32, coef, group, G::Integer, plain::Bool, priorkid::Integer, nt::Integer)
     sec = Ref{Float64}(0.0)
     chk(s, ccall(sym(:dsmgp_predict_run), Cint, (Ptr{Cvoid}, Ref{Float64}), s.h, sec))
@@ -365,9 +414,7 @@ end
 function predict(model::DSMGP, x::AbstractMatrix)
     s = session(model.root)
     xt = Matrix{Float64}(x)
-    rows = Dict{Symbol,Vector{Int}}()
-    route!(rows, model.root, xt, collect(1:size(xt, 1)))
-    settest!(s, xt, rows)
+    settestrouted!(s, xt)          # (route! + settest! above are the host form of the same lists: rows in ascending order per leaf)
     w = Dict{Symbol,Float64}()
     pathweights!(w, model.root, 0.0)
     coef = Float64[w[l.id] for l in s.leaves]

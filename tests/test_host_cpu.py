@@ -491,7 +491,7 @@ def _julia_ccalls(src):
 
 _JL_TO_C = {"Int32": {"int32_t"}, "Int64": {"int64_t"}, "Cint": {"int"}, "Ptr{Float64}": {"double*"}, "Ref{Float64}": {"double*"},
             "Ptr{Int32}": {"int32_t*"}, "Ptr{Int64}": {"int64_t*"}, "Ptr{Cvoid}": {"dsmgp_ctx*"}, "Ref{Ptr{Cvoid}}": {"dsmgp_ctx**"},
-            "Cstring": {"char*"}, "Ptr{UInt8}": {"char*"}}
+            "Cstring": {"char*"}, "Ptr{UInt8}": {"char*"}, "Ptr{Int8}": {"int8_t*"}}
 
 
 def test_julia_binding_matches_the_header():
