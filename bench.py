@@ -372,6 +372,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="diagnostic: DSMGP_OPT_FIT_GRAPH = 1 (the untimed fits replay a captured hipGraph)")
     ap.add_argument("--no-diag-ahead", action="store_true",
                     help="diagnostic: DSMGP_OPT_DIAG_IN_UPDATE = 0 (a diagonal-block launch per classic step), for A/B runs")
+    ap.add_argument("--lanes", type=int, default=None, choices=[0, 1, 2],
+                    help="leaf lanes inside the context (DSMGP_OPT_LANES): default 0 = automatic (two from 64 sharing groups on)")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
@@ -456,6 +458,8 @@ def main():
         ctx.set_option(dsm.hipabi.OPT_DIAG_IN_UPDATE, 0)
     if args.graph:
         ctx.set_option(dsm.hipabi.OPT_FIT_GRAPH, 1)
+    if args.lanes is not None:
+        ctx.set_option(dsm.hipabi.OPT_LANES, args.lanes)
     if args.mode == "train":
         return bench_train(args, model, X, y, rank, world, td, torch)
     ctx.set_profile(0 if args.no_profile else 1)   # timed region: events around the update launches only
@@ -523,7 +527,7 @@ def main():
         ctx.set_profile(2)
         step()
         cats = {k: v * args.steps for k, v in ctx.timings().items()}
-        for k in ("chol_update", "chol_fused", "total_fit", "total_predict"):   # these come from the timed region itself
+        for k in ("chol_update", "chol_fused", "chol_update_union", "chol_fused_union", "total_fit", "total_predict"):   # from the timed region itself
             cats[k] = timed.get(k, 0.0)
         ctx.set_profile(1)
     if td is not None:
@@ -548,6 +552,7 @@ def main():
     alg_flops, _ = ctx.work()
     alg_fused, _ = ctx.work_fused()
     roof = None
+    lanes = ctx.lanes() if hasattr(ctx, "lanes") else 1
     fused_dominant = cats.get("chol_fused", 0.0) > cats.get("chol_update", 0.0)
     if not args.no_profile and max(cats.get("chol_update", 0.0), cats.get("chol_fused", 0.0)) > 0:
         if fused_dominant:
@@ -560,9 +565,13 @@ def main():
                      "evaluating the kernel function of its own tile; <false, 0, true> in launches with >= 10 % short tiles; "
                      "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel, the shallow block steps "
                      "(K <= 512) as diag_fused_reg_kernel + tile_fused8_kernel: all timed apart, device_seconds_per_step; the diagonal blocks of the other steps ride in these launches as DiagFinishTasks)")
+        # With two leaf lanes the launches of the kernel overlap in time: `achieved` = their flops over the time during which ANY of
+        # them ran (the union of the launch intervals, two events per launch: dsmgp_timings chol_*_union); avg_launch_ms stays
+        # the mean duration of a launch, the figure a profiler's per-kernel average shows.  One lane: union = sum.
+        t_union = cats.get("chol_fused_union" if fused_dominant else "chol_update_union", 0.0) or t_cat
         avg_launch = t_cat / max(1, n_l)
         flops_per_launch = fl_step * args.steps / max(1, n_l)
-        achieved = flops_per_launch / avg_launch / 1e12
+        achieved = fl_step * args.steps / t_union / 1e12
         traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath) and world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard and not fused_dominant:
@@ -580,7 +589,7 @@ def main():
         roof = {"bound": "mfma", "achieved": achieved, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / F64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kname, "avg_launch_ms": avg_launch * 1e3, "launches_per_step": n_l // args.steps,
-                "alg_flops_per_step": fl_step}
+                "alg_flops_per_step": fl_step, "lanes": lanes, "launch_seconds_per_step": {"sum": t_cat / args.steps, "union": t_union / args.steps}}
         if probe_after is not None:
             # the same kernel against what THIS chip's matrix pipe delivered right after the timed loop (register-only f64 MFMA
             # loop, 8 waves per SIMD), and the peak rescaled to the shader clock held inside the steps: 78.6 TFLOP/s is

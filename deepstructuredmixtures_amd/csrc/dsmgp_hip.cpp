@@ -79,6 +79,10 @@ enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 #endif
 constexpr int FUSED_SHALLOW_STEPS = DSMGP_FUSED_SHALLOW;   // block steps 0..4 (K <= 512) run fused where at least ...
 constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leaves take part in the step
+#ifndef DSMGP_LANES_AUTO_MIN
+#define DSMGP_LANES_AUTO_MIN 64
+#endif
+constexpr int LANES_AUTO_MIN_LEAVES = DSMGP_LANES_AUTO_MIN; // two leaf lanes (dsmgp_ctx::nlanes) from this many sharing groups on
 #ifndef DSMGP_SOLO_FACTOR
 #define DSMGP_SOLO_FACTOR 1.56             // time of one workgroup alone on a CU relative to its share of a co-resident pair
 #endif
@@ -390,16 +394,26 @@ struct dsmgp_ctx {
     // piece to arrive sums up to 46 slabs alone where the reduce launch spreads a tile over 8 workgroups, and the row-split
     // main loop the in-register solve needs runs 5-10 % behind the 2 x 2 one at K >= 2000.  Removed again.)
     std::vector<char> fused_step[2];
-    StepLists phase[2];             // 0: FULL leaves, 1: PREFIX leaves (need their source first)
+    // Leaf lanes (round 5, DSMGP_OPT_LANES): the leaves of a table are dealt to one or two LANES (longest-processing-time on n^3,
+    // sharing groups together); every lane has step lists and a split-K workspace of its own and runs them on a stream of its
+    // own, joined at the end of fit!.  One lane's latency-bound launches (diagonal blocks, panel solves, split-K reduces) then
+    // run under the other's update launches -- what several contexts per GPU bought (hipabi.MultiContext: headline -1.4 %, depth
+    // 4 -3..-4 %) without a second copy of X, a second plan or host threads.  Per-leaf results do not depend on the lane.
+    int lanes_opt = 0;              // 0 = auto (lanes_for), 1, 2
+    int nlanes = 1;                 // lanes of the current plan
+    hipStream_t lane_stream[2] = {nullptr, nullptr};   // [0] = stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<char> leaf_lane;    // per leaf (COPY / PREFIX leaves: their source's)
+    StepLists phase[2][2];          // [lane][0: FULL leaves, 1: PREFIX leaves (need their source first)]
     std::vector<char> leaf_group;   // per leaf: the phase it belongs to (COPY leaves ride with their source)
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
     // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
     // allocation (5 s per 230 GB group measured), which dominated the streaming mode's wall time.
     char* pool_base = nullptr;
     size_t pool_cap = 0, pool_top = 0, pool_mark_plan = 0;
-    double* slabF = nullptr;        // split-K workspace of the factorisation
-    StepLists phaseJ[2];            // the same with the resident test rows riding along (built by set_test)
-    double* slabJ = nullptr;
+    double* slabF[2] = {nullptr, nullptr};   // split-K workspace of the factorisation, per lane
+    StepLists phaseJ[2][2];         // the same with the resident test rows riding along (built by set_test)
+    double* slabJ[2] = {nullptr, nullptr};
     double alg_flops_joint = 0.0;
     bool joint = true;              // fit advances the resident test rows too
     bool joint_ready = false;
@@ -693,16 +707,17 @@ void free_plan(dsmgp_ctx* c) {
     dev_free(c->d_mll);
     dev_free(c->d_leaves);
     dev_free(c->gram);
-    for (auto& ph : c->phase) {
-        dev_free(ph.upd);
-        dev_free(ph.trsm);
-        dev_free(ph.red);
-        dev_free(ph.diag);
-        dev_free(ph.fdiag);
-        dev_free(ph.ftile8);
-        dev_free(ph.dfin);
-    }
-    arena_put(c, c->slabF);
+    for (auto& lane : c->phase)
+        for (auto& ph : lane) {
+            dev_free(ph.upd);
+            dev_free(ph.trsm);
+            dev_free(ph.red);
+            dev_free(ph.diag);
+            dev_free(ph.fdiag);
+            dev_free(ph.ftile8);
+            dev_free(ph.dfin);
+        }
+    for (auto& sl : c->slabF) arena_put(c, sl);
     dev_free(c->fwd);
     dev_free(c->bwd);
     dev_free(c->dinvc_prefix);
@@ -752,16 +767,17 @@ void free_test(dsmgp_ctx* c, bool keep) {
     dev_drop(c->psweep8, keep);
     dev_drop(c->psegs, keep);
     dev_drop(c->pzero, keep);
-    for (auto& ph : c->phaseJ) {
-        dev_drop(ph.upd, keep);
-        dev_drop(ph.trsm, keep);
-        dev_drop(ph.red, keep);
-        dev_drop(ph.diag, keep);
-        dev_drop(ph.fdiag, keep);
-        dev_drop(ph.ftile8, keep);
-        dev_drop(ph.dfin, keep);
-    }
-    arena_put(c, c->slabJ);
+    for (auto& lane : c->phaseJ)
+        for (auto& ph : lane) {
+            dev_drop(ph.upd, keep);
+            dev_drop(ph.trsm, keep);
+            dev_drop(ph.red, keep);
+            dev_drop(ph.diag, keep);
+            dev_drop(ph.fdiag, keep);
+            dev_drop(ph.ftile8, keep);
+            dev_drop(ph.dfin, keep);
+        }
+    for (auto& sl : c->slabJ) arena_put(c, sl);
     c->joint_ready = false;
     c->vt_valid = false;
     c->test_ready = false;
@@ -902,7 +918,7 @@ void push_fused8_tasks(std::vector<FusedTask8>& out, std::vector<RowBlock>& bloc
 // with_test: the rows of K_tn (Vt) of every leaf are appended below its factor and advance through the same
 // update / panel-solve launches -- prediction's triangular solves (src/gaussianprocess.jl:120) cost no launches
 // of their own when the test set is resident at fit time.
-int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops,
+int build_factor_steps(dsmgp_ctx* c, int lane, bool with_test, StepLists (&phase)[2], double*& slab_ws, double& alg_flops,
                        double& alg_flops_fused, bool slab_outside_pool = false) {
     const int L = c->L;
     alg_flops = 0.0;
@@ -915,7 +931,10 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
         U.xcd = c->xcd_order;
         U.tail_split = c->tail_split;
         U.tail_rounds = c->tail_rounds;
-        auto in_phase = [&](const LeafHost& lf) { return c->leaf_group[&lf - c->leaves.data()] == ph; };
+        auto in_phase = [&](const LeafHost& lf) {
+            const size_t l = (size_t)(&lf - c->leaves.data());
+            return c->leaf_group[l] == ph && c->leaf_lane[l] == lane;
+        };
         int nsteps = 0;
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
@@ -1224,6 +1243,7 @@ int build_factor_steps(dsmgp_ctx* c, bool with_test, StepLists (&phase)[2], doub
     alg_flops_fused = 0.0;
     for (int l = 0; l < L; ++l) {
         const LeafHost& lf = c->leaves[l];
+        if (c->leaf_lane[l] != lane) continue;
         const std::vector<char>& md = c->fused_step[(int)c->leaf_group[l]];
         auto mode = [&](int k) { return k < (int)md.size() ? (int)md[k] : (int)STEP_CLASSIC; };
         auto depth = [&](int k) { return mode(k) == STEP_FUSED ? 0 : k; };
@@ -1375,6 +1395,36 @@ int build_plan(dsmgp_ctx* c) {
     c->leaf_group.assign(L, 0);
     for (int l = 0; l < L; ++l)
         if (c->leaves[l].op == DSMGP_SHARE_PREFIX) c->leaf_group[l] = 1;
+    // Lanes: sharing groups (a source with its COPY and PREFIX leaves) dealt longest-processing-time first on n^3.
+    {
+        std::vector<int> unit(L);
+        std::vector<double> cost(L, 0.0);
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            unit[l] = lf.op == DSMGP_SHARE_FULL ? l : lf.src;
+            const double n = (double)lf.n;
+            cost[unit[l]] += lf.op == DSMGP_SHARE_COPY ? n * n : n * n * n;
+        }
+        int nunits = 0;
+        for (int l = 0; l < L; ++l) nunits += unit[l] == l ? 1 : 0;
+        c->nlanes = c->lanes_opt > 0 ? c->lanes_opt : ((nunits >= LANES_AUTO_MIN_LEAVES && !c->pool_base) ? 2 : 1);
+        if (c->pool_base || nunits < 2) c->nlanes = 1;      // (the pool is a stack: one split-K workspace per table)
+        c->leaf_lane.assign(L, 0);
+        if (c->nlanes == 2) {
+            std::vector<int> order;
+            for (int l = 0; l < L; ++l)
+                if (unit[l] == l) order.push_back(l);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+            double load[2] = {0.0, 0.0};
+            std::vector<char> of_unit(L, 0);
+            for (int u : order) {
+                const int lane = load[1] < load[0] ? 1 : 0;
+                of_unit[u] = (char)lane;
+                load[lane] += cost[u];
+            }
+            for (int l = 0; l < L; ++l) c->leaf_lane[l] = of_unit[unit[l]];
+        }
+    }
     // How every block step runs (STEP_*).  Fused: the steps whose diagonal blocks alone fill the chip (or shallow ones).
     for (int ph = 0; ph < 2; ++ph) {
         int ns = 0;
@@ -1560,7 +1610,13 @@ int build_plan(dsmgp_ctx* c) {
 int ensure_phase(dsmgp_ctx* c) {
     if (c->phase_ready) return 0;
     HostLog hl("ensure_phase: factor steps");
-    if (int rc = build_factor_steps(c, false, c->phase, c->slabF, c->alg_flops_update, c->alg_flops_fused, true)) return rc;
+    c->alg_flops_update = c->alg_flops_fused = 0.0;
+    for (int lane = 0; lane < c->nlanes; ++lane) {
+        double fu = 0.0, ff = 0.0;
+        if (int rc = build_factor_steps(c, lane, false, c->phase[lane], c->slabF[lane], fu, ff, true)) return rc;
+        c->alg_flops_update += fu;
+        c->alg_flops_fused += ff;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->phase_ready = true;
     return 0;
@@ -1570,7 +1626,13 @@ int ensure_phase(dsmgp_ctx* c) {
 int ensure_joint(dsmgp_ctx* c) {
     if (c->joint_ready) return 0;
     HostLog hl("ensure_joint: joint factor steps");
-    if (int rc = build_factor_steps(c, true, c->phaseJ, c->slabJ, c->alg_flops_joint, c->alg_flops_fused_joint)) return rc;
+    c->alg_flops_joint = c->alg_flops_fused_joint = 0.0;
+    for (int lane = 0; lane < c->nlanes; ++lane) {
+        double fu = 0.0, ff = 0.0;
+        if (int rc = build_factor_steps(c, lane, true, c->phaseJ[lane], c->slabJ[lane], fu, ff)) return rc;
+        c->alg_flops_joint += fu;
+        c->alg_flops_fused_joint += ff;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->joint_ready = true;
     return 0;
@@ -1578,19 +1640,20 @@ int ensure_joint(dsmgp_ctx* c) {
 
 // dpos / dfin / ndfin: an update launch that carries its step's diagonal-block tasks (tile_gemm_kernel_v2's grid layout)
 void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 update, 1 panel solve */, bool pad = false,
-                  int dpos = 0, const DiagFinishTask* dfin = nullptr, int ndfin = 0) {
+                  int dpos = 0, const DiagFinishTask* dfin = nullptr, int ndfin = 0, hipStream_t st = nullptr) {
     const int g = n + ndfin;
+    if (!st) st = c->stream;
     if (pad) {   // launches with many padding-row tiles (small leaves): waves without data rows stay off the matrix pipe
-        if (role == 1) tile_trsm_kernel<true><<<n, 256, 0, c->stream>>>(tasks);
-        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
-        else tile_gemm_kernel_v2<false, 0, true><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+        if (role == 1) tile_trsm_kernel<true><<<n, 256, 0, st>>>(tasks);
+        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+        else tile_gemm_kernel_v2<false, 0, true><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
         return;
     }
     // ROLE only names the instantiation: with per-launch timing switched off (dsmgp_set_profile(ctx, 0)) the same code
     // runs as <false, 2>, so that a profiler's per-kernel average of <false, 0> covers exactly the launches bench.py times
-    if (role == 1) tile_trsm_kernel<false><<<n, 256, 0, c->stream>>>(tasks);   // B = inverse of a diagonal block, K = 128
-    else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
-    else tile_gemm_kernel_v2<false, 0><<<g, 256, 0, c->stream>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+    if (role == 1) tile_trsm_kernel<false><<<n, 256, 0, st>>>(tasks);   // B = inverse of a diagonal block, K = 128
+    else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+    else tile_gemm_kernel_v2<false, 0><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
 }
 
 // Two events bracketing a call on the context's stream; destroyed on every exit path.
@@ -1645,72 +1708,114 @@ struct PhaseTimer {
         if (!on) return;
         (void)hipEventRecord(c->event_pool[spans.back().e1], st ? st : c->stream);
     }
-    void collect() {
+    // ref: an event recorded before every span (the start of the call).  With two lanes the launches of a slot overlap in time:
+    // next to the SUM of their durations (timings[slot]: what a profiler's per-kernel total is) the time during which ANY of
+    // them ran -- the union of the intervals -- goes to timings[19] (update launches) and [20] (fused tile launches).
+    void collect(hipEvent_t ref = nullptr) {
         const bool log = std::getenv("DSMGP_STEPLOG") != nullptr;
+        std::vector<std::pair<float, float>> iv[2];
         for (const Span& s : spans) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, c->event_pool[s.e0], c->event_pool[s.e1]);
             c->timings[s.slot] += ms * 1e-3;
+            if (ref && (s.slot == 1 || s.slot == 18)) {
+                float a = 0.f;
+                (void)hipEventElapsedTime(&a, ref, c->event_pool[s.e0]);
+                iv[s.slot == 1 ? 0 : 1].push_back({a, a + ms});
+            }
             if (log && s.step >= 0)
                 std::fprintf(stderr, "steplog slot %d step %d tasks %d tiles %d ms %.4f\n", s.slot, s.step, s.tasks, s.red, ms);
+        }
+        for (int q = 0; q < 2; ++q) {
+            std::sort(iv[q].begin(), iv[q].end());
+            double tot = 0.0;
+            float lo = 0.f, hi = -1.f;
+            for (const auto& p : iv[q]) {
+                if (hi < 0.f || p.first > hi) {
+                    if (hi >= 0.f) tot += hi - lo;
+                    lo = p.first;
+                    hi = p.second;
+                } else if (p.second > hi) {
+                    hi = p.second;
+                }
+            }
+            if (hi >= 0.f) tot += hi - lo;
+            c->timings[19 + q] += tot * 1e-3;
         }
         spans.clear();
         used = 0;
     }
 };
 
-// One factorisation phase on the context's stream.  Classic step: update (-> split-K reduce) -> diagonal block -> panel solve.
-// Fused step (many leaves, or shallow): diag_fused_reg_kernel -> tile_fused8_kernel.
-int run_phase(dsmgp_ctx* c, StepLists& S, PhaseTimer& pt, bool count_launches) {
-    for (int k = 0; k < S.nsteps; ++k) {
-        const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft8 = S.ftile8_off[k + 1] - S.ftile8_off[k];
-        const int nu = S.upd_off[k + 1] - S.upd_off[k];
-        if (nfd > 0 || nft8 > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
-            if (nfd > 0) {
-                pt.begin(2);
-                diag_fused_reg_kernel<<<nfd, 256, DIAGR_LDS_BYTES, c->stream>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
-                pt.note(k, nfd, 0);
-                pt.end();
-            }
-            if (nft8 > 0) {
-                pt.begin(18);
-                tile_fused8_kernel<<<nft8, 512, 0, c->stream>>>(S.ftile8.p + S.ftile8_off[k], c->d_kp, c->D);
-                pt.note(k, nft8, nft8);
-                pt.end();
-                if (count_launches) c->n_fused_launches++;
-            }
-            continue;
+// One block step of one lane's factorisation phase, on that lane's stream.  Classic step: update (-> split-K reduce) -> diagonal
+// block -> panel solve.  Fused step (many leaves, or shallow): diag_fused_reg_kernel -> tile_fused8_kernel.
+void run_step(dsmgp_ctx* c, StepLists& S, int k, PhaseTimer& pt, hipStream_t st, bool count_launches) {
+    if (k >= S.nsteps) return;
+    const int nfd = S.fdiag_off[k + 1] - S.fdiag_off[k], nft8 = S.ftile8_off[k + 1] - S.ftile8_off[k];
+    const int nu = S.upd_off[k + 1] - S.upd_off[k];
+    if (nfd > 0 || nft8 > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
+        if (nfd > 0) {
+            pt.begin(2, st);
+            diag_fused_reg_kernel<<<nfd, 256, DIAGR_LDS_BYTES, st>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
+            pt.note(k, nfd, 0);
+            pt.end(st);
         }
-        const int ndf = S.dfin_off[k + 1] - S.dfin_off[k];
-        if (nu > 0 || ndf > 0) {
-            pt.begin(1);
-            launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0, S.dpos[k], S.dfin.p + S.dfin_off[k], ndf);
-            pt.note(k, nu, S.step_tiles[k]);
-            pt.end();
-            const int nr = S.red_off[k + 1] - S.red_off[k];
-            if (nr > 0) {
-                pt.begin(13);
-                tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(S.red.p + S.red_off[k]);
-                pt.end();
-            }
-            if (count_launches) c->n_update_launches++;
+        if (nft8 > 0) {
+            pt.begin(18, st);
+            tile_fused8_kernel<<<nft8, 512, 0, st>>>(S.ftile8.p + S.ftile8_off[k], c->d_kp, c->D);
+            pt.note(k, nft8, nft8);
+            pt.end(st);
+            if (count_launches) c->n_fused_launches++;
         }
-        const int nd = S.diag_off[k + 1] - S.diag_off[k];
-        if (nd > 0) {
-            pt.begin(2);
-            chol_diag_packed_kernel<<<nd, 256, DIAGP_LDS_BYTES, c->stream>>>(S.diag.p + S.diag_off[k]);
-            pt.note(k, nd, 0);
-            pt.end();
-        }
-        const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
-        if (ns > 0) {
-            pt.begin(3);
-            launch_tiles(c, S.trsm.p + S.trsm_off[k], ns, 1, S.pad[k] != 0);
-            pt.note(k, ns, 0);
-            pt.end();
-        }
+        return;
     }
+    const int ndf = S.dfin_off[k + 1] - S.dfin_off[k];
+    if (nu > 0 || ndf > 0) {
+        pt.begin(1, st);
+        launch_tiles(c, S.upd.p + S.upd_off[k], nu, 0, S.pad[k] != 0, S.dpos[k], S.dfin.p + S.dfin_off[k], ndf, st);
+        pt.note(k, nu, S.step_tiles[k]);
+        pt.end(st);
+        const int nr = S.red_off[k + 1] - S.red_off[k];
+        if (nr > 0) {
+            pt.begin(13, st);
+            tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, st>>>(S.red.p + S.red_off[k]);
+            pt.end(st);
+        }
+        if (count_launches) c->n_update_launches++;
+    }
+    const int nd = S.diag_off[k + 1] - S.diag_off[k];
+    if (nd > 0) {
+        pt.begin(2, st);
+        chol_diag_packed_kernel<<<nd, 256, DIAGP_LDS_BYTES, st>>>(S.diag.p + S.diag_off[k]);
+        pt.note(k, nd, 0);
+        pt.end(st);
+    }
+    const int ns = S.trsm_off[k + 1] - S.trsm_off[k];
+    if (ns > 0) {
+        pt.begin(3, st);
+        launch_tiles(c, S.trsm.p + S.trsm_off[k], ns, 1, S.pad[k] != 0, 0, nullptr, 0, st);
+        pt.note(k, ns, 0);
+        pt.end(st);
+    }
+}
+
+// Phase `ph` of every lane: the lanes' streams wait for what the context's stream has queued so far (fork), take their block
+// steps -- enqueued step by step, lane after lane, so that both queues stay fed -- and the context's stream waits for them (join).
+int run_lanes(dsmgp_ctx* c, StepLists (*lists)[2], int ph, PhaseTimer& pt, bool count_launches) {
+    int nsteps = 0;
+    for (int lane = 0; lane < c->nlanes; ++lane) nsteps = std::max(nsteps, lists[lane][ph].nsteps);
+    if (nsteps == 0) return 0;
+    if (c->nlanes > 1) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->lane_stream[1], c->ev_fork, 0));
+    }
+    for (int k = 0; k < nsteps; ++k)
+        for (int lane = 0; lane < c->nlanes; ++lane) run_step(c, lists[lane][ph], k, pt, c->lane_stream[lane], count_launches);
     HIPCHK(c, hipGetLastError());
+    if (c->nlanes > 1) {
+        HIPCHK(c, hipEventRecord(c->ev_join, c->lane_stream[1]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
     return 0;
 }
 
@@ -1767,6 +1872,13 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         delete c;
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
+    c->lane_stream[0] = c->stream;
+    if (hipStreamCreate(&c->lane_stream[1]) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(nullptr, DSMGP_E_HIP, "cannot create the second lane's stream");
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dinv_complete_kernel),
@@ -1813,6 +1925,9 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->rws_counts);
     dev_free(c->rws_bits);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->lane_stream[1]) (void)hipStreamDestroy(c->lane_stream[1]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1865,6 +1980,16 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
     if (option == DSMGP_OPT_FIT_GRAPH) {
         if (value == 0) drop_graphs(c);
         c->use_graph = value != 0;
+        return 0;
+    }
+    if (option == DSMGP_OPT_LANES) {
+        if (value < 0 || value > 2) return fail(c, DSMGP_E_ARG, "set_option: lanes must be 0 (automatic), 1 or 2");
+        if (value != c->lanes_opt) {
+            HIPCHK(c, hipSetDevice(c->device));
+            free_plan(c);
+            free_test(c);
+        }
+        c->lanes_opt = value;
         return 0;
     }
     if (option == DSMGP_OPT_DIAG_IN_UPDATE) {
@@ -2024,7 +2149,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     c->timings[11] = 0.0;
     c->timings[13] = 0.0;
     c->timings[14] = 0.0;
-    c->timings[18] = 0.0;
+    c->timings[18] = c->timings[19] = c->timings[20] = 0.0;
     c->n_update_launches = 0;
     c->n_fused_launches = 0;
     PhaseTimer pt(c);
@@ -2033,7 +2158,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     const hipEvent_t t0 = ev.a, t1 = ev.b;
     HIPCHK(c, hipEventRecord(t0, c->stream));
 
-    StepLists* phases = joint ? c->phaseJ : c->phase;
+    StepLists (*phases)[2] = joint ? c->phaseJ : c->phase;
     auto enqueue = [&]() -> int {
         HIPCHK(c, hipMemsetAsync(c->d_info, 0, L * sizeof(int), c->stream));
         if (joint && c->acc_count) HIPCHK(c, hipMemsetAsync(c->arenaPV + c->acc_off, 0, c->acc_count * sizeof(double), c->stream));
@@ -2052,7 +2177,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
             for (auto& lf : c->leaves) maxpad = std::max(maxpad, lf.npad);
             copy_vec_kernel<<<dim3((maxpad + 255) / 256, L), 256, 0, c->stream>>>(c->d_leaves);
         }
-        if (int rc = run_phase(c, phases[0], pt, true)) return rc;
+        if (int rc = run_lanes(c, phases, 0, pt, true)) return rc;
         // 3. prefix leaves: copy the leading blocks of the source factor, continue (src/fit.jl:276-278)
         bool any_prefix = false;
         for (int l = 0; l < L; ++l) {
@@ -2069,7 +2194,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
         if (any_prefix) {
             if (c->dinvc_prefix.count)      // copied blocks that a fused step factorised: their whole inverse, for the classic steps below
                 dinv_complete_kernel<<<(int)c->dinvc_prefix.count, 256, DIAGP_LDS_BYTES, c->stream>>>(c->dinvc_prefix.p);
-            if (int rc = run_phase(c, phases[1], pt, true)) return rc;
+            if (int rc = run_lanes(c, phases, 1, pt, true)) return rc;
         }
         // 4. z = L^-1 (y - m) for the leaves whose factor came from another leaf (COPY, PREFIX); leaves factorised in
         //    full produced z during the factorisation.  alpha = L^-T z (src/gaussianprocess.jl:105) is NOT computed here:
@@ -2133,7 +2258,7 @@ int dsmgp_fit(dsmgp_ctx* c, double* mll_out, int32_t* info_out, double* seconds)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
-    pt.collect();
+    pt.collect(t0);
     c->timings[11] = ms * 1e-3;
     if (seconds) *seconds = ms * 1e-3;
     if (mll_out) HIPCHK(c, hipMemcpy(mll_out, c->d_mll, L * sizeof(double), hipMemcpyDeviceToHost));
@@ -3263,6 +3388,12 @@ int dsmgp_work(dsmgp_ctx* c, double* alg_flops_update, int32_t* n_update_launche
     if (!c) return DSMGP_E_ARG;
     if (alg_flops_update) *alg_flops_update = c->last_fit_joint ? c->alg_flops_joint : c->alg_flops_update;
     if (n_update_launches) *n_update_launches = c->n_update_launches;
+    return 0;
+}
+
+int dsmgp_lanes(dsmgp_ctx* c, int32_t* lanes) {
+    if (!c || !lanes) return DSMGP_E_ARG;
+    *lanes = c->plan_ready ? c->nlanes : 0;
     return 0;
 }
 

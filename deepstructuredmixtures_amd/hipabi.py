@@ -10,13 +10,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsmgp_hip.so")
 
-N_TIMINGS = 19
+N_TIMINGS = 21
 AGG_MIXTURE, AGG_POE, AGG_GPOE, AGG_RBCM = 0, 1, 2, 3     # include/dsmgp_hip.h DSMGP_AGG_*
 OPT_ARD_LENGTHSCALE_GRADIENT = 1
 OPT_FUSED_GRAM = 2
 OPT_FUSED_STEPS = 3
 OPT_DIAG_IN_UPDATE = 4
 OPT_FIT_GRAPH = 5
+OPT_LANES = 6
 SCORE_NAMES = ("mse", "sse", "mae", "sae", "nlpd")
 
 
@@ -25,7 +26,7 @@ def agg_width(family, n_groups=0):
     return 3 if family == AGG_MIXTURE else (2 * int(n_groups) if family == AGG_RBCM else 2)
 TIMING_NAMES = ("gram", "chol_update", "chol_diag", "chol_trsm", "solve", "mll", "predict_gram",
                 "predict_update", "predict_trsm", "predict_var", "gradients", "total_fit", "total_predict", "chol_reduce", "alpha",
-                "grad_inverse", "grad_contraction", "grad_traces", "chol_fused")
+                "grad_inverse", "grad_contraction", "grad_traces", "chol_fused", "chol_update_union", "chol_fused_union")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -53,6 +54,7 @@ SIGNATURES = {
     "dsmgp_gradients": (C.c_int, [_ctx, _dp, C.c_int32]),
     "dsmgp_set_gradient_leaves": (C.c_int, [_ctx, _ip]),
     "dsmgp_set_option": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
+    "dsmgp_lanes": (C.c_int, [_ctx, _ip]),
     "dsmgp_aggregate": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "dsmgp_aggregate_partial": (C.c_int, [_ctx, C.c_int32, _dp, _ip, C.c_int32, _dp]),
     "dsmgp_aggregate_finish": (C.c_int, [_ctx, _dp, C.c_int32, C.c_int32, _dp, _dp]),
@@ -291,6 +293,12 @@ class Context:
     def set_option(self, option, value):
         """include/dsmgp_hip.h DSMGP_OPT_*: OPT_ARD_LENGTHSCALE_GRADIENT = 1, OPT_FUSED_GRAM = 2, OPT_FUSED_STEPS = 3."""
         self._chk(self.lib.dsmgp_set_option(self.h, int(option), int(value)))
+
+    def lanes(self):
+        """Leaf lanes of the current plan (1 or 2; 0 before the first fit of a leaf table)."""
+        n = C.c_int32(0)
+        self._chk(self.lib.dsmgp_lanes(self.h, C.byref(n)))
+        return n.value
 
     def set_gradient_leaves(self, active=None):
         """Restrict `gradients` to the leaves with a true flag (None: all): the other rows come back as zeros."""

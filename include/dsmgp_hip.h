@@ -51,8 +51,10 @@ typedef struct dsmgp_ctx dsmgp_ctx;
  * predict_trsm, predict_var, gradients, total_fit, total_predict, chol_reduce (split-K reduce launches of the
  * factorisation), alpha (the backward sweep alpha = L^-T z, run on first use after a fit: gradients, download_factor),
  * grad_inverse (L^-T by blocked triangular inversion), grad_contraction (tile_graddot_kernel), grad_traces,
- * chol_fused (the tile_fused8_kernel launches of fused block steps: update + solve of the tiles below the diagonal blocks) */
-#define DSMGP_N_TIMINGS 19
+ * chol_fused (the tile_fused8_kernel launches of fused block steps: update + solve of the tiles below the diagonal blocks),
+ * chol_update_union, chol_fused_union (with two leaf lanes the launches of a kind overlap in time: chol_update / chol_fused are the
+ * SUM of their durations, these the time during which any of them ran; one lane: the same numbers) */
+#define DSMGP_N_TIMINGS 21
 
 /* kernel ids are dense small integers (one hyper-vector each; finetune! gives every leaf its own) */
 #define DSMGP_MAX_KERNEL_IDS (1 << 22)
@@ -191,7 +193,17 @@ int dsmgp_set_gradient_leaves(dsmgp_ctx* ctx, const int32_t* active /* L flags, 
  * -> 2.47 ms) and nothing elsewhere, and a capture does not tolerate other contexts being driven from concurrent host threads
  * in the same process. */
 #define DSMGP_OPT_FIT_GRAPH 5
+/* DSMGP_OPT_LANES: leaf lanes of a fit (src/fit.jl:88-119: the leaves are independent): 0 (default) = automatic -- two lanes from 64
+ * sharing groups on, one below (a single GP, the shards of a multi-GPU job) and with a reserved device pool -- 1 = one lane, 2 = two.
+ * With two lanes the leaves are dealt longest-processing-time first into two halves with step lists, split-K workspace and HIP
+ * stream of their own, joined at the end of the factorisation: one half's latency-bound launches (diagonal blocks, panel solves,
+ * reduces) run under the other's update launches.  Per-leaf results agree to rounding with the one-lane schedule (a launch of half
+ * the tiles cuts its tail along K differently: the order of a few additions per entry), a fit is bit-reproducible either way.
+ * Changing it discards the leaf plan and a registered test set. */
+#define DSMGP_OPT_LANES 6
 int dsmgp_set_option(dsmgp_ctx* ctx, int32_t option, int32_t value);
+/* leaf lanes of the current plan (DSMGP_OPT_LANES: 1 or 2; 0 = no plan yet: it is made by the first fit / set_test of a leaf table) */
+int dsmgp_lanes(dsmgp_ctx* ctx, int32_t* lanes);
 
 /* ---- inspection ------------------------------------------------------------------------------- */
 /* kernelmatrix(kernel, x1, x2) (src/kernels.jl:15-18) through the same device code as the fit path */

@@ -1935,3 +1935,73 @@ def test_device_routing_equals_the_host_routing_entry_by_entry():
         c2.set_test_routed(Xt)
     assert "set_tree" in str(e.value)
     c2.close()
+
+
+def test_two_leaf_lanes_agree_with_one_lane(ctx):
+    """DSMGP_OPT_LANES (round 5): the leaves of a table dealt into two halves with step lists, split-K workspace and stream of their
+    own, joined at the end of fit! (`src/fit.jl:88-119`: the leaves are independent).  (1) A table whose block steps all run fused
+    -- 300 leaves of 130..700 rows: no split-K anywhere -- gives the one-lane schedule's results to the BIT, per leaf: log-marginals,
+    moments of routed rows riding through the fit and of the standalone sweep, gradients.  (2) A table of few large leaves
+    (classic steps: a launch of half the tiles cuts its tail along K differently) agrees to rounding, 1e-12 / 1e-10, and against
+    the oracle on sampled leaves at the north-star tolerance.  (3) Two fits with two lanes are bit-identical (fixed summation
+    orders per lane, no atomics); the automatic rule takes two lanes from 64 sharing groups on and one below."""
+    def table(sizes, seed, D=3, n_test=96):
+        N = int(np.sum(sizes)) + 10
+        X, y, Xt = regression_data(N, D, n_test=n_test, seed=seed)
+        rng = np.random.default_rng(seed)
+        obs = [np.sort(rng.choice(N, size=int(n), replace=False)) for n in sizes]
+        obs[1] = obs[0].copy()                                            # a COPY leaf: rides in its source's lane
+        return X, y, Xt, obs
+
+    def run(lanes, X, y, Xt, obs, joint):
+        L = len(obs)
+        ctx.set_option(hipabi.OPT_LANES, lanes)
+        ctx.set_train(X, y)
+        ctx.set_leaves(np.concatenate([[0], np.cumsum([o.size for o in obs])]), np.concatenate(obs), np.zeros(L, np.int32),
+                       [float(np.mean(y[o])) for o in obs])
+        op, src = np.zeros(L, np.int32), np.full(L, -1, np.int32)
+        op[1], src[1] = 1, 0
+        ctx.set_sharing(op, src, np.zeros(L, np.int64))
+        ctx.set_hyper(0, 0, [np.log(0.4), 0.1, np.log(0.15)])
+        ctx.set_joint(joint)
+        rp = np.arange(L + 1) * Xt.shape[0]
+        ri = np.tile(np.arange(Xt.shape[0]), L)
+        if joint:
+            ctx.set_test(Xt, rp, ri)
+        mll, info, _ = ctx.fit()
+        assert np.all(info == 0)
+        if not joint:
+            ctx.set_test(Xt, rp, ri)
+        ctx.predict_run()
+        mu, var = ctx.predict_fetch()
+        return mll, mu, var, ctx.gradients(3), ctx.lanes()
+
+    try:
+        # (1) fused steps only
+        sizes = np.random.default_rng(5).integers(130, 701, size=300)
+        X, y, Xt, obs = table(sizes, 7101)
+        for joint in (True, False):
+            one, two = run(1, X, y, Xt, obs, joint), run(2, X, y, Xt, obs, joint)
+            assert one[4] == 1 and two[4] == 2
+            for a, b in zip(one[:4], two[:4]):
+                assert np.array_equal(a, b)
+        again = run(2, X, y, Xt, obs, True)
+        assert all(np.array_equal(a, b) for a, b in zip(two[:4], again[:4]))
+        assert run(0, X, y, Xt, obs, True)[4] == 2                         # automatic: 299 sharing groups
+        # (2) classic steps, split along K
+        sizes = np.array([2100, 2100, 1900, 1700, 1500, 1300, 900, 700, 2300, 1100])
+        X, y, Xt, obs = table(sizes, 7102, n_test=150)
+        one, two = run(1, X, y, Xt, obs, True), run(2, X, y, Xt, obs, True)
+        assert two[4] == 2 and run(0, X, y, Xt, obs, True)[4] == 1         # automatic: 9 sharing groups -> one lane
+        assert np.allclose(one[0], two[0], rtol=1e-12) and np.allclose(one[1], two[1], rtol=1e-10, atol=1e-12)
+        assert np.allclose(one[2], two[2], rtol=1e-9, atol=1e-13) and np.allclose(one[3], two[3], rtol=1e-8, atol=1e-9)
+        for l in (0, 7, 8):
+            g = ogp.GaussianProcess(X[obs[l]], y[obs[l]], float(np.mean(y[obs[l]])), ogp.make_kernel(0, [np.log(0.4), 0.1]), np.log(0.15),
+                                    True).update_cholesky()
+            mo, vo = g.prediction(Xt)
+            sl = slice(l * Xt.shape[0], (l + 1) * Xt.shape[0])
+            assert abs(two[0][l] - g.mll()) <= RTOL * abs(g.mll())
+            assert np.allclose(two[1][sl], mo, rtol=RTOL, atol=1e-10) and np.allclose(two[2][sl], vo, rtol=RTOL, atol=1e-10)
+    finally:
+        ctx.set_option(hipabi.OPT_LANES, 0)
+        ctx.set_joint(True)
