@@ -80,9 +80,12 @@ enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
 constexpr int FUSED_SHALLOW_STEPS = DSMGP_FUSED_SHALLOW;   // block steps 0..4 (K <= 512) run fused where at least ...
 constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leaves take part in the step
 #ifndef DSMGP_LANES_AUTO_MIN
-#define DSMGP_LANES_AUTO_MIN 64
+#define DSMGP_LANES_AUTO_MIN 8
 #endif
-constexpr int LANES_AUTO_MIN_LEAVES = DSMGP_LANES_AUTO_MIN; // two leaf lanes (dsmgp_ctx::nlanes) from this many sharing groups on
+// two leaf lanes (dsmgp_ctx::nlanes) from this many sharing groups on.  Same-box A/B, one lane -> two (profiles/r05_lanes_ab.log): headline
+// (144 leaves) 0.4084 / 0.4079 -> 0.3926 / 0.3912 s; depth 4 (18k leaves) 0.0512 / 0.0514 -> 0.0498 / 0.0499; the shards of 2-, 4- and
+// 8-rank jobs (72 / 36 / 18 leaves) 0.2110 -> 0.1994, 0.1082 -> 0.1044, 0.0584 -> 0.0572; PoE of 128 experts 4.72 -> 4.67 ms
+constexpr int LANES_AUTO_MIN_LEAVES = DSMGP_LANES_AUTO_MIN;
 #ifndef DSMGP_SOLO_FACTOR
 #define DSMGP_SOLO_FACTOR 1.56             // time of one workgroup alone on a CU relative to its share of a co-resident pair
 #endif
@@ -1235,6 +1238,15 @@ int build_factor_steps(dsmgp_ctx* c, int lane, bool with_test, StepLists (&phase
             split[ph].bind(slab_ws);
             if (int rc = dev_upload(c, phase[ph].upd, split[ph].upd)) return rc;
             if (int rc = dev_upload(c, phase[ph].red, split[ph].red)) return rc;
+        }
+        if (std::getenv("DSMGP_HOSTLOG")) {      // how many tiles of the factorisation pass through a split-K reduce before their panel solve
+            size_t tiles = 0, panel = 0;
+            for (int ph = 0; ph < 2; ++ph) {
+                for (int v : phase[ph].step_tiles) tiles += (size_t)v;
+                panel += (size_t)phase[ph].trsm_off[phase[ph].nsteps];
+            }
+            std::fprintf(stderr, "hostlog lane %d: %zu update tiles, %zu of them cut along K (reduce tasks), %zu panel-solve tiles\n", lane, tiles,
+                         split[0].red.size() + split[1].red.size(), panel);
         }
     }
     // algorithmic flops of the launches timed as "update" (slot 1: tile_gemm_kernel_v2): 2 K per element of block column k with

@@ -1940,11 +1940,11 @@ def test_device_routing_equals_the_host_routing_entry_by_entry():
 def test_two_leaf_lanes_agree_with_one_lane(ctx):
     """DSMGP_OPT_LANES (round 5): the leaves of a table dealt into two halves with step lists, split-K workspace and stream of their
     own, joined at the end of fit! (`src/fit.jl:88-119`: the leaves are independent).  (1) A table whose block steps all run fused
-    -- 300 leaves of 130..700 rows: no split-K anywhere -- gives the one-lane schedule's results to the BIT, per leaf: log-marginals,
+    -- 300 leaves of 130..640 rows: no split-K anywhere -- gives the one-lane schedule's results to the BIT, per leaf: log-marginals,
     moments of routed rows riding through the fit and of the standalone sweep, gradients.  (2) A table of few large leaves
     (classic steps: a launch of half the tiles cuts its tail along K differently) agrees to rounding, 1e-12 / 1e-10, and against
     the oracle on sampled leaves at the north-star tolerance.  (3) Two fits with two lanes are bit-identical (fixed summation
-    orders per lane, no atomics); the automatic rule takes two lanes from 64 sharing groups on and one below."""
+    orders per lane, no atomics); the automatic rule takes two lanes from 8 sharing groups on and one below."""
     def table(sizes, seed, D=3, n_test=96):
         N = int(np.sum(sizes)) + 10
         X, y, Xt = regression_data(N, D, n_test=n_test, seed=seed)
@@ -1978,9 +1978,9 @@ def test_two_leaf_lanes_agree_with_one_lane(ctx):
 
     try:
         # (1) fused steps only
-        sizes = np.random.default_rng(5).integers(130, 701, size=300)
+        sizes = np.random.default_rng(5).integers(130, 641, size=300)      # five block steps at most: all of them run fused
         X, y, Xt, obs = table(sizes, 7101)
-        for joint in (True, False):
+        for joint in (False, True):
             one, two = run(1, X, y, Xt, obs, joint), run(2, X, y, Xt, obs, joint)
             assert one[4] == 1 and two[4] == 2
             for a, b in zip(one[:4], two[:4]):
@@ -1992,7 +1992,9 @@ def test_two_leaf_lanes_agree_with_one_lane(ctx):
         sizes = np.array([2100, 2100, 1900, 1700, 1500, 1300, 900, 700, 2300, 1100])
         X, y, Xt, obs = table(sizes, 7102, n_test=150)
         one, two = run(1, X, y, Xt, obs, True), run(2, X, y, Xt, obs, True)
-        assert two[4] == 2 and run(0, X, y, Xt, obs, True)[4] == 1         # automatic: 9 sharing groups -> one lane
+        assert two[4] == 2 and run(0, X, y, Xt, obs, True)[4] == 2         # automatic: 9 sharing groups -> two lanes
+        few = [o for o in obs[:5]]
+        assert run(0, X, y, Xt, few, True)[4] == 1                         # 4 sharing groups -> one
         assert np.allclose(one[0], two[0], rtol=1e-12) and np.allclose(one[1], two[1], rtol=1e-10, atol=1e-12)
         assert np.allclose(one[2], two[2], rtol=1e-9, atol=1e-13) and np.allclose(one[3], two[3], rtol=1e-8, atol=1e-9)
         for l in (0, 7, 8):

@@ -20,6 +20,8 @@ def options(ctx):
         ctx.set_option(dsm.hipabi.OPT_DIAG_IN_UPDATE, 0)
     if "--graph" in xa:
         ctx.set_option(dsm.hipabi.OPT_FIT_GRAPH, 1)
+    if "--lanes" in xa:
+        ctx.set_option(dsm.hipabi.OPT_LANES, int(xa.split("--lanes")[1].split()[0]))
 options(gp.model.ctx)
 def step2():
     dsm.update_cholesky(gp); return dsm.prediction(gp, Xt)

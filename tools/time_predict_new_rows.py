@@ -40,3 +40,20 @@ for rep in range(6):
     t3 = time.perf_counter()
     print(f"{cfg}: predict on new rows {t3 - t2:.4f} s (device sweep {model.last_predict_seconds:.4f}): " +
           ", ".join(f"{k} {v:.4f}" for k, v in acc.items()), flush=True)
+
+# Where does a sweep right after a registration spend the milliseconds its event span does not show?  The same call with a pause
+# between registration and sweep:
+if os.environ.get("DSMGP_PAUSE"):
+    orig = ctx.set_test_routed
+
+    def paused(xt):
+        r = orig(xt)
+        time.sleep(float(os.environ["DSMGP_PAUSE"]))
+        return r
+    ctx.set_test_routed = paused
+    for rep in range(4):
+        x = np.ascontiguousarray(Xt[::-1] if rep % 2 == 0 else Xt)
+        acc.clear()
+        mu, var = dsm.predict(model, x)
+        print(f"{cfg}: with a {os.environ['DSMGP_PAUSE']} s pause after the registration: device sweep {model.last_predict_seconds:.4f}: " +
+              ", ".join(f"{k} {v:.4f}" for k, v in acc.items()), flush=True)
