@@ -91,7 +91,9 @@ def build_model(cfg, rank, world, device, n_sub=1, hyper="survey"):
 def default_sub(world):
     """Concurrent contexts per GPU (hipabi.MultiContext: the leaves of this rank split over several contexts driven from
     host threads, so that one context's dependent chain of diagonal block / panel solve / reduce launches runs under
-    another's update launches).  ONE since round 3, at every world size: with the chain itself shortened (diagonal-block
+    another's update launches).  Since round 5 the library does that INSIDE one context (two leaf lanes, DSMGP_OPT_LANES,
+    --lanes: no second copy of X, no host threads, the device exchange stays possible), so this stays at ONE.  History:
+    ONE since round 3, at every world size: with the chain itself shortened (diagonal-block
     launch 51 -> 35 us, fused shallow steps) extra contexts no longer pay on the shards of a multi-GPU job -- one shard at
     a time on one GPU, same box, 1 / 2 / 3 contexts: 2 ranks 0.1996 / 0.1979 / 0.2054 s, 4 ranks 0.1051 / 0.1067 / 0.1142
     and 0.1062 / 0.1072 / 0.1144, 8 ranks 0.0582 / 0.0638 / 0.0646 and 0.0593 / 0.0581 / 0.0635 (round 2 ran 8 ranks with
@@ -372,7 +374,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="diagnostic: DSMGP_OPT_FIT_GRAPH = 1 (the untimed fits replay a captured hipGraph)")
     ap.add_argument("--no-diag-ahead", action="store_true",
                     help="diagnostic: DSMGP_OPT_DIAG_IN_UPDATE = 0 (a diagonal-block launch per classic step), for A/B runs")
-    ap.add_argument("--lanes", type=int, default=None, choices=[0, 1, 2],
+    ap.add_argument("--lanes", type=int, default=None, choices=[0, 1, 2, 3, 4],
                     help="leaf lanes inside the context (DSMGP_OPT_LANES): default 0 = automatic (two from 64 sharing groups on)")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
@@ -642,6 +644,30 @@ def main():
                               "running its own sweep (the reference's call pattern, src/common.jl:304); predict_new_rows: "
                               "predict(model, x) on a test matrix the model has not seen (routing, registration, sweep)"}
 
+    # With two leaf lanes the launches of the roofline kernel overlap: the SAME step once more on one lane (untimed extra: plan and
+    # test set are rebuilt for it), so that the per-launch figure of earlier rounds stays readable beside the union-based one.
+    single_lane = None
+    if roof is not None and lanes > 1 and standalone is not None:
+        model.set_option(dsm.hipabi.OPT_LANES, 1)
+        ctx.set_profile(1)
+        dsm.resident_test(model, Xt)
+        step()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        tm1 = ctx.timings()
+        slot = "chol_fused" if fused_dominant else "chol_update"
+        fl1, nl1 = ctx.work_fused() if fused_dominant else ctx.work()
+        if tm1.get(slot, 0.0) > 0 and nl1 > 0:
+            single_lane = {"step_s": min(ts), "avg_launch_ms": tm1[slot] / nl1 * 1e3, "launches_per_step": nl1,
+                           "achieved": fl1 / tm1[slot] / 1e12, "frac": fl1 / tm1[slot] / 1e12 / F64_MATRIX_PEAK_TFLOPS,
+                           "note": "the same step with DSMGP_OPT_LANES = 1, two untimed repetitions after one to rebuild the lists: "
+                                   "flops of a launch over its own duration, as in the lines of rounds 1-4"}
+        model.set_option(dsm.hipabi.OPT_LANES, args.lanes if args.lanes is not None else 0)
+        roof["single_lane"] = single_lane
+
     if rank == 0:
         c = CONFIGS[args.config]
         out = {
@@ -658,6 +684,7 @@ def main():
                                    f"fit! (Gram+Cholesky+forward solve+mll) + update! + predict",
                        "parallelism": f"leaves sharded over {world} GPU(s), all-gather of mll and of the aggregation's partial sums"
                                       + (f"; {n_sub} concurrent contexts per GPU" if n_sub > 1 else "")
+                                      + (f"; {lanes} leaf lanes inside the context" if lanes > 1 else "")
                                       + (f"; exchange: {model.shard.exchange} over the {exchange_backend} process group"
                                          if world > 1 else "")},
             "matrix_tflops_fit_predict": matrix_flops_total / ((cats.get("total_fit", 0.0) + cats.get("total_predict", 0.0))

@@ -74,6 +74,7 @@ struct HostLog {
 };
 
 enum { STEP_CLASSIC = 0, STEP_FUSED = 1 };
+constexpr int MAX_LANES = 4;
 #ifndef DSMGP_FUSED_SHALLOW
 #define DSMGP_FUSED_SHALLOW 4
 #endif
@@ -402,21 +403,21 @@ struct dsmgp_ctx {
     // own, joined at the end of fit!.  One lane's latency-bound launches (diagonal blocks, panel solves, split-K reduces) then
     // run under the other's update launches -- what several contexts per GPU bought (hipabi.MultiContext: headline -1.4 %, depth
     // 4 -3..-4 %) without a second copy of X, a second plan or host threads.  Per-leaf results do not depend on the lane.
-    int lanes_opt = 0;              // 0 = auto (lanes_for), 1, 2
+    int lanes_opt = 0;              // 0 = automatic, 1 .. MAX_LANES
     int nlanes = 1;                 // lanes of the current plan
-    hipStream_t lane_stream[2] = {nullptr, nullptr};   // [0] = stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t lane_stream[MAX_LANES] = {};           // [0] = stream
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
     std::vector<char> leaf_lane;    // per leaf (COPY / PREFIX leaves: their source's)
-    StepLists phase[2][2];          // [lane][0: FULL leaves, 1: PREFIX leaves (need their source first)]
+    StepLists phase[MAX_LANES][2];  // [lane][0: FULL leaves, 1: PREFIX leaves (need their source first)]
     std::vector<char> leaf_group;   // per leaf: the phase it belongs to (COPY leaves ride with their source)
     // Optional device pool (dsmgp_reserve): the large arenas are carved out of one allocation made once, in stack
     // order plan < test < gradients, instead of hipMalloc/hipFree per leaf table -- the driver clears memory on
     // allocation (5 s per 230 GB group measured), which dominated the streaming mode's wall time.
     char* pool_base = nullptr;
     size_t pool_cap = 0, pool_top = 0, pool_mark_plan = 0;
-    double* slabF[2] = {nullptr, nullptr};   // split-K workspace of the factorisation, per lane
-    StepLists phaseJ[2][2];         // the same with the resident test rows riding along (built by set_test)
-    double* slabJ[2] = {nullptr, nullptr};
+    double* slabF[MAX_LANES] = {};  // split-K workspace of the factorisation, per lane
+    StepLists phaseJ[MAX_LANES][2]; // the same with the resident test rows riding along (built by set_test)
+    double* slabJ[MAX_LANES] = {};
     double alg_flops_joint = 0.0;
     bool joint = true;              // fit advances the resident test rows too
     bool joint_ready = false;
@@ -464,7 +465,6 @@ struct dsmgp_ctx {
     size_t cap_dXt = 0, cap_route_ptr = 0, cap_route_idx = 0, cap_row_ptr = 0, cap_row_ent = 0, cap_ent_leaf = 0, cap_agg_coef = 0,
            cap_agg_group = 0, cap_agg_out = 0, cap_Xt = 0, cap_PV = 0, cap_slabP = 0;
     DevBuf<SweepSeg> psegs;         // (leaf, block step) pairs of the sweep's fused steps: build_sweep8_kernel makes the tasks
-    DevBuf<ZeroRange> pzero;        // K_tn rows that must start as zeros (leaves whose sweep has classic steps)
     double* arenaXt = nullptr;
     double* arenaPV = nullptr;      // mu | var (route order, unpadded) | macc | sacc (padded accumulators of the sweep)
     size_t acc_off = 0, acc_count = 0;
@@ -769,7 +769,6 @@ void free_test(dsmgp_ctx* c, bool keep) {
     dev_drop(c->pred, keep);
     dev_drop(c->psweep8, keep);
     dev_drop(c->psegs, keep);
-    dev_drop(c->pzero, keep);
     for (auto& lane : c->phaseJ)
         for (auto& ph : lane) {
             dev_drop(ph.upd, keep);
@@ -1420,17 +1419,20 @@ int build_plan(dsmgp_ctx* c) {
         int nunits = 0;
         for (int l = 0; l < L; ++l) nunits += unit[l] == l ? 1 : 0;
         c->nlanes = c->lanes_opt > 0 ? c->lanes_opt : ((nunits >= LANES_AUTO_MIN_LEAVES && !c->pool_base) ? 2 : 1);
-        if (c->pool_base || nunits < 2) c->nlanes = 1;      // (the pool is a stack: one split-K workspace per table)
+        if (c->pool_base) c->nlanes = 1;                    // (the pool is a stack: one split-K workspace per table)
+        c->nlanes = std::max(1, std::min(c->nlanes, nunits));
         c->leaf_lane.assign(L, 0);
-        if (c->nlanes == 2) {
+        if (c->nlanes > 1) {
             std::vector<int> order;
             for (int l = 0; l < L; ++l)
                 if (unit[l] == l) order.push_back(l);
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-            double load[2] = {0.0, 0.0};
+            double load[MAX_LANES] = {};
             std::vector<char> of_unit(L, 0);
             for (int u : order) {
-                const int lane = load[1] < load[0] ? 1 : 0;
+                int lane = 0;
+                for (int q = 1; q < c->nlanes; ++q)
+                    if (load[q] < load[lane]) lane = q;
                 of_unit[u] = (char)lane;
                 load[lane] += cost[u];
             }
@@ -1819,14 +1821,18 @@ int run_lanes(dsmgp_ctx* c, StepLists (*lists)[2], int ph, PhaseTimer& pt, bool 
     if (nsteps == 0) return 0;
     if (c->nlanes > 1) {
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->lane_stream[1], c->ev_fork, 0));
+        for (int lane = 1; lane < c->nlanes; ++lane) HIPCHK(c, hipStreamWaitEvent(c->lane_stream[lane], c->ev_fork, 0));
     }
+    // (Starting the second lane half a step late -- after the first launch of the first lane's step 0, so that the latency-bound
+    // launches of one lane meet the pipe-bound ones of the other from the start -- measured nothing: headline 0.3870 / 0.3865 /
+    // 0.3928 plain, 0.3870 / 0.3878 / 0.3922 staggered; depth 4 0.0495 / 0.0500 / 0.0495 against 0.0501 / 0.0498 / 0.0500
+    // (profiles/r05_lane_stagger_ab.log): the lanes drift apart by themselves within a few steps.)
     for (int k = 0; k < nsteps; ++k)
         for (int lane = 0; lane < c->nlanes; ++lane) run_step(c, lists[lane][ph], k, pt, c->lane_stream[lane], count_launches);
     HIPCHK(c, hipGetLastError());
-    if (c->nlanes > 1) {
-        HIPCHK(c, hipEventRecord(c->ev_join, c->lane_stream[1]));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    for (int lane = 1; lane < c->nlanes; ++lane) {
+        HIPCHK(c, hipEventRecord(c->ev_join[lane], c->lane_stream[lane]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[lane], 0));
     }
     return 0;
 }
@@ -1885,11 +1891,14 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
     c->lane_stream[0] = c->stream;
-    if (hipStreamCreate(&c->lane_stream[1]) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    bool lanes_ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int lane = 1; lane < MAX_LANES && lanes_ok; ++lane)
+        lanes_ok = hipStreamCreate(&c->lane_stream[lane]) == hipSuccess &&
+                   hipEventCreateWithFlags(&c->ev_join[lane], hipEventDisableTiming) == hipSuccess;
+    if (!lanes_ok) {
         (void)hipStreamDestroy(c->stream);
         delete c;
-        return fail(nullptr, DSMGP_E_HIP, "cannot create the second lane's stream");
+        return fail(nullptr, DSMGP_E_HIP, "cannot create the lanes' streams");
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_packed_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, DIAGP_LDS_BYTES);
@@ -1938,8 +1947,10 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     dev_free(c->rws_bits);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->lane_stream[1]) (void)hipStreamDestroy(c->lane_stream[1]);
+    for (int lane = 1; lane < MAX_LANES; ++lane) {
+        if (c->ev_join[lane]) (void)hipEventDestroy(c->ev_join[lane]);
+        if (c->lane_stream[lane]) (void)hipStreamDestroy(c->lane_stream[lane]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -1995,7 +2006,7 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
         return 0;
     }
     if (option == DSMGP_OPT_LANES) {
-        if (value < 0 || value > 2) return fail(c, DSMGP_E_ARG, "set_option: lanes must be 0 (automatic), 1 or 2");
+        if (value < 0 || value > MAX_LANES) return fail(c, DSMGP_E_ARG, "set_option: lanes must be 0 (automatic) or 1 .. 4");
         if (value != c->lanes_opt) {
             HIPCHK(c, hipSetDevice(c->device));
             free_plan(c);
@@ -2426,27 +2437,24 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
     // all leaves beyond the shallow steps of a model with few).
     std::vector<SweepSeg> segs;
     std::vector<std::vector<int>> classic((size_t)nsteps);
-    std::vector<ZeroRange> zr;
     {
         std::vector<int> cnt8((size_t)nsteps, 0);
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
             if (lf.nt == 0) continue;
             const int nt8 = ((lf.nt + 15) / 16 + 7) / 8;
-            bool any_classic = false;
             for (int k = 0; k < lf.nb; ++k) {
-                if (fused_at(l, k)) {
-                    cnt8[(size_t)k] += nt8;
-                } else {
-                    classic[(size_t)k].push_back(l);
-                    any_classic = true;
-                }
+                if (fused_at(l, k)) cnt8[(size_t)k] += nt8;
+                else classic[(size_t)k].push_back(l);
             }
-            // the update / panel-solve tiles of the classic steps read and write whole 128-row tiles: the rows beyond the routed
-            // ones must be zeros (the Gram kernel writes data rows only, gram_half_tile).  Fused tasks touch the 16-row blocks
-            // that hold data and nothing else: a leaf without classic steps needs no zeros (at depth 4: 9.6 GB not cleared)
-            if (any_classic) zr.push_back(ZeroRange{c->h_leaves[l].Vt, (size_t)lf.ntpad * (size_t)lf.npad});
         }
+        // (The K_tn arena is NOT cleared.  Rounds 1-4 zeroed it at every registration because the update / panel-solve tiles of
+        // the classic steps read and write whole 128-row tiles while the Gram kernel writes data rows only -- but a row of a tile
+        // product depends on its own row of the first operand alone, every rider sums per row, and nothing reads a row beyond a
+        // leaf's routed ones (pred_finish / pred_mu / pred_var stop at nt): what sits in the padding rows never reaches a result.
+        // Clearing cost more than its own time: 9.6 GB per registration at depth 4, and at the headline model a sweep that starts
+        // right behind 5.4 GB of hipMemsetAsync ran 15-25 ms longer than its own event span, on every box that was asked
+        // (profiles/r05_zero_memset_vs_kernel_ab.log; gone after a 50 ms pause).)
         for (int k = 0; k < nsteps; ++k) c->psweep8_off[(size_t)k + 1] = c->psweep8_off[(size_t)k] + cnt8[(size_t)k];
         std::vector<int> cursor((size_t)nsteps, 0);
         segs.reserve((size_t)L * 4);
@@ -2529,8 +2537,6 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
     if (!segs.empty())
         build_sweep8_kernel<<<(unsigned)((segs.size() + 127) / 128), 128, 0, c->stream>>>(c->psegs.p, (int)segs.size(), c->d_leaves, c->psweep8.p,
                                                                                         c->xcd_order ? 1 : 0);
-    if (int rc = dev_upload(c, c->pzero, zr)) return rc;
-    if (!zr.empty()) zero_ranges_kernel<<<dim3(128, (unsigned)zr.size()), 256, 0, c->stream>>>(c->pzero.p);
     HIPCHK(c, hipGetLastError());
     if (U.max_slabs) {
         if (c->pool_base) {

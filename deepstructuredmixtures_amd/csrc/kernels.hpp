@@ -107,8 +107,9 @@ __device__ __forceinline__ void gram_half_tile(const GramTask& tk, const KParam&
     const int r0 = (t & 31) * 4;
     const int cb = t >> 5;
     const int c0 = 64 * half;
-    // K_tn tiles (sym == 0): the four rows of this thread are all padding -> nothing to compute or store; the padding
-    // rows of the K_tn arena are zeroed once by dsmgp_set_test and every later kernel keeps zero rows zero
+    // K_tn tiles (sym == 0): the four rows of this thread are all padding -> nothing to compute or store.  What the padding rows
+    // of the K_tn arena hold never reaches a result (a row of a tile product depends on its own operand row only, the riders sum
+    // per row, nothing reads beyond a leaf's routed rows): since round 5 the arena is not even cleared (register_test)
     const bool rows_live = tk.sym != 0 || r0 < tk.na;
     double acc[8][4];
 #pragma unroll

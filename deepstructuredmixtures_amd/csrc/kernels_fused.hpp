@@ -475,20 +475,6 @@ __global__ __launch_bounds__(128) void build_sweep8_kernel(const SweepSeg* __res
     }
 }
 
-// p[0 .. count) <- 0 for a list of ranges (the K_tn rows of the leaves whose sweep has classic steps: register_test)
-struct ZeroRange {
-    double* p;
-    size_t count;
-};
-__global__ __launch_bounds__(256) void zero_ranges_kernel(const ZeroRange* __restrict__ ranges) {
-    const ZeroRange zr = ranges[blockIdx.y];
-    const d2 zero = {0.0, 0.0};
-    d2* q = reinterpret_cast<d2*>(zr.p);                // arenas and leaf offsets are multiples of 128 doubles
-    const size_t n2 = zr.count / 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) q[i] = zero;
-    if ((zr.count & 1) && blockIdx.x == 0 && threadIdx.x == 0) zr.p[zr.count - 1] = 0.0;
-}
-
 // Rows [r0, 128) of a block row of a factor over `ncols` columns <- 0 (build_plan: the padding rows below a leaf's last data rows)
 struct ZeroRowsTask {
     double* p;

@@ -57,3 +57,22 @@ if os.environ.get("DSMGP_PAUSE"):
         mu, var = dsm.predict(model, x)
         print(f"{cfg}: with a {os.environ['DSMGP_PAUSE']} s pause after the registration: device sweep {model.last_predict_seconds:.4f}: " +
               ", ".join(f"{k} {v:.4f}" for k, v in acc.items()), flush=True)
+
+# Is the device simply not available for a while after a registration?  A 1 ms one-wave kernel on the side stream, timed on the
+# host right behind the registration, then the sweep.
+if os.environ.get("DSMGP_PROBE_AFTER"):
+    orig2 = ctx.set_test_routed
+
+    def probed(xt):
+        r = orig2(xt)
+        t0 = time.perf_counter()
+        ctx.clock_sample_start(1.0)
+        ghz, ms = ctx.clock_sample_read()
+        print(f"   1 ms sampler right behind the registration: {1e3 * (time.perf_counter() - t0):.2f} ms on the host, {ghz:.3f} GHz over {ms:.2f} ms", flush=True)
+        return r
+    ctx.set_test_routed = probed
+    for rep in range(4):
+        x = np.ascontiguousarray(Xt[::-1] if rep % 2 == 0 else Xt)
+        acc.clear()
+        mu, var = dsm.predict(model, x)
+        print(f"{cfg}: device sweep {model.last_predict_seconds:.4f}: " + ", ".join(f"{k} {v:.4f}" for k, v in acc.items()), flush=True)
