@@ -1987,6 +1987,17 @@ def test_two_leaf_lanes_agree_with_one_lane(ctx):
                 assert np.array_equal(a, b)
         again = run(2, X, y, Xt, obs, True)
         assert all(np.array_equal(a, b) for a, b in zip(two[:4], again[:4]))
+        # the captured hipGraph of a two-lane fit (fork / join across the lanes' streams inside the capture) replays the same bits
+        ctx.set_option(hipabi.OPT_FIT_GRAPH, 1)
+        ctx.set_profile(0)
+        try:
+            g1 = run(2, X, y, Xt, obs, True)
+            g2 = ctx.fit()
+            assert all(np.array_equal(a, b) for a, b in zip(two[:4], g1[:4])) and np.array_equal(g2[0], two[0])
+            four = run(4, X, y, Xt, obs, True)
+            assert four[4] == 4 and all(np.array_equal(a, b) for a, b in zip(two[:4], four[:4]))
+        finally:
+            ctx.set_option(hipabi.OPT_FIT_GRAPH, 0)
         assert run(0, X, y, Xt, obs, True)[4] == 2                         # automatic: 299 sharing groups
         # (2) classic steps, split along K
         sizes = np.array([2100, 2100, 1900, 1700, 1500, 1300, 900, 700, 2300, 1100])

@@ -79,7 +79,7 @@ def write_traffic(per_step):
     res = {"source_stamp": bench.source_stamp(), "commit": commit,
            "kernel": "tile_gemm_kernel_v2<false, 0, false>: update launches of the last fit (test rows riding along)",
            "launches": len(fu), "fetch_bytes_total": fetch, "write_bytes_total": write,
-           "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)),
+           "hbm_bytes_per_launch": (fetch + write) / max(1, len(fu)), "hbm_bytes_per_fit": fetch + write,
            "note": "FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024 over the update launches of one fit; separate --pmc "
                    "passes of `python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline`, taken BEFORE the stats pass of the same "
                    "profile round (tools/profile_round.sh), whose bench line quotes this figure"}
