@@ -349,6 +349,7 @@ struct dsmgp_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int profile = 0;                // 0: totals only, 1: events around the update launches (dominant kernel), 2: every category
+    bool alt_names = false;         // launches under the instantiation names of profile 0 whatever the level (dsmgp_set_profile 3)
 
     int64_t N = 0;
     int D = 0;
@@ -1659,14 +1660,14 @@ void launch_tiles(dsmgp_ctx* c, const TileTask* tasks, int n, int role = 0 /* 0 
     if (!st) st = c->stream;
     if (pad) {   // launches with many padding-row tiles (small leaves): waves without data rows stay off the matrix pipe
         if (role == 1) tile_trsm_kernel<true><<<n, 256, 0, st>>>(tasks);
-        else if (c->profile == 0) tile_gemm_kernel_v2<false, 2, true><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+        else if (c->profile == 0 || c->alt_names) tile_gemm_kernel_v2<false, 2, true><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
         else tile_gemm_kernel_v2<false, 0, true><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
         return;
     }
     // ROLE only names the instantiation: with per-launch timing switched off (dsmgp_set_profile(ctx, 0)) the same code
     // runs as <false, 2>, so that a profiler's per-kernel average of <false, 0> covers exactly the launches bench.py times
     if (role == 1) tile_trsm_kernel<false><<<n, 256, 0, st>>>(tasks);   // B = inverse of a diagonal block, K = 128
-    else if (c->profile == 0) tile_gemm_kernel_v2<false, 2><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
+    else if (c->profile == 0 || c->alt_names) tile_gemm_kernel_v2<false, 2><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
     else tile_gemm_kernel_v2<false, 0><<<g, 256, 0, st>>>(tasks, nullptr, c->d_kp, c->D, dpos, dfin, ndfin);
 }
 
@@ -1776,7 +1777,8 @@ void run_step(dsmgp_ctx* c, StepLists& S, int k, PhaseTimer& pt, hipStream_t st,
         }
         if (nft8 > 0) {
             pt.begin(18, st);
-            tile_fused8_kernel<<<nft8, 512, 0, st>>>(S.ftile8.p + S.ftile8_off[k], c->d_kp, c->D);
+            if (c->profile == 0 || c->alt_names) tile_fused8_kernel<2><<<nft8, 512, 0, st>>>(S.ftile8.p + S.ftile8_off[k], c->d_kp, c->D);
+            else tile_fused8_kernel<0><<<nft8, 512, 0, st>>>(S.ftile8.p + S.ftile8_off[k], c->d_kp, c->D);
             pt.note(k, nft8, nft8);
             pt.end(st);
             if (count_launches) c->n_fused_launches++;
@@ -2029,7 +2031,8 @@ int dsmgp_set_option(dsmgp_ctx* c, int32_t option, int32_t value) {
 
 int dsmgp_set_profile(dsmgp_ctx* c, int32_t on) {
     if (!c) return DSMGP_E_ARG;
-    c->profile = on < 0 ? 0 : (on > 2 ? 2 : on);
+    c->alt_names = on == 3;         // level 3 = level 1 under the kernel names of level 0 (bench.py's single-lane extra)
+    c->profile = on < 0 ? 0 : (on == 3 ? 1 : (on > 2 ? 2 : on));
     return 0;
 }
 
@@ -2789,7 +2792,7 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
                 const int n8 = c->psweep8_off[k + 1] - c->psweep8_off[k];
                 if (n8 > 0) {
                     pt.begin(7);
-                    tile_fused8_kernel<<<n8, 512, 0, c->stream>>>(c->psweep8.p + c->psweep8_off[k], c->d_kp, c->D);
+                    tile_fused8_kernel<1><<<n8, 512, 0, c->stream>>>(c->psweep8.p + c->psweep8_off[k], c->d_kp, c->D);
                     pt.end();
                 }
                 const int nu = c->pupd_off[k + 1] - c->pupd_off[k];

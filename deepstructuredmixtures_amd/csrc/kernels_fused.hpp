@@ -410,6 +410,10 @@ __device__ __forceinline__ void tile_fused8_body(const FusedTask8* __restrict__ 
     }
 }
 
+// ROLE only names the instantiation (same code), as for tile_gemm_kernel_v2: 0 = the fused tile launches of a fit while per-launch
+// timing is on (what bench.py's roofline times where these launches dominate: a profiler's average of <0> is that quantity),
+// 1 = the launches of the standalone prediction sweep, 2 = fits without per-launch timing and bench.py's single-lane extra
+template <int ROLE>
 __global__ __launch_bounds__(512, 4) void tile_fused8_kernel(const FusedTask8* __restrict__ tasks, const KParam* __restrict__ kp, int D) {
     __shared__ __attribute__((aligned(16))) double smem[2 * NRING * KC2 * LDP + TB];
     const FusedTask8* task = tasks + blockIdx.x;

@@ -433,7 +433,7 @@ class Context:
         self._chk(self.lib.dsmgp_reserve(self.h, int(nbytes)))
 
     def set_profile(self, level):
-        """0/False: totals only; 1: update launches only; 2/True: every kernel category."""
+        """0/False: totals only; 1: update launches only; 2/True: every kernel category; 3: as 1 under the kernel names of 0."""
         lv = 2 if level is True else int(level)
         self._chk(self.lib.dsmgp_set_profile(self.h, lv))
 

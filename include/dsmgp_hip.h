@@ -214,7 +214,10 @@ int dsmgp_download_factor(dsmgp_ctx* ctx, int32_t leaf, double* F /* n x n */, d
 /* hipEvent timing per launch: level 0 = totals only, 1 = the update launches of the factorisation (the dominant
  * kernel; what bench.py's roofline uses), 2 = every kernel category (adds event records between all launches;
  * also switched on by the environment variable DSMGP_PROFILE=1 at dsmgp_create -- the only environment variable the
- * product library reads besides DSMGP_STEPLOG / DSMGP_HOSTLOG (stderr logging); none of them changes results) */
+ * product library reads besides DSMGP_STEPLOG / DSMGP_HOSTLOG (stderr logging); none of them changes results);
+ * 3 = level 1 with the launches under the kernel instantiation names of level 0 (the timed launches of bench.py run as
+ * tile_gemm_kernel_v2<false, 0, *> / tile_fused8_kernel<0>, every other launch as <false, 2, *> / <1> (sweeps) / <2>: a profiler's
+ * per-kernel average of the first names is exactly the timed quantity) */
 int dsmgp_set_profile(dsmgp_ctx* ctx, int32_t level);
 int dsmgp_timings(dsmgp_ctx* ctx, double* out /* DSMGP_N_TIMINGS, seconds of the last fit/predict */);
 /* work of the dominant kernel (the f64-MFMA Cholesky update) in the last fit: algorithmic flops over

@@ -1,7 +1,8 @@
 /*
  * c_abi_smoke.c -- a host that is NOT Python calling the C ABI of include/dsmgp_hip.h (plain C99, the header only):
  * what a Julia `ccall` (julia/DSMGPHip.jl) or any other FFI does.  One exact GP:
- *     dsmgp_create -> set_train -> set_leaves -> set_hyper -> fit -> predict_leaves -> download_factor -> destroy
+ *     dsmgp_create -> set_train -> set_leaves -> set_hyper -> fit -> predict_leaves -> download_factor
+ *     -> set_tree -> set_test_routed -> predict_run -> predict_fetch (the routing of predict on the device: same numbers) -> destroy
  * i.e. update_cholesky! / mll / prediction of src/gaussianprocess.jl:82-137,163 on the device, compared with the expected
  * numbers the caller passes in (tests/test_gpu_parity.py writes them from the mpmath-pinned fixture
  * tests/golden/gp_edge.npz; n = 160 crosses a 128-tile edge).
@@ -55,8 +56,11 @@ int main(int argc, char** argv) {
     int64_t hdr[5];
     int64_t n, D, nt, kind, nhyp, i;
     double *X, *y, *Xt, *loghyp, *scal, *mu_want, *var_want, *alpha_want;
-    double *mu, *var, *alpha, *F;
-    double mll = 0.0, seconds = 0.0, maxabs = 0.0;
+    double *mu, *var, *alpha, *F, *mu2, *var2;
+    const int8_t tree_kind[1] = {0};            /* the tree of a single GP: one region, leaf 0 of the table */
+    const int64_t tree_zero[1] = {0};
+    const double tree_thr[1] = {0.0};
+    double mll = 0.0, seconds = 0.0, sweep_seconds = 0.0, maxabs = 0.0;
     int32_t info = -1, kid = 0;
     int64_t obs_ptr[2], route_ptr[2];
     int64_t *obs_idx, *route_idx;
@@ -91,7 +95,9 @@ int main(int argc, char** argv) {
     var = (double*)malloc((size_t)nt * sizeof(double));
     alpha = (double*)malloc((size_t)n * sizeof(double));
     F = (double*)malloc((size_t)(n * n) * sizeof(double));
-    if (!obs_idx || !route_idx || !mu || !var || !alpha || !F) return 3;
+    mu2 = (double*)malloc((size_t)nt * sizeof(double));
+    var2 = (double*)malloc((size_t)nt * sizeof(double));
+    if (!obs_idx || !route_idx || !mu || !var || !alpha || !F || !mu2 || !var2) return 3;
     for (i = 0; i < n; ++i) obs_idx[i] = i;
     for (i = 0; i < nt; ++i) route_idx[i] = i;
     obs_ptr[0] = 0; obs_ptr[1] = n;
@@ -114,6 +120,18 @@ int main(int argc, char** argv) {
         fprintf(stderr, "c_abi_smoke: leaf out of range was not rejected\n");
         bad = 1;
     }
+    /* the same prediction with the rows routed on the device: tree as flat arrays, then the routed registration */
+    if ((rc = dsmgp_set_tree(ctx, 1, tree_kind, tree_zero, tree_zero, tree_zero, tree_thr, 1, tree_zero)) != 0) return fail(ctx, "dsmgp_set_tree", rc);
+    if ((rc = dsmgp_set_test_routed(ctx, Xt, nt)) != 0) return fail(ctx, "dsmgp_set_test_routed", rc);
+    if ((rc = dsmgp_routes(ctx, route_ptr, route_idx)) != 0) return fail(ctx, "dsmgp_routes", rc);
+    if (route_ptr[0] != 0 || route_ptr[1] != nt || (nt > 0 && route_idx[nt - 1] != nt - 1)) {
+        fprintf(stderr, "c_abi_smoke: device routing of a one-leaf tree is not the identity\n");
+        bad = 1;
+    }
+    if ((rc = dsmgp_predict_run(ctx, &sweep_seconds)) != 0) return fail(ctx, "dsmgp_predict_run", rc);
+    if ((rc = dsmgp_predict_fetch(ctx, mu2, var2)) != 0) return fail(ctx, "dsmgp_predict_fetch", rc);
+    bad |= close_enough("mu (routed on the device)", mu2, mu, nt, 0.0, 0.0);
+    bad |= close_enough("var (routed on the device)", var2, var, nt, 0.0, 0.0);
     if ((rc = dsmgp_destroy(ctx)) != 0) return fail(NULL, "dsmgp_destroy", rc);
 
     bad |= close_enough("mll", &mll, &scal[1], 1, 1e-8, 0.0);
