@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <array>
 #include <chrono>
 #include <dlfcn.h>
@@ -80,6 +81,9 @@ constexpr int MAX_LANES = 4;
 #endif
 constexpr int FUSED_SHALLOW_STEPS = DSMGP_FUSED_SHALLOW;   // block steps 0..4 (K <= 512) run fused where at least ...
 constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leaves take part in the step
+#ifndef DSMGP_STREAM_FLAGS
+#define DSMGP_STREAM_FLAGS hipStreamDefault
+#endif
 #ifndef DSMGP_LANES_AUTO_MIN
 #define DSMGP_LANES_AUTO_MIN 8
 #endif
@@ -465,6 +469,10 @@ struct dsmgp_ctx {
     // capacities of the test set's other buffers (dev_grow: kept across registrations, freed with the context / the plan)
     size_t cap_dXt = 0, cap_route_ptr = 0, cap_route_idx = 0, cap_row_ptr = 0, cap_row_ent = 0, cap_ent_leaf = 0, cap_agg_coef = 0,
            cap_agg_group = 0, cap_agg_out = 0, cap_Xt = 0, cap_PV = 0, cap_slabP = 0;
+    // pinned host staging for the uploads of a registration (stage_upload): the lists of a test set are ~10 MB at the headline
+    // model; through hipMemcpy from pageable vectors they took 9 ms of a 25 ms registration and left the runtime busy behind them
+    char* stage = nullptr;
+    size_t stage_cap = 0, stage_top = 0;
     DevBuf<SweepSeg> psegs;         // (leaf, block step) pairs of the sweep's fused steps: build_sweep8_kernel makes the tasks
     double* arenaXt = nullptr;
     double* arenaPV = nullptr;      // mu | var (route order, unpadded) | macc | sacc (padded accumulators of the sweep)
@@ -479,6 +487,7 @@ struct dsmgp_ctx {
     DevBuf<TileTask> pupd, ptrsm;
     DevBuf<ReduceTask> pred;
     int psteps = 0;
+    int plan_lanes_test = 1;        // lanes the registered test set's sweep lists were built for
     bool test_ready = false;
     bool predicted = false;
     int64_t route_total = 0;
@@ -626,6 +635,39 @@ void dev_drop(T*& p, size_t& cap, bool keep) {
 bool in_pool(const dsmgp_ctx* c, const void* p) {
     return c->pool_base && (const char*)p >= c->pool_base && (const char*)p < c->pool_base + c->pool_cap;
 }
+// `bytes` from host memory to the device through the context's PINNED staging buffer, asynchronously on the context's stream: the
+// caller's memory is free again on return, the copy is done once the stream is synchronised (stage_done, which every user calls
+// before it returns).  Grows on demand; growing waits for the copies in flight.
+int stage_upload(dsmgp_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return 0;
+    const size_t at = (c->stage_top + 63) & ~size_t(63);
+    if (at + bytes > c->stage_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->stage) (void)hipHostFree(c->stage);
+        c->stage = nullptr;
+        c->stage_cap = 0;
+        c->stage_top = 0;
+        const size_t want = std::max<size_t>(size_t(8) << 20, 2 * (at + bytes));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->stage), want, hipHostMallocDefault));
+        c->stage_cap = want;
+        return stage_upload(c, dst, src, bytes);
+    }
+    std::memcpy(c->stage + at, src, bytes);
+    c->stage_top = at + bytes;
+    HIPCHK(c, hipMemcpyAsync(dst, c->stage + at, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int stage_done(dsmgp_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stage_top = 0;
+    return 0;
+}
+template <class T>
+int stage_upload_list(dsmgp_ctx* c, DevBuf<T>& buf, const std::vector<T>& host) {     // dev_upload through the staging buffer
+    if (int rc = dev_reserve(c, buf, host.size())) return rc;
+    return stage_upload(c, buf.p, host.data(), host.size() * sizeof(T));
+}
+
 // `count` doubles for one of the large arenas: from the pool when there is one, else its own allocation
 int arena_get(dsmgp_ctx* c, double*& p, size_t count) {
     const size_t bytes = std::max<size_t>(1, count) * sizeof(double);
@@ -1888,14 +1930,14 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, DSMGP_E_ARG, "device id out of range");
     dsmgp_ctx* c = new dsmgp_ctx();
     c->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, DSMGP_STREAM_FLAGS) != hipSuccess) {
         delete c;
         return fail(nullptr, DSMGP_E_HIP, "cannot initialise device");
     }
     c->lane_stream[0] = c->stream;
     bool lanes_ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int lane = 1; lane < MAX_LANES && lanes_ok; ++lane)
-        lanes_ok = hipStreamCreate(&c->lane_stream[lane]) == hipSuccess &&
+        lanes_ok = hipStreamCreateWithFlags(&c->lane_stream[lane], DSMGP_STREAM_FLAGS) == hipSuccess &&
                    hipEventCreateWithFlags(&c->ev_join[lane], hipEventDisableTiming) == hipSuccess;
     if (!lanes_ok) {
         (void)hipStreamDestroy(c->stream);
@@ -1947,6 +1989,8 @@ int dsmgp_destroy(dsmgp_ctx* c) {
     free_tree(c);
     dev_free(c->rws_counts);
     dev_free(c->rws_bits);
+    if (c->stage) (void)hipHostFree(c->stage);
+    c->stage = nullptr;
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int lane = 1; lane < MAX_LANES; ++lane) {
@@ -2372,7 +2416,7 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
         d.ntpad = lf.ntpad;
         maxpad = std::max(maxpad, lf.ntpad);
     }
-    HIPCHK(c, hipMemcpy(c->d_leaves, c->h_leaves.data(), L * sizeof(LeafDev), hipMemcpyHostToDevice));
+    if (int rc = stage_upload(c, c->d_leaves, c->h_leaves.data(), (size_t)L * sizeof(LeafDev))) return rc;
     if (maxpad > 0) {
         for (int l0 = 0; l0 < L; l0 += 32768) {
             const int cnt = std::min(32768, L - l0);
@@ -2424,66 +2468,78 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
         }
     }
     c->psteps = nsteps;
-    UpdateSplitter U;
-    U.ncu = c->ncu;
-    U.xcd = c->xcd_order;
-    U.tail_split = c->tail_split;
-    U.tail_rounds = c->tail_rounds;
-    std::vector<TileTask> trsm;
-    c->pupd_off.assign(nsteps + 1, 0);
-    c->pred_off.assign(nsteps + 1, 0);
-    c->ptrsm_off.assign(nsteps + 1, 0);
-    c->psweep8_off.assign(nsteps + 1, 0);
+    // The sweep runs lane by lane like the factorisation (dsmgp_ctx::nlanes): the lists of lane q's block step k are entry
+    // q * nsteps + k of the offset tables, one lane's panel solves and reduces run under the other's update launches.
+    const int nl = c->nlanes, nv = nl * nsteps;
+    c->plan_lanes_test = nl;
+    std::vector<UpdateSplitter> U((size_t)nl);
+    for (UpdateSplitter& u : U) {
+        u.ncu = c->ncu;
+        u.xcd = c->xcd_order;
+        u.tail_split = c->tail_split;
+        u.tail_rounds = c->tail_rounds;
+    }
+    std::vector<std::vector<TileTask>> trsm_l((size_t)nl);
+    std::vector<int> upd_loc((size_t)nv + 1, 0), red_loc((size_t)nv + 1, 0), trsm_loc((size_t)nv + 1, 0);   // offsets inside the lane's own lists
+    c->pupd_off.assign(nv + 1, 0);
+    c->pred_off.assign(nv + 1, 0);
+    c->ptrsm_off.assign(nv + 1, 0);
+    c->psweep8_off.assign(nv + 1, 0);
     // Fused steps: the tasks are made on the device (build_sweep8_kernel) from one SweepSeg per (leaf, step); the host counts them
     // per step -- a leaf of nt routed rows has ceil(ceil(nt / 16) / 8) tasks in each of its fused steps -- and says where each
     // pair's tasks start.  Classic steps: the leaves that have them, per step (few: the largest leaves of a many-leaf model,
     // all leaves beyond the shallow steps of a model with few).
     std::vector<SweepSeg> segs;
-    std::vector<std::vector<int>> classic((size_t)nsteps);
+    std::vector<std::vector<int>> classic((size_t)nv);
     {
-        std::vector<int> cnt8((size_t)nsteps, 0);
+        std::vector<int> cnt8((size_t)nv, 0);
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
             if (lf.nt == 0) continue;
             const int nt8 = ((lf.nt + 15) / 16 + 7) / 8;
+            const size_t v0 = (size_t)c->leaf_lane[l] * (size_t)nsteps;
             for (int k = 0; k < lf.nb; ++k) {
-                if (fused_at(l, k)) cnt8[(size_t)k] += nt8;
-                else classic[(size_t)k].push_back(l);
+                if (fused_at(l, k)) cnt8[v0 + (size_t)k] += nt8;
+                else classic[v0 + (size_t)k].push_back(l);
             }
         }
         // (The K_tn arena is NOT cleared.  Rounds 1-4 zeroed it at every registration because the update / panel-solve tiles of
         // the classic steps read and write whole 128-row tiles while the Gram kernel writes data rows only -- but a row of a tile
         // product depends on its own row of the first operand alone, every rider sums per row, and nothing reads a row beyond a
         // leaf's routed ones (pred_finish / pred_mu / pred_var stop at nt): what sits in the padding rows never reaches a result.
-        // Clearing cost more than its own time: 9.6 GB per registration at depth 4, and at the headline model a sweep that starts
-        // right behind 5.4 GB of hipMemsetAsync ran 15-25 ms longer than its own event span, on every box that was asked
-        // (profiles/r05_zero_memset_vs_kernel_ab.log; gone after a 50 ms pause).)
-        for (int k = 0; k < nsteps; ++k) c->psweep8_off[(size_t)k + 1] = c->psweep8_off[(size_t)k] + cnt8[(size_t)k];
-        std::vector<int> cursor((size_t)nsteps, 0);
+        // Clearing cost more than its own time: 9.6 GB per registration at depth 4.)
+        for (int v = 0; v < nv; ++v) c->psweep8_off[(size_t)v + 1] = c->psweep8_off[(size_t)v] + cnt8[(size_t)v];
+        std::vector<int> cursor((size_t)nv, 0);
         segs.reserve((size_t)L * 4);
         for (int l = 0; l < L; ++l) {
             const LeafHost& lf = c->leaves[l];
             if (lf.nt == 0) continue;
             const int nt8 = ((lf.nt + 15) / 16 + 7) / 8;
+            const size_t v0 = (size_t)c->leaf_lane[l] * (size_t)nsteps;
             for (int k = 0; k < lf.nb; ++k)
                 if (fused_at(l, k)) {
                     SweepSeg sg{};
                     sg.leaf = l;
                     sg.k = k;
-                    sg.src0 = cursor[(size_t)k];
-                    sg.begin = c->psweep8_off[(size_t)k];
-                    sg.n = cnt8[(size_t)k];
+                    sg.src0 = cursor[v0 + (size_t)k];
+                    sg.begin = c->psweep8_off[v0 + (size_t)k];
+                    sg.n = cnt8[v0 + (size_t)k];
                     segs.push_back(sg);
-                    cursor[(size_t)k] += nt8;
+                    cursor[v0 + (size_t)k] += nt8;
                 }
         }
     }
-    for (int k = 0; k < nsteps; ++k) {
-        c->pupd_off[k] = (int)U.upd.size();
-        c->pred_off[k] = (int)U.red.size();
-        c->ptrsm_off[k] = (int)trsm.size();
+    // (the lanes' lists are independent: one host thread per lane -- 90k tile tasks at the headline model, 10 ms on one thread)
+    auto build_lane = [&](int lane) {
+      for (int k = 0; k < nsteps; ++k) {
+        const int v = lane * nsteps + k;
+        UpdateSplitter& Ul = U[(size_t)lane];
+        std::vector<TileTask>& trsm = trsm_l[(size_t)lane];
+        upd_loc[(size_t)v] = (int)Ul.upd.size();
+        red_loc[(size_t)v] = (int)Ul.red.size();
+        trsm_loc[(size_t)v] = (int)trsm.size();
         std::vector<TileTask> tiles;
-        for (int l : classic[(size_t)k]) {
+        for (int l : classic[(size_t)v]) {
             const LeafHost& lf = c->leaves[l];
             const LeafDev& d = c->h_leaves[l];
             for (int ti = 0; ti < lf.ntpad / TB; ++ti) {
@@ -2529,35 +2585,75 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
                 trsm.push_back(s);
             }
         }
-        U.add_step(tiles, k * TB);
+        Ul.add_step(tiles, k * TB);
+      }
+    };
+    if (nl > 1) {
+        std::vector<std::thread> th;
+        for (int q = 1; q < nl; ++q) th.emplace_back(build_lane, q);
+        build_lane(0);
+        for (std::thread& t : th) t.join();
+    } else {
+        build_lane(0);
     }
-    c->pupd_off[nsteps] = (int)U.upd.size();
-    c->pred_off[nsteps] = (int)U.red.size();
-    c->ptrsm_off[nsteps] = (int)trsm.size();
+    // one split-K workspace per lane, one list of each kind for all lanes (lane after lane)
+    size_t slab_tot = 0;
+    std::vector<size_t> slab_base((size_t)nl, 0);
+    for (int q = 0; q < nl; ++q) {
+        slab_base[(size_t)q] = slab_tot;
+        slab_tot += U[(size_t)q].max_slabs;
+    }
     hl.lap("set_test: task uploads");
-    if (int rc = dev_upload(c, c->psegs, segs)) return rc;
-    if (int rc = dev_reserve(c, c->psweep8, (size_t)c->psweep8_off[(size_t)nsteps])) return rc;
+    if (int rc = stage_upload_list(c, c->psegs, segs)) return rc;
+    if (int rc = dev_reserve(c, c->psweep8, (size_t)c->psweep8_off[(size_t)nv])) return rc;
     if (!segs.empty())
         build_sweep8_kernel<<<(unsigned)((segs.size() + 127) / 128), 128, 0, c->stream>>>(c->psegs.p, (int)segs.size(), c->d_leaves, c->psweep8.p,
                                                                                         c->xcd_order ? 1 : 0);
     HIPCHK(c, hipGetLastError());
-    if (U.max_slabs) {
+    if (slab_tot) {
         if (c->pool_base) {
-            if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
-        } else if (!c->slabP || c->cap_slabP < U.max_slabs * TB * TB) {
+            if (int rc = arena_get(c, c->slabP, slab_tot * TB * TB)) return rc;
+        } else if (!c->slabP || c->cap_slabP < slab_tot * TB * TB) {
             arena_put(c, c->slabP);
-            if (int rc = arena_get(c, c->slabP, U.max_slabs * TB * TB)) return rc;
-            c->cap_slabP = U.max_slabs * TB * TB;
+            if (int rc = arena_get(c, c->slabP, slab_tot * TB * TB)) return rc;
+            c->cap_slabP = slab_tot * TB * TB;
         }
     }
-    U.bind(c->slabP);
-    if (int rc = dev_upload(c, c->pupd, U.upd)) return rc;
-    if (int rc = dev_upload(c, c->pred, U.red)) return rc;
-    if (int rc = dev_upload(c, c->ptrsm, trsm)) return rc;
-    if (int rc = dev_upload(c, c->pgram, pg)) return rc;
-    if (int rc = dev_upload(c, c->pgram0, pg0)) return rc;
-    if (int rc = dev_upload(c, c->ptasks, ptk)) return rc;
-    if (int rc = dev_upload(c, c->ptasks_slow, ptk_slow)) return rc;
+    {   // the lanes' lists one behind the other in one device list of each kind, uploaded lane by lane
+        size_t nu = 0, nr = 0, nt_ = 0;
+        for (int q = 0; q < nl; ++q) {
+            nu += U[(size_t)q].upd.size();
+            nr += U[(size_t)q].red.size();
+            nt_ += trsm_l[(size_t)q].size();
+        }
+        if (int rc = dev_reserve(c, c->pupd, nu)) return rc;
+        if (int rc = dev_reserve(c, c->pred, nr)) return rc;
+        if (int rc = dev_reserve(c, c->ptrsm, nt_)) return rc;
+        int bu = 0, br = 0, bt = 0;
+        for (int q = 0; q < nl; ++q) {
+            UpdateSplitter& Uq = U[(size_t)q];
+            Uq.bind(c->slabP + slab_base[(size_t)q] * TB * TB);
+            for (int k = 0; k < nsteps; ++k) {
+                const size_t v = (size_t)q * (size_t)nsteps + (size_t)k;
+                c->pupd_off[v] = bu + upd_loc[v];
+                c->pred_off[v] = br + red_loc[v];
+                c->ptrsm_off[v] = bt + trsm_loc[v];
+            }
+            if (int rc = stage_upload(c, c->pupd.p + bu, Uq.upd.data(), Uq.upd.size() * sizeof(TileTask))) return rc;
+            if (int rc = stage_upload(c, c->pred.p + br, Uq.red.data(), Uq.red.size() * sizeof(ReduceTask))) return rc;
+            if (int rc = stage_upload(c, c->ptrsm.p + bt, trsm_l[(size_t)q].data(), trsm_l[(size_t)q].size() * sizeof(TileTask))) return rc;
+            bu += (int)Uq.upd.size();
+            br += (int)Uq.red.size();
+            bt += (int)trsm_l[(size_t)q].size();
+        }
+        c->pupd_off[(size_t)nv] = bu;
+        c->pred_off[(size_t)nv] = br;
+        c->ptrsm_off[(size_t)nv] = bt;
+    }
+    if (int rc = stage_upload_list(c, c->pgram, pg)) return rc;
+    if (int rc = stage_upload_list(c, c->pgram0, pg0)) return rc;
+    if (int rc = stage_upload_list(c, c->ptasks, ptk)) return rc;
+    if (int rc = stage_upload_list(c, c->ptasks_slow, ptk_slow)) return rc;
     // The same test rows as riders of the factorisation launches (used by fit while this test set is resident).  With a device
     // pool (the streaming context: the pool is a stack, plan < test < gradients, and a fit follows at once) the lists are built
     // here; otherwise by the first fit that wants them (ensure_joint) -- predict(model, x) on rows the model has not seen
@@ -2567,7 +2663,7 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
     if (c->pool_base)
         if (int rc = ensure_joint(c)) return rc;
     hl.lap("set_test: final sync");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = stage_done(c)) return rc;
     c->test_ready = true;
     c->vt_valid = false;
     return 0;
@@ -2585,7 +2681,8 @@ int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* r
     if (!c->plan_ready)
         if (int rc = build_plan(c)) return rc;
     HostLog hl("set_test: free old");
-    free_test(c, true);     // the K_tn arena of the set this one replaces is kept for it (spareVt)
+    free_test(c, true);     // every buffer of the set this one replaces is kept for it
+    c->stage_top = 0;       // (the stream is idle: every entry point synchronises before it returns)
     hl.lap("set_test: validate");
     const int L = c->L;
     if (route_ptr[0] != 0) return fail(c, DSMGP_E_ARG, "route_ptr[0] must be 0");
@@ -2693,6 +2790,7 @@ int dsmgp_set_test_routed(dsmgp_ctx* c, const double* Xt, int64_t n_t) {
         if (int rc = build_plan(c)) return rc;
     HostLog hl("set_test: free old");
     free_test(c, true);
+    c->stage_top = 0;
     hl.lap("set_test: route on the device");
     const int L = c->L;
     const int64_t wpl = (n_t + 31) / 32;
@@ -2715,7 +2813,7 @@ int dsmgp_set_test_routed(dsmgp_ctx* c, const double* Xt, int64_t n_t) {
     uint32_t* bitmap = c->rws_bits;
     uint32_t* wprefix = bitmap + nbits;
     if (int rc = dev_grow(c, c->dXt, c->cap_dXt, (size_t)n_t * c->D)) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->dXt, Xt, (size_t)n_t * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (int rc = stage_upload(c, c->dXt, Xt, (size_t)n_t * c->D * sizeof(double))) return rc;
     if (int rc = dev_grow(c, c->d_route_ptr, c->cap_route_ptr, (size_t)L + 1)) return rc;
     if (int rc = dev_grow(c, c->d_row_ptr, c->cap_row_ptr, (size_t)n_t + 1)) return rc;
     HIPCHK(c, hipMemsetAsync(bitmap, 0, nbits * sizeof(uint32_t), c->stream));
@@ -2787,28 +2885,40 @@ int dsmgp_predict_run(dsmgp_ctx* c, double* seconds) {
                 gram_tile_kernel<<<2 * (int)c->pgram.count, 256, 0, c->stream>>>(c->pgram.p, c->d_kp, c->D);
                 pt.end();
             }
-            // V^T = K_tn L^-T, block column by block column (src/gaussianprocess.jl:120)
-            for (int k = 0; k < c->psteps; ++k) {
-                const int n8 = c->psweep8_off[k + 1] - c->psweep8_off[k];
-                if (n8 > 0) {
-                    pt.begin(7);
-                    tile_fused8_kernel<1><<<n8, 512, 0, c->stream>>>(c->psweep8.p + c->psweep8_off[k], c->d_kp, c->D);
-                    pt.end();
+            // V^T = K_tn L^-T, block column by block column (src/gaussianprocess.jl:120), lane by lane on the lanes' streams
+            const int nl = c->plan_lanes_test;
+            if (nl > 1) {
+                HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+                for (int lane = 1; lane < nl; ++lane) HIPCHK(c, hipStreamWaitEvent(c->lane_stream[lane], c->ev_fork, 0));
+            }
+            for (int k = 0; k < c->psteps; ++k)
+                for (int lane = 0; lane < nl; ++lane) {
+                    const int v = lane * c->psteps + k;
+                    hipStream_t st = c->lane_stream[lane];
+                    const int n8 = c->psweep8_off[v + 1] - c->psweep8_off[v];
+                    if (n8 > 0) {
+                        pt.begin(7, st);
+                        tile_fused8_kernel<1><<<n8, 512, 0, st>>>(c->psweep8.p + c->psweep8_off[v], c->d_kp, c->D);
+                        pt.end(st);
+                    }
+                    const int nu = c->pupd_off[v + 1] - c->pupd_off[v];
+                    if (nu > 0) {
+                        pt.begin(7, st);
+                        launch_tiles(c, c->pupd.p + c->pupd_off[v], nu, 0, false, 0, nullptr, 0, st);
+                        const int nr = c->pred_off[v + 1] - c->pred_off[v];
+                        if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, st>>>(c->pred.p + c->pred_off[v]);
+                        pt.end(st);
+                    }
+                    const int ns = c->ptrsm_off[v + 1] - c->ptrsm_off[v];
+                    if (ns > 0) {
+                        pt.begin(8, st);
+                        launch_tiles(c, c->ptrsm.p + c->ptrsm_off[v], ns, 1, false, 0, nullptr, 0, st);
+                        pt.end(st);
+                    }
                 }
-                const int nu = c->pupd_off[k + 1] - c->pupd_off[k];
-                if (nu > 0) {
-                    pt.begin(7);
-                    launch_tiles(c, c->pupd.p + c->pupd_off[k], nu);
-                    const int nr = c->pred_off[k + 1] - c->pred_off[k];
-                    if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(c->pred.p + c->pred_off[k]);
-                    pt.end();
-                }
-                const int ns = c->ptrsm_off[k + 1] - c->ptrsm_off[k];
-                if (ns > 0) {
-                    pt.begin(8);
-                    launch_tiles(c, c->ptrsm.p + c->ptrsm_off[k], ns, 1);
-                    pt.end();
-                }
+            for (int lane = 1; lane < nl; ++lane) {
+                HIPCHK(c, hipEventRecord(c->ev_join[lane], c->lane_stream[lane]));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[lane], 0));
             }
             c->vt_valid = true;
         }
