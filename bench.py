@@ -99,7 +99,7 @@ def default_sub(world):
     and 0.1062 / 0.1072 / 0.1144, 8 ranks 0.0582 / 0.0638 / 0.0646 and 0.0593 / 0.0581 / 0.0635 (round 2 ran 8 ranks with
     3, 4 and 2 ranks with 2 contexts: 0.0651 -> 0.0614 s then) -- and with one context per GPU the exchange of a `nccl` job
     stays on the device (dist.Shard.device_comm).  On a full GPU two contexts measure -1.4 % on the headline step and
-    -2.7 % at depth 4; N = 1 stays at one too: with two contexts' kernels sharing the chip the per-launch
+    -2.7 % at depth 4 (profiles/r04_DESIGN_history.md 8d); N = 1 stays at one too: with two contexts' kernels sharing the chip the per-launch
     duration behind `roofline` is no longer a property of the kernel.  --sub N overrides."""
     return 1
 
@@ -241,7 +241,7 @@ def bench_train(args, model, X, y, rank, world, td, torch):
         td.barrier()
     elapsed = time.perf_counter() - t0
     if td is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
     per = elapsed / args.steps
@@ -308,16 +308,18 @@ def self_launch(args):
 
 
 def init_distributed(rank, world, local_rank, torch):
-    """Process group of an N > 1 run -> (torch.distributed, backend in use, local device index).
+    """Process groups of an N > 1 run -> (torch.distributed, backend of the data path, local device index).
 
     RCCL ("nccl") is what the run is meant to use; whether it comes up is a verdict the ranks must AGREE on before any of them
     depends on it (round-4 advisor: decided per rank inside try/except, a partial failure left some ranks in nccl and the
-    others in gloo until the 300 s timeout).  So: (1) a gloo group first -- it exists on every rank whatever the GPUs do;
-    (2) every rank tries a nccl group beside it and proves it with one all-reduce; (3) the verdicts are MIN- and MAX-reduced
-    over gloo.  All yes: the default group is re-created as nccl.  All no (fewer GPUs than ranks, an IPC or driver problem:
-    the same everywhere): the run completes over gloo and its line says so (exchange_backend).  Mixed: every rank exits 3."""
+    others in gloo until the 300 s timeout).  So: (1) the DEFAULT group is gloo -- it exists on every rank whatever the GPUs
+    do, and carries the barriers, the timing reduction and the per-rank report; (2) every rank opens a nccl group BESIDE it and
+    proves it with one all-reduce; (3) the verdicts are MIN- and MAX-reduced over gloo.  All yes: the exchanges of the path
+    (dist.GROUP) travel over the proven nccl group -- nothing is destroyed or re-initialised.  All no (fewer GPUs than ranks, an IPC
+    or driver problem: the same everywhere): they travel over gloo and the line says so (exchange_backend).  Mixed: exit 3."""
     import datetime
     import torch.distributed as td
+    from deepstructuredmixtures_amd import dist as pdist
     ndev = torch.cuda.device_count()
     want = os.environ.get("DSMGP_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on one GPU
     local_rank = local_rank % max(1, ndev)
@@ -325,12 +327,12 @@ def init_distributed(rank, world, local_rank, torch):
     td.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     if want != "nccl":
         return td, "gloo", local_rank
-    ok, why = 1, ""
+    ok, why, g = 1, "", None
     if ndev < world:                                          # the same on every rank of the node: nobody opens a nccl group
         ok, why = 0, f"{world} ranks need {world} GPUs, {ndev} visible"
     else:
         try:
-            g = td.new_group(backend="nccl", timeout=datetime.timedelta(seconds=90))
+            g = td.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
             probe = torch.ones(1, device="cuda")
             td.all_reduce(probe, group=g)
             torch.cuda.synchronize()
@@ -348,10 +350,7 @@ def init_distributed(rank, world, local_rank, torch):
     if int(lo.item()) == 0:
         print(f"# rank {rank}: RCCL process group not usable ({why}); falling back to gloo for the exchange", file=sys.stderr)
         return td, "gloo", local_rank
-    td.barrier()
-    td.destroy_process_group()
-    td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                          timeout=datetime.timedelta(seconds=300))
+    pdist.GROUP = g
     return td, "nccl", local_rank
 
 
@@ -443,7 +442,7 @@ def main():
     if n_sub > 1:               # fall back to one context per GPU on EVERY rank or on none: creating the single context may
         if td is not None:      # enter a collective (the opt-in device exchange), which one rank alone must not do
             flag = torch.tensor([ctx_ok], dtype=torch.int32,
-                                device="cuda" if td.get_backend() == "nccl" else "cpu")
+                                device="cpu")
             td.all_reduce(flag, op=td.ReduceOp.MIN)
             ctx_ok = int(flag.item())
         if not ctx_ok:
@@ -533,7 +532,7 @@ def main():
             cats[k] = timed.get(k, 0.0)
         ctx.set_profile(1)
     if td is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if td.get_backend() == "nccl" else "cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
     per_step = elapsed / args.steps

@@ -10,12 +10,23 @@ tests) or when that path cannot be set up, through `torch.distributed` from host
 import numpy as np
 
 
+# The process group the exchanges of the path travel over: None = the default group.  A launcher may keep a host-side (gloo)
+# default group for agreement and bookkeeping and hand the data path a second group of its own -- bench.py does: its RCCL group
+# is a subgroup created and PROVEN beside a gloo default group, so that no rank ever depends on a half-built communicator and
+# nothing has to be destroyed and re-initialised.
+GROUP = None
+
+
 def _pg():
     try:
         import torch.distributed as td
     except Exception:
         return None
     return td if td.is_available() and td.is_initialized() else None
+
+
+def _backend(td):
+    return td.get_backend(GROUP) if GROUP is not None else td.get_backend()
 
 
 class Shard:
@@ -44,9 +55,9 @@ class Shard:
         """MIN over ranks of a per-rank verdict, on whatever device the process group moves (gloo: host, nccl: GPU)."""
         import torch
         td = _pg()
-        dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+        dev = torch.device("cuda", torch.cuda.current_device()) if _backend(td) == "nccl" else torch.device("cpu")
         flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
-        td.all_reduce(flag, op=td.ReduceOp.MIN)
+        td.all_reduce(flag, op=td.ReduceOp.MIN, group=GROUP)
         return int(flag.item())
 
     def device_comm(self, ctx, force=False):
@@ -68,7 +79,7 @@ class Shard:
             return self.exchange
         if self.world == 1 or td is None or self.comm_ctx is not None:
             return self.exchange
-        if not force and not (td.get_backend() == "nccl" and self.device_exchange_requested()):
+        if not force and not (_backend(td) == "nccl" and self.device_exchange_requested()):
             return self.exchange
         uid = None
         try:
@@ -78,7 +89,7 @@ class Shard:
         if self._all_min(uid is not None) != 1:
             return self.exchange
         box = [uid if self.rank == 0 else None]
-        td.broadcast_object_list(box, src=0)
+        td.broadcast_object_list(box, src=0)            # (the default group: object collectives are host work)
         ok = 1
         try:
             ctx.comm_init(self.rank, self.world, box[0])
@@ -196,12 +207,12 @@ class Shard:
             self.exchanges += 1
 
     def _all_gather_padded_timed(self, td, torch, local, maxlen):
-        backend = td.get_backend()
+        backend = _backend(td)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         buf = torch.zeros(maxlen, dtype=torch.float64, device=dev)
         buf[: local.size] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64)).to(dev)
         out = [torch.empty_like(buf) for _ in range(self.world)]
-        td.all_gather(out, buf)
+        td.all_gather(out, buf, group=GROUP)
         return [o.cpu().numpy() for o in out]
 
     def allgather_sum(self, local):

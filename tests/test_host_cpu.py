@@ -270,15 +270,21 @@ from oracle_context import OracleContext, OraclePartialContext
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 td.init_process_group("gloo", rank=rank, world_size=world)
 z = np.load(os.path.join({root!r}, "tests", "golden", "tree_small.npz"))
-for make_ctx in (OracleContext, OraclePartialContext):   # all-gather of the moments / of the aggregation's partial sums
-    m = dsm.buildDSMGP(z["X"], z["y"], 2, 4, M=20, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=3,
-                       fit_now=False, ctx=make_ctx(), shard_world=(rank, world))
-    assert 0 < len(m.shard.local) < m.L
-    dsm.fit(m)
-    assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=1e-10, atol=1e-9)
-    dsm.update(m)
-    mu, var = dsm.predict(m, z["Xt"])
-    assert np.allclose(mu, z["mu"], rtol=1e-9, atol=1e-10) and np.allclose(var, z["var"], rtol=1e-8, atol=1e-10)
+from deepstructuredmixtures_amd import dist as pdist
+# over the default group, then over a group of its own handed to the data path (dist.GROUP: what bench.py does with its RCCL group)
+for group in (None, td.new_group(backend="gloo")):
+    pdist.GROUP = group
+    for make_ctx in (OracleContext, OraclePartialContext):   # all-gather of the moments / of the aggregation's partial sums
+        m = dsm.buildDSMGP(z["X"], z["y"], 2, 4, M=20, kernel=dsm.IsoSE(np.log(0.3), 0.0), logNoise=np.log(0.1), seed=3,
+                           fit_now=False, ctx=make_ctx(), shard_world=(rank, world))
+        assert 0 < len(m.shard.local) < m.L
+        dsm.fit(m)
+        assert np.allclose(m.leaf_mll, z["leaf_mll"], rtol=1e-10, atol=1e-9)
+        dsm.update(m)
+        mu, var = dsm.predict(m, z["Xt"])
+        assert np.allclose(mu, z["mu"], rtol=1e-9, atol=1e-10) and np.allclose(var, z["var"], rtol=1e-8, atol=1e-10)
+        assert m.shard.exchanges >= 2
+pdist.GROUP = None
 td.barrier(); td.destroy_process_group()
 print("rank", rank, "ok", len(m.shard.local))
 """
