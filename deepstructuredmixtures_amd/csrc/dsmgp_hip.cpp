@@ -2588,13 +2588,19 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
         Ul.add_step(tiles, k * TB);
       }
     };
-    if (nl > 1) {
+    {
         std::vector<std::thread> th;
-        for (int q = 1; q < nl; ++q) th.emplace_back(build_lane, q);
+        int started = 1;                    // lanes [1, started) have a thread of their own
+        try {
+            for (int q = 1; q < nl; ++q) {
+                th.emplace_back(build_lane, q);
+                started = q + 1;
+            }
+        } catch (...) {                     // no thread to be had: the remaining lanes are built here (nothing may throw across the ABI)
+        }
         build_lane(0);
         for (std::thread& t : th) t.join();
-    } else {
-        build_lane(0);
+        for (int q = started; q < nl; ++q) build_lane(q);
     }
     // one split-K workspace per lane, one list of each kind for all lanes (lane after lane)
     size_t slab_tot = 0;
