@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -205,6 +206,34 @@ struct TreeBuild {
     std::vector<int64_t> thr_ptr, obs_ptr;               // per node (+1)
     std::vector<double> thr, dir_u;
     std::vector<int32_t> obs;                            // N < 2^31 (checked at the entry point)
+    // Work space of build_split, allocated once: the coordinates of a region (vals), their selection inside the bounds
+    // (sel) and the child slot of every row (key) are dead before the recursion goes down, so every call uses the same
+    // N-sized buffers (uninitialised: a std::vector per call zero-fills what the pass then overwrites and, above the
+    // allocator's mmap threshold, faults its pages in again at every node); the children's row lists live across the
+    // recursion and come from a stack of blocks that is popped on the way up.
+    std::unique_ptr<double[]> vals, sel, sel2;
+    std::unique_ptr<int32_t[]> key;
+    std::unique_ptr<uint16_t[]> bucket;                  // median_of: bucket of every value (HIST_B <= 65536)
+    struct RowStack {
+        std::vector<std::unique_ptr<int32_t[]>> block;
+        std::vector<size_t> cap;
+        size_t cur = 0, top = 0;                         // block in use, entries used in it
+        int32_t* push(size_t n) {
+            while (cur < block.size() && top + n > cap[cur]) {
+                ++cur;
+                top = 0;
+            }
+            if (cur == block.size()) {
+                const size_t c = std::max<size_t>(n, (size_t)1 << 20);
+                block.emplace_back(new int32_t[c]);
+                cap.push_back(c);
+                top = 0;
+            }
+            int32_t* p = block[cur].get() + top;
+            top += n;
+            return p;
+        }
+    } rows;
 
     double rand() {
         uint64_t z = seed + (pos + 1) * 0x9E3779B97F4A7C15ull;
@@ -231,52 +260,112 @@ struct TreeBuild {
         obs_ptr.push_back((int64_t)obs.size());
         return (int)kind.size() - 1;
     }
-    // getSplits (src/treeStructure.jl:23-129) on [b, e): the coordinates of the region inside the caller's (l, u].  The
+    // Median of the n > 0 values a[0..n) (all inside (l, u]) as NumPy's median returns it: the middle element, or the mean
+    // of the two middle ones.  Only the SET matters, so the selection is free to be any exact one: a histogram over
+    // (l, u] finds the bucket that holds the middle rank (x -> (x - l) * scale is monotone in floating point: a smaller
+    // bucket never holds a larger value), its members are collected into w and the rank is selected among them; the
+    // largest value of the buckets below serves the lower middle of an even count when the bucket starts at the rank.
+    // Two sequential passes with no data-dependent branch (the bucket of every value is kept from the first for the
+    // second) instead of a quickselect's mispredicted ones, which were half of the builder's time at depth 4.  Small or
+    // degenerate inputs go to std::nth_element on a copy.
+    static constexpr int HIST_B = 1024;
+    int32_t hist[HIST_B];
+    double median_of(const double* a, int64_t n, double l, double u, double* w) {
+        const int64_t h = n / 2;
+        int B = 32;                                       // about 8 values per bucket: clearing and scanning the
+        while (B < HIST_B && (int64_t)B * 8 < n) B *= 2;  // counters must stay small beside the two passes
+        const double scale = (double)B / (u - l);
+        double hi, lomax;
+        if (n < 192 || !(scale > 0.0) || !std::isfinite(scale)) {
+            std::copy(a, a + n, w);
+            std::nth_element(w, w + h, w + n);
+            hi = w[h];
+            lomax = (n % 2) ? hi : *std::max_element(w, w + h);
+        } else {
+            std::memset(hist, 0, (size_t)B * sizeof(hist[0]));
+            uint16_t* const bk = bucket.get();
+            for (int64_t i = 0; i < n; ++i) {
+                const int k = std::min(B - 1, (int)((a[i] - l) * scale));
+                bk[i] = (uint16_t)k;
+                hist[k]++;
+            }
+            int64_t below = 0;
+            int kb = 0;
+            while (below + hist[kb] <= h) below += hist[kb++];
+            int64_t c = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                w[c] = a[i];
+                c += (bk[i] == (uint16_t)kb) ? 1 : 0;
+            }
+            const int64_t r = h - below;                  // rank inside the bucket
+            std::nth_element(w, w + r, w + c);
+            hi = w[r];
+            lomax = hi;
+            if (n % 2 == 0) {
+                if (r > 0) {
+                    lomax = *std::max_element(w, w + r);
+                } else {                                  // the bucket starts at the rank: the largest value below it
+                    lomax = -std::numeric_limits<double>::infinity();
+                    for (int64_t i = 0; i < n; ++i) lomax = (bk[i] < (uint16_t)kb && a[i] > lomax) ? a[i] : lomax;
+                }
+            }
+        }
+        // + 0.0 turns -0.0 into +0.0: which of two signed zeros a selection returns is not defined (NumPy's median and
+        // a selection differ), and the sign would reach the stored thresholds through 0 * a + m
+        return ((n % 2) ? hi : (lomax + hi) / 2.0) + 0.0;
+    }
+    // getSplits (src/treeStructure.jl:23-129) on a[0..n): the coordinates of the region inside the caller's (l, u].  The
     // reference filters the whole region again at every recursion level, with l = max(lower, region min) and
     // u = min(upper, region max); the bounds only shrink on the way down and a child's bound is the cut s_new itself, so
-    // the two children's selections are exactly the two sides of the parent's selection around s_new: the range is
-    // reordered in place (selection for the median, then a partition around the cut) and each child works on its side.
-    // Only the SET matters to every quantity computed here (median, counts).  rmin / rmax: extrema of the WHOLE region on
-    // this dimension, as the reference uses them.
-    void get_splits(double* b, double* e, double rmin, double rmax, double lower, double upper, int depth,
+    // the two children's selections are exactly the two sides of the parent's selection around s_new: the values are
+    // dealt to the two ends of the second buffer w (same length) and each child works on its side, with the roles of
+    // the two buffers exchanged -- only when a child is large enough to cut again.  Only the SET matters to every
+    // quantity computed here (median, counts).  rmin / rmax: extrema of the WHOLE region on this dimension, as the
+    // reference uses them.
+    void get_splits(double* a, int64_t n, double* w, double rmin, double rmax, double lower, double upper, int depth,
                     std::vector<double>& s) {
         int K_ = depth * depth;
         const double l = std::max(lower, rmin), u = std::min(upper, rmax);
         const double v = u - l;
-        const int64_t n = e - b;
         if (n <= 2 * (int64_t)minData) return;
-        const int64_t h = n / 2;
-        std::nth_element(b, b + h, e);
-        const double hi = b[h];
-        // + 0.0 turns -0.0 into +0.0: which of two signed zeros a selection returns is not defined (NumPy's median and
-        // nth_element differ), and the sign would reach the stored thresholds through 0 * a + m
-        const double m = ((n % 2) ? hi : (*std::max_element(b, b + h) + hi) / 2.0) + 0.0;
+        const double m = median_of(a, n, l, u, w);
         int64_t z1 = 0, z2 = 0;
         int cnt = 0;
         double s_new = m;
-        bool selected = true;                      // [b, b+h) <= hi <= (b+h, e) still holds
         while (z1 == 0 || z2 == 0) {
-            const double a = beta22() * v + l;
-            const double t1 = bnoise * a, t2 = (1.0 - bnoise) * m;
+            const double x = beta22() * v + l;
+            const double t1 = bnoise * x, t2 = (1.0 - bnoise) * m;
             s_new = t1 + t2;
             const double cut = s_new;
-            auto below = [cut](double x) { return x <= cut; };
-            double* mid;
-            if (!selected) mid = std::partition(b, e, below);
-            else if (cut >= hi) mid = std::partition(b + h + 1, e, below);     // everything up to b+h is <= hi <= cut
-            else mid = std::partition(b, b + h, below);                        // everything from b+h on is >= hi > cut
-            selected = false;
-            z1 = mid - b;
+            int64_t le = 0;
+            for (int64_t i = 0; i < n; ++i) le += (a[i] <= cut) ? 1 : 0;
+            z1 = le;
             z2 = n - z1;
             if (++cnt > 100) return;
         }
         const bool first_low = (1 + (int)(rand() * 2.0)) == 1;
+        bool dealt = false;
         for (int posn = 0; posn < 2; ++posn) {
             const bool low = (posn == 0) == first_low;
             const int64_t z = low ? z1 : z2;
             if (z > minData && K_ < K) {
-                if (low) get_splits(b, b + z1, rmin, rmax, lower, s_new, depth + 1, s);
-                else get_splits(b + z1, e, rmin, rmax, s_new, upper, depth + 1, s);
+                if (z > 2 * (int64_t)minData) {           // (a smaller side returns at once and draws nothing)
+                    if (!dealt) {
+                        const double cut = s_new;
+                        int64_t lo = 0, hi = 0;
+                        for (int64_t i = 0; i < n; ++i) {
+                            const double x = a[i];
+                            const bool le = x <= cut;
+                            w[lo] = x;
+                            w[n - 1 - hi] = x;            // one of the two stays: lo + hi <= i, the cursors never cross
+                            lo += le ? 1 : 0;
+                            hi += le ? 0 : 1;
+                        }
+                        dealt = true;
+                    }
+                    if (low) get_splits(w, z1, a, rmin, rmax, lower, s_new, depth + 1, s);
+                    else get_splits(w + z1, z2, a + z1, rmin, rmax, s_new, upper, depth + 1, s);
+                }
                 if (posn == 0) K_ += 1;
             }
         }
@@ -290,9 +379,10 @@ struct TreeBuild {
     void build_split(int par, const int32_t* idx, int64_t n, const std::vector<double>& lowerBound,
                      const std::vector<double>& upperBound, int depth, int d) {
         const double* xd = X + (size_t)d * N;
-        std::vector<double> vals((size_t)n);
+        double* const vals = this->vals.get();
         double rmin = xd[idx[0]], rmax = rmin;
         for (int64_t q = 0; q < n; ++q) {
+            if (q + 24 < n) __builtin_prefetch(xd + idx[q + 24]);      // rows of a deep region lie a page apart
             const double x = xd[idx[q]];
             vals[q] = x;
             rmin = std::min(rmin, x);
@@ -301,23 +391,23 @@ struct TreeBuild {
         std::vector<double> s;
         {
             const double l = std::max(lowerBound[d], rmin), u = std::min(upperBound[d], rmax);
-            std::vector<double> sel((size_t)n);
+            double* const sel = this->sel.get();
             int64_t ns = 0;
             for (int64_t q = 0; q < n; ++q) {
                 const double x = vals[q];
                 sel[ns] = x;
                 ns += (x > l && x <= u) ? 1 : 0;
             }
-            get_splits(sel.data(), sel.data() + ns, rmin, rmax, lowerBound[d], upperBound[d], 1, s);
+            get_splits(sel, ns, sel2.get(), rmin, rmax, lowerBound[d], upperBound[d], 1, s);
         }
         std::sort(s.begin(), s.end());
         const double lo = lowerBound[d], up = upperBound[d];
         if (s.empty()) {
-            std::vector<int32_t> sub;
-            sub.reserve((size_t)n);
+            int32_t* const sub = key.get();
+            int64_t m = 0;
             for (int64_t q = 0; q < n; ++q)
-                if (vals[q] > lo && vals[q] <= up) sub.push_back(idx[q]);
-            build_gp(par, sub.data(), (int64_t)sub.size(), lowerBound, upperBound);
+                if (vals[q] > lo && vals[q] <= up) sub[m++] = idx[q];
+            build_gp(par, sub, m, lowerBound, upperBound);
             return;
         }
         const int id = new_node(1, par, lowerBound, upperBound);
@@ -327,7 +417,7 @@ struct TreeBuild {
         // child k holds the points with s[k-1] < x <= s[k] (s[-1] = lowerBound[d]): k = number of cuts below x; a
         // counting pass and a scatter into one buffer, the children are spans of it
         const size_t nc = s.size();
-        std::vector<int32_t> key((size_t)n);
+        int32_t* const key = this->key.get();
         std::vector<int64_t> off(nc + 2, 0);
         for (int64_t q = 0; q < n; ++q) {
             const double x = vals[q];
@@ -340,20 +430,23 @@ struct TreeBuild {
             key[q] = (int32_t)k;
             off[k + 1]++;
         }
-        std::vector<double>().swap(vals);
         for (size_t k = 0; k <= nc; ++k) off[k + 1] += off[k];
-        std::vector<int32_t> buf((size_t)off[nc]);
+        const size_t mark_cur = rows.cur, mark_top = rows.top;
+        int32_t* const buf = rows.push((size_t)off[nc] + 1);
         {
-            std::vector<int64_t> fill(off.begin(), off.begin() + nc);
-            for (int64_t q = 0; q < n; ++q)
-                if ((size_t)key[q] < nc) buf[fill[key[q]]++] = idx[q];
+            std::vector<int64_t> fill(off.begin(), off.begin() + nc + 1);
+            fill[nc] = off[nc];                          // rows outside the bounds land in one spare entry
+            for (int64_t q = 0; q < n; ++q) {
+                const size_t k = (size_t)key[q];
+                buf[fill[k]] = idx[q];
+                fill[k] += k < nc ? 1 : 0;
+            }
         }
-        std::vector<int32_t>().swap(key);
         std::vector<double> lb_(lowerBound), ub_(upperBound);
         for (size_t k = 0; k < nc; ++k) {
             const double si = s[k];
             ub_[d] = si;
-            const int32_t* sub = buf.data() + off[k];
+            const int32_t* sub = buf + off[k];
             const int64_t m = off[k + 1] - off[k];
             if (depth < maxDepth && m > (int64_t)minData) {
                 if (sumRoot) build_sum(id, sub, m, lb_, ub_, depth);
@@ -363,12 +456,15 @@ struct TreeBuild {
             }
             lb_[d] = si;
         }
+        rows.cur = mark_cur;
+        rows.top = mark_top;
     }
     void build_sum(int par, const int32_t* idx, int64_t n, const std::vector<double>& lowerBound,
                    const std::vector<double>& upperBound, int depth) {
         const int id = new_node(2, par, lowerBound, upperBound);
         std::vector<double> mn(Xr.begin() + (size_t)idx[0] * D, Xr.begin() + (size_t)(idx[0] + 1) * D), mx(mn), phi(D);
         for (int64_t q = 0; q < n; ++q) {
+            if (q + 16 < n) __builtin_prefetch(Xr.data() + (size_t)idx[q + 16] * D);
             const double* row = Xr.data() + (size_t)idx[q] * D;
             for (int d = 0; d < D; ++d) {
                 mn[d] = std::min(mn[d], row[d]);
@@ -433,6 +529,11 @@ int dsmgp_tree_build(const double* X, int64_t N, int32_t D, int32_t min_data, in
         for (int l = 0; l < depth && rows < 1e9; ++l) rows *= (double)n_sum_children;
         if (rows < 1e9) b.obs.reserve((size_t)rows);
     }
+    b.vals.reset(new double[(size_t)N]);
+    b.sel.reset(new double[(size_t)N]);
+    b.sel2.reset(new double[(size_t)N]);
+    b.key.reset(new int32_t[(size_t)N]);
+    b.bucket.reset(new uint16_t[(size_t)N]);
     std::vector<int32_t> all((size_t)N);
     for (int64_t i = 0; i < N; ++i) all[i] = (int32_t)i;
     const double inf = std::numeric_limits<double>::infinity();
@@ -443,6 +544,12 @@ int dsmgp_tree_build(const double* X, int64_t N, int32_t D, int32_t min_data, in
     b.obs_ptr.push_back((int64_t)b.obs.size());
     b.X = nullptr;
     std::vector<double>().swap(b.Xr);
+    b.vals.reset();
+    b.sel.reset();
+    b.sel2.reset();
+    b.key.reset();
+    b.bucket.reset();
+    b.rows = TreeBuild::RowStack();
     *out = t;
     return 0;
 }

@@ -7,8 +7,14 @@ what crosses the C ABI.  Behaviour follows the reference's builder
 (`src/fit.jl:71-122,208-292`) and routing (`src/common.jl:101-122`); indices are 0-based here.
 Random draws come from `datagen.Stream` (Julia's RNG stream cannot be reproduced).
 """
+import gc
 import itertools
 import numpy as np
+
+try:                                   # at import, not inside the first buildDSMGP (0.15 s of its first call otherwise)
+    import scipy.sparse as sp
+except ImportError:                    # pragma: no cover
+    sp = None
 
 from .datagen import Stream
 from .kernels import ConstMean, KernelFunction
@@ -95,6 +101,9 @@ class DSMGPConfig:
 
 
 def get_leaves(node):
+    known = node.__dict__.get("_leaves") if node.kind != "gp" else None
+    if known is not None:              # the root of a tree from the native builder: its regions in creation order
+        return list(known)
     """Leaves in depth-first child order (`src/fit.jl:9-10`)."""
     if node.kind == "gp":
         return [node]
@@ -226,14 +235,40 @@ def _build_tree_native(X, y, config, seed):
     nk = len(config.kernels) if kvec else 0
     tab = hipabi.tree_build(X, config.minData, config.K, config.V, config.depth, config.bnoise, config.sumRoot, nk, seed,
                             y=y if config.meanFun is None else None)
+    kind = tab["kind"].tolist()
+    n = len(kind)
+    nodes = [None] * n
+    leaves = []
+    sum_lw = np.full(config.V, -np.log(config.V))        # what V calls of GPSumNode.add(child, -log V) build up
+    # tens of thousands of new containers and none to free: the cyclic collector would walk the growing tree again and
+    # again (a third of this loop at depth 4), so it rests until the loop is through
+    collect = gc.isenabled()
+    gc.disable()
+    try:
+        _nodes_from_table(config, tab, nodes, leaves, kvec, nk)
+    finally:
+        if collect:
+            gc.enable()
+    for i in range(n):
+        if kind[i] == 2:                                  # every split call under a sum node returns exactly one child
+            assert len(nodes[i].children) == config.V
+            nodes[i].logweights = sum_lw.copy()
+    root = nodes[0]
+    if root.kind != "gp":
+        root._leaves = leaves        # creation order of the regions = get_leaves order (children are appended in creation order)
+    return root
+
+
+def _nodes_from_table(config, tab, nodes, leaves, kvec, nk):
+    """Node objects of the native builder's table, in creation (pre-)order: parents come first."""
     kind, parent, sdim = tab["kind"].tolist(), tab["parent"].tolist(), tab["split_dim"].tolist()
     tptr, optr = tab["thr_ptr"].tolist(), tab["obs_ptr"].tolist()
     lbs, ubs, thr, obs_all = tab["lb"], tab["ub"], tab["thr"].tolist(), tab["obs"]
-    n = len(kind)
-    nodes = [None] * n
+    means = tab["mean"].tolist() if config.meanFun is None else None
+    noise = float(config.observationNoise)
+    new, gp_cls, mean_cls = object.__new__, GPNode, ConstMean
     region = 0
-    sum_lw = np.full(config.V, -np.log(config.V))        # what V calls of GPSumNode.add(child, -log V) build up
-    for i in range(n):                                    # creation (pre-)order: parents come first
+    for i in range(len(kind)):
         k = kind[i]
         if k == 1:
             d = sdim[i]
@@ -241,11 +276,13 @@ def _build_tree_native(X, y, config, seed):
         elif k == 2:
             node = GPSumNode()
         else:
-            obs = obs_all[optr[i]:optr[i + 1]]            # views of the builder's tables: one allocation for all regions
-            if config.meanFun is None:
-                mfun = ConstMean(float(tab["mean"][region]) if obs.size else 0.0)
-            else:
+            o0, o1 = optr[i], optr[i + 1]
+            obs = obs_all[o0:o1]                          # views of the builder's tables: one allocation for all regions
+            if means is None:
                 mfun = config.meanFun
+            else:
+                mfun = new(mean_cls)
+                mfun.m = means[region] if o1 > o0 else 0.0
             if kvec:
                 u = tab["dir_u"][region * nk:(region + 1) * nk]
                 e = -np.log(1.0 - u)                     # Stream.dirichlet1 on the uniforms the builder drew
@@ -253,21 +290,21 @@ def _build_tree_native(X, y, config, seed):
                 node = GPSumNode(of_gps=True)
                 for v, kern in enumerate(config.kernels):
                     node.add(GPNode(obs, lbs[i], ubs[i], kern.copy(), v, mfun, config.observationNoise), np.log(w[v]))
+                for ch in node.children:
+                    ch.leaf = len(leaves)
+                    leaves.append(ch)
             else:
-                node = GPNode(obs, lbs[i], ubs[i], config.kernels.copy(), 0, mfun, config.observationNoise)
+                # GPNode(obs, lb, ub, kernel.copy(), 0, mean, noise) without the conversions of its constructor: 18k
+                # regions at depth 4, and the table already holds int64 rows and Python floats
+                node = new(gp_cls)
+                node.__dict__.update(id=_gensym("GP"), obs=obs, nobs=o1 - o0, lb=lbs[i], ub=ubs[i], kernel=config.kernels.copy(),
+                                     kernelid=0, mean=mfun, logNoise=noise, dnoise=0.0, leaf=len(leaves), children=[])
+                leaves.append(node)
             region += 1
         nodes[i] = node
         par = parent[i]
         if par >= 0:
             nodes[par].children.append(node)
-    for i in range(n):
-        if kind[i] == 2:                                  # every split call under a sum node returns exactly one child
-            assert len(nodes[i].children) == config.V
-            nodes[i].logweights = sum_lw.copy()
-    root = nodes[0]
-    for i, leaf in enumerate(get_leaves(root)):
-        leaf.leaf = i
-    return root
 
 
 def build_tree_python(X, y, config, seed=7):
@@ -312,7 +349,8 @@ def obs_table(leaves):
 
 def _membership(leaves):
     """Sparse leaf-membership matrix M (L x N, int32 ones) and the leaf sizes."""
-    import scipy.sparse as sp
+    if sp is None:
+        raise ImportError("the leaf-overlap matrix needs scipy.sparse")
     L = len(leaves)
     nobs = np.array([lf.nobs for lf in leaves], dtype=np.int64)
     rows = np.repeat(np.arange(L), nobs)

@@ -790,6 +790,19 @@ def test_native_tree_builder_equals_the_interpreted_builder_bit_for_bit():
         y = normal(400 + seed, 0, 1200)
         cfg = lambda: ptree.DSMGPConfig(None, dsm.IsoSE(0, 0), 1.0, 25, 4, 1, 2, 0.0, False)  # noqa: E731
         assert _same_tree(ptree.build_tree(X, y, cfg(), seed=seed, native=True), ptree.build_tree(X, y, cfg(), seed=seed, native=False))
+    # columns that defeat the histogram of the native median (dsmgp_tree_build: median_of): nine values in ten inside one
+    # bucket (the selection runs over nearly all of them), and a column of seven distinct values (buckets full of ties)
+    for seed in range(4):
+        X = uniform(700 + seed, 0, 2400 * 3).reshape((2400, 3), order="F")
+        dense = uniform(710 + seed, 0, 2400) < 0.9
+        X[dense, 0] = 0.5 + 1e-5 * X[dense, 0]
+        X[:, 2] = np.floor(X[:, 2] * 7.0) / 7.0
+        y = normal(800 + seed, 0, 2400)
+        cfg = lambda: ptree.DSMGPConfig(None, dsm.IsoSE(0, 0), 1.0, 30, 4, 3, 3, 0.1, True)  # noqa: E731
+        a, b = ptree.build_tree(X, y, cfg(), seed=seed, native=True), ptree.build_tree(X, y, cfg(), seed=seed, native=False)
+        assert len(ptree.get_leaves(a)) > 8 and _same_tree(a, b), seed
+        dims = {n.split[0][0] for n in ptree.ordered_nodes(a) if n.kind == "split"}
+        assert dims == {0, 1, 2}, (seed, dims)
     # the committed leaf table of config 1 pins both builders
     z = np.load(os.path.join(ROOT, "tests", "golden", "config1.npz"))
     m = dsm.buildDSMGP(z["x"].reshape(-1, 1), z["y"], 3, 4, M=10, kernel=dsm.IsoSE(1.0, 1.0), meanFun=dsm.ConstMean(0.5), seed=11,
