@@ -374,7 +374,7 @@ def main():
     ap.add_argument("--no-diag-ahead", action="store_true",
                     help="diagnostic: DSMGP_OPT_DIAG_IN_UPDATE = 0 (a diagonal-block launch per classic step), for A/B runs")
     ap.add_argument("--lanes", type=int, default=None, choices=[0, 1, 2, 3, 4],
-                    help="leaf lanes inside the context (DSMGP_OPT_LANES): default 0 = automatic (two from 64 sharing groups on)")
+                    help="leaf lanes inside the context (DSMGP_OPT_LANES): default 0 = automatic (two from 8 independent sharing groups on; one in streaming mode)")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
