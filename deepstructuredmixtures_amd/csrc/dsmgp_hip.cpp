@@ -3772,7 +3772,11 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
         std::fprintf(stderr, "  splitter: %zu tiles -> %zu tasks, %zu reduces\n", (size_t)ntiles, tasks.size(), U.red.size());
     } else {
         std::vector<int> dummy(tasks.size());
-        xcd_permute(tasks, dummy, 0, tasks.size(), c->xcd_order && mode == 0);
+        xcd_permute(tasks, dummy, 0, tasks.size(), c->xcd_order && (mode == 0 || mode == 6));
+        // mode 6: mode 0 with the first workgroup of every CU at half depth -- the two workgroups of a CU then run half a task
+        // apart for the rest of the launch instead of reaching their epilogues (and the next tasks' first loads) together
+        if (mode == 6)
+            for (int i = 0; i < std::min(ntiles, c->ncu); ++i) tasks[i].k1 = K / 2 / KC * KC;
     }
     DevBuf<TileTask> dt;
     DevBuf<ReduceTask> dr;
@@ -3833,6 +3837,103 @@ int dsmgp_bench_tile(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t mode, int3
     dev_free(A);
     dev_free(B);
     dev_free(C);
+    return 0;
+}
+// Diagnostic: the eight-wave fused tile task (tile_fused8_kernel) on a uniform batch of `ntasks` tasks of depth K -- eight full
+// 16-row blocks each with their own A rows, groups of `group` tasks sharing a B panel, the access pattern of bench_tile's mode 0.
+// A task of depth K is its kernel function, K / 128 block columns of product, one substitution and a store: the SLOPE of the
+// launch time over K is the steady-state rate of the eight-wave product loop (four waves per SIMD), to set against
+// tile_gemm_kernel_v2's (two waves per SIMD) on the same shape.
+int dsmgp_bench_fused8(dsmgp_ctx* c, int32_t ntasks, int32_t K, int32_t group, int32_t reps, double* seconds_per_launch) {
+    if (!c || ntasks <= 0 || K < 0 || K % TB || !seconds_per_launch || group <= 0 || reps <= 0) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int D = 8;
+    const size_t apanel = (size_t)TB * K, bpanel = (size_t)TB * (K + TB);
+    const int nB = (ntasks + group - 1) / group;
+    double *A = nullptr, *B = nullptr, *Cc = nullptr, *Dv = nullptr, *gx = nullptr, *l2 = nullptr;
+    KParam* kp = nullptr;
+    HIPCHK(c, hipMalloc(&A, std::max<size_t>(1, (size_t)ntasks * apanel) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&B, (size_t)nB * bpanel * sizeof(double)));
+    HIPCHK(c, hipMalloc(&Cc, (size_t)ntasks * TB * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&Dv, (size_t)TB * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&gx, (size_t)TB * D * sizeof(double)));
+    HIPCHK(c, hipMalloc(&l2, 2 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&kp, sizeof(KParam)));
+    {
+        std::vector<double> hv(std::max(apanel, bpanel));
+        for (size_t i = 0; i < hv.size(); ++i) hv[i] = 1e-3 * (double)((i * 2654435761u) % 2001) - 1.0;
+        for (int i = 0; i < ntasks && apanel; ++i) HIPCHK(c, hipMemcpy(A + i * apanel, hv.data(), apanel * sizeof(double), hipMemcpyHostToDevice));
+        for (int i = 0; i < nB; ++i) HIPCHK(c, hipMemcpy(B + i * bpanel, hv.data(), bpanel * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> id((size_t)TB * TB, 0.0), xs((size_t)TB * D);
+        for (int i = 0; i < TB; ++i) id[i + (size_t)i * TB] = 1.0;
+        for (size_t i = 0; i < xs.size(); ++i) xs[i] = 1e-3 * (double)((i * 40503u) % 1000);
+        HIPCHK(c, hipMemcpy(Dv, id.data(), id.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(gx, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+        const double hl2[2] = {1.0, -0.5};
+        HIPCHK(c, hipMemcpy(l2, hl2, sizeof(hl2), hipMemcpyHostToDevice));
+        KParam h{};
+        h.kind = 0;
+        h.nl = 1;
+        h.sigma2 = h.sigma = 1.0;
+        h.noise = 0.01;
+        h.l2 = l2;
+        h.nh = l2 + 1;
+        h.nh0 = -0.5;
+        h.il2 = 1.0;
+        HIPCHK(c, hipMemcpy(kp, &h, sizeof(h), hipMemcpyHostToDevice));
+    }
+    std::vector<FusedTask8> tasks(ntasks);
+    for (int i = 0; i < ntasks; ++i) {
+        FusedTask8 t{};
+        t.B = B + (size_t)(i / group) * bpanel;
+        t.Dinv = Dv;
+        t.zk = nullptr;
+        t.gxb = gx;
+        t.ldb = TB;
+        t.gldb = TB;
+        t.gnb = TB;
+        t.k1 = K;
+        t.kid = 0;
+        t.nblk = 8;
+        for (int w = 0; w < 8; ++w) {
+            RowBlock& r = t.rb[w];
+            r.A = (K ? A + (size_t)i * apanel : B) + 16 * w;
+            r.C = Cc + (size_t)i * TB * TB + 16 * w;
+            r.gx = gx + 16 * w;
+            r.wi = nullptr;
+            r.sq = nullptr;
+            r.lda = TB;
+            r.ldc = TB;
+            r.glda = TB;
+            r.nvalid = 16;
+        }
+        tasks[i] = t;
+    }
+    {
+        std::vector<int> dummy(tasks.size());
+        xcd_permute(tasks, dummy, 0, tasks.size(), c->xcd_order);
+    }
+    DevBuf<FusedTask8> dt;
+    if (int rc = dev_upload(c, dt, tasks)) return rc;
+    auto run = [&]() { tile_fused8_kernel<2><<<ntasks, 512, 0, c->stream>>>(dt.p, kp, D); };
+    EventPair ev;
+    HIPCHK(c, ev.init());
+    run();
+    HIPCHK(c, hipEventRecord(ev.a, c->stream));
+    for (int r = 0; r < reps; ++r) run();
+    HIPCHK(c, hipEventRecord(ev.b, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+    *seconds_per_launch = ms * 1e-3 / reps;
+    dev_free(dt);
+    dev_free(A);
+    dev_free(B);
+    dev_free(Cc);
+    dev_free(Dv);
+    dev_free(gx);
+    dev_free(l2);
+    dev_free(kp);
     return 0;
 }
 // Diagnostic: the diagonal-block kernel alone on `ntiles` well-conditioned blocks (microseconds per launch over `reps`

@@ -98,6 +98,7 @@ DIAG_SIGNATURES = {
     "dsmgp_probe_coissue": (C.c_int, [_ctx, _dp]),
     "dsmgp_bench_tile": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "dsmgp_probe_diag": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
+    "dsmgp_bench_fused8": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
 }
 DIAG_LIB_PATH = os.path.join(_HERE, "libdsmgp_hip_diag.so")
 
@@ -501,6 +502,12 @@ class Context:
         s = C.c_double(0.0)
         self._chk(self.lib.dsmgp_bench_tile(self.h, int(ntiles), int(K), int(mode), int(group), int(reps), C.byref(s)))
         return 2.0 * 128 * 128 * K * ntiles / s.value / 1e12
+
+    def bench_fused8(self, ntasks, K, group=16, reps=3):
+        """seconds per launch of the eight-wave fused tile task on a uniform batch (diagnostic)."""
+        s = C.c_double(0.0)
+        self._chk(self.lib.dsmgp_bench_fused8(self.h, int(ntasks), int(K), int(group), int(reps), C.byref(s)))
+        return s.value
 
     def probe_f64_mfma(self):
         t = C.c_double(0.0)

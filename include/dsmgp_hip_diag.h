@@ -19,6 +19,9 @@ int dsmgp_probe_coissue(dsmgp_ctx* ctx, double* out);
  * (mode 0: own A panel per tile, B panel shared by `group` tiles; mode 1: all operands shared, L2-resident) */
 int dsmgp_bench_tile(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t mode, int32_t group, int32_t reps,
                      double* seconds_per_launch);
+/* diagnostic: seconds per launch of the eight-wave fused tile task on ntasks tasks of depth K (eight full 16-row blocks each, own A
+ * rows, B panel shared by `group` tasks): the slope over K is the steady-state rate of its product loop */
+int dsmgp_bench_fused8(dsmgp_ctx* ctx, int32_t ntasks, int32_t K, int32_t group, int32_t reps, double* seconds_per_launch);
 /* diagnostic: the diagonal-block kernel alone on ntiles blocks (us per launch) and the wall-clock phases of one block:
  * phases_us[23] = load, first 16x16 block, (P1, P2) x 8 block steps, write-back, inverse phase, and inside step 3's P2 on
  * wave 0 the trailing product and the potrf + inverse of the next 16x16 diagonal block (us, then shader cycles) */
