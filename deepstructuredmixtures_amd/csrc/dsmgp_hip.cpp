@@ -91,6 +91,12 @@ constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leav
 // (144 leaves) 0.4084 / 0.4079 -> 0.3926 / 0.3912 s; depth 4 (18k leaves) 0.0512 / 0.0514 -> 0.0498 / 0.0499; the shards of 2-, 4- and
 // 8-rank jobs (72 / 36 / 18 leaves) 0.2110 -> 0.1994, 0.1082 -> 0.1044, 0.0584 -> 0.0572; PoE of 128 experts 4.72 -> 4.67 ms
 constexpr int LANES_AUTO_MIN_LEAVES = DSMGP_LANES_AUTO_MIN;
+#ifndef DSMGP_SYM_SHARE
+#define DSMGP_SYM_SHARE 0                // > 0: diagonal tiles run as FULL tiles where they are under 1 / this of a launch's tiles (A/B builds)
+#endif
+#ifndef DSMGP_PAD_SHARE
+#define DSMGP_PAD_SHARE 0                // > 0: short tiles take the column-split form only from 1 / this of a launch's tiles on (A/B builds)
+#endif
 #ifndef DSMGP_SOLO_FACTOR
 #define DSMGP_SOLO_FACTOR 1.56             // time of one workgroup alone on a CU relative to its share of a co-resident pair
 #endif
@@ -1214,23 +1220,25 @@ int build_factor_steps(dsmgp_ctx* c, int lane, bool with_test, StepLists (&phase
                 // rows share tasks)
                 push_fused8_tasks(ftile8, blocks8, d, lf, k);
             }
-            // The lower-blocks-only form of a diagonal tile takes ~0.6 of a full tile (tools/bench_tile_sym.py).  It pays
-            // where diagonal tiles are a large share of a launch (many small leaves: -6 % on the update launches of the
-            // depth-4 model).  In launches dominated by full tiles it does not: tasks of one launch run in rounds of
-            // equal duration and tiles that share a B panel stream it through L2 together; a few shorter tasks mixed in
-            // break that lockstep (measured +1.2 % on the headline model, +0.4 % when issued last), so there the
-            // diagonal tiles stay full tiles.
-            if (nsym * 5 < tiles.size())
+            // The lower-blocks-only form of a diagonal tile takes ~0.6 of a full tile (tools/bench_tile_sym.py), the column-split
+            // form of a short tile (padding rows below: tile_rows_body) its share of rows: together 3.4 % of the headline
+            // model's executed flops (full diagonal tiles 1.5 %, the last row tile of every leaf and of its test rows 1.9 %).
+            // Until round 5 both forms were kept for launches in which such tiles are a large share (1/5, 1/10: depth 4, -6 %
+            // there) -- in launches dominated by full tiles a few shorter tasks measured +1.2 % (round 3, +0.4 % when
+            // issued last).  With the schedule as it is now they pay everywhere: headline, same box, four alternating runs,
+            // 0.3819 -> 0.3792 s with both (two lanes), 0.3981 -> 0.3951 with one lane; depth 4, configs 2 and 3, the shards of 4- and 8-rank
+            // jobs unchanged (profiles/r05_sym_pad_ab.log).
+            if (DSMGP_SYM_SHARE > 0 && nsym * DSMGP_SYM_SHARE < tiles.size())
                 for (auto& u : tiles) u.sym = 0;
-            {   // short tiles (padding rows below): worth the PAD instantiations of the kernels from a 10 % share on (step 0
-                // has no update launch: its panel solves decide)
+            {   // short tiles: the PAD instantiations of the kernels (step 0 has no update launch: its panel solves decide)
                 size_t npad = 0, ntot = tiles.size();
                 for (const auto& u : tiles) npad += (u.mrows != 0 && u.mrows <= 96) ? 1 : 0;
                 if (tiles.empty()) {
                     ntot = trsm.size() - (size_t)S.trsm_off[k];
                     for (size_t q = (size_t)S.trsm_off[k]; q < trsm.size(); ++q) npad += (trsm[q].mrows != 0 && trsm[q].mrows <= 64) ? 1 : 0;
                 }
-                S.pad[k] = (npad * 10 >= ntot && ntot >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
+                const bool share = DSMGP_PAD_SHARE == 0 || npad * (size_t)DSMGP_PAD_SHARE >= ntot;
+                S.pad[k] = (npad > 0 && share && ntot >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
             }
             U.add_step(tiles, k * TB);
             S.step_tiles[k] = (int)tiles.size();
