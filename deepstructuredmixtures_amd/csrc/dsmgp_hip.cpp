@@ -91,6 +91,21 @@ constexpr int FUSED_SHALLOW_MIN_LEAVES = 32;               // ... this many leav
 // (144 leaves) 0.4084 / 0.4079 -> 0.3926 / 0.3912 s; depth 4 (18k leaves) 0.0512 / 0.0514 -> 0.0498 / 0.0499; the shards of 2-, 4- and
 // 8-rank jobs (72 / 36 / 18 leaves) 0.2110 -> 0.1994, 0.1082 -> 0.1044, 0.0584 -> 0.0572; PoE of 128 experts 4.72 -> 4.67 ms
 constexpr int LANES_AUTO_MIN_LEAVES = DSMGP_LANES_AUTO_MIN;
+// The tail of an update launch (UpdateSplitter::add_step): K pieces per tile, and full rounds of tiles that join the tail in
+// launches of under two rounds -- with ONE leaf lane, and with two or more (where the other lane's launch fills the slots a tail
+// leaves idle and cutting it only costs: see add_step)
+#ifndef DSMGP_TAIL_SPLIT_DEFAULT
+#define DSMGP_TAIL_SPLIT_DEFAULT 4
+#endif
+#ifndef DSMGP_TAIL_ROUNDS_DEFAULT
+#define DSMGP_TAIL_ROUNDS_DEFAULT 1
+#endif
+#ifndef DSMGP_TAIL_SPLIT_LANES
+#define DSMGP_TAIL_SPLIT_LANES 1
+#endif
+#ifndef DSMGP_TAIL_ROUNDS_LANES
+#define DSMGP_TAIL_ROUNDS_LANES 0
+#endif
 #ifndef DSMGP_SYM_SHARE
 #define DSMGP_SYM_SHARE 0                // > 0: diagonal tiles run as FULL tiles where they are under 1 / this of a launch's tiles (A/B builds)
 #endif
@@ -198,8 +213,8 @@ void xcd_deal_by_work(std::vector<T>& a, std::vector<U>& b, size_t begin, size_t
 struct UpdateSplitter {
     int ncu = 256;
     bool xcd = true;
-    int tail_split = 4;     // K pieces per tile in the tail of a launch
-    int tail_rounds = 1;    // full rounds (of ncu tiles) that belong to the tail
+    int tail_split = DSMGP_TAIL_SPLIT_DEFAULT;     // K pieces per tile in the tail of a launch (1 = the tail is not cut)
+    int tail_rounds = DSMGP_TAIL_ROUNDS_DEFAULT;   // full rounds (of ncu tiles) that belong to the tail
     std::vector<TileTask> upd;
     std::vector<ReduceTask> red;
     std::vector<int64_t> upd_slab, red_slab;   // slab index of a task's output / first slab, -1 = none
@@ -292,6 +307,12 @@ struct UpdateSplitter {
             // of 256 extra tiles cut in four costs the headline step 3 ms of reduce traffic for nothing, while the 8-rank
             // shard, whose launches are that short, gains 1.7 % from it; with this rule: headline 0.4048 / 0.4019 ->
             // 0.3989 / 0.3993 s, 4-rank shard 0.1080 / 0.1070 -> 0.1051 / 0.1054 s, 8-rank shard and depth 4 unchanged).
+            // Round 5: with two leaf lanes the other lane's launch runs in the slots a tail leaves idle, and the cut tail only
+            // costs (its slabs, the reduce launch on the chain): tail_split 4 -> 1 and tail_rounds 1 -> 0 WHERE THE PLAN HAS LANES,
+            // same box, alternating: headline 0.3871 / 0.3862 -> 0.3825 / 0.3838 s, 8-rank shards 0.0548 / 0.0559 -> 0.0531 / 0.0534
+            // and 0.0551 / 0.0557 -> 0.0531 / 0.0531, 4-rank shard 0.1018 / 0.1024 -> 0.1000 / 0.1009, depth 4 unchanged; with one
+            // lane the same setting costs 4 % (0.4090 / 0.4116 -> 0.4261 / 0.4266; shards +2-3 %): profiles/r05_tail_ab.log.  What
+            // stays with lanes: a remainder of under a quarter round is cut finely enough to fill one round (below).
             const size_t r = T % (size_t)ncu;
             size_t ntail = r + (T < (size_t)(2 * ncu) ? (size_t)tail_rounds * ncu : 0);
             if (ntail > T) ntail = T;
@@ -437,7 +458,8 @@ struct dsmgp_ctx {
     double* slabP = nullptr;        // ... of the prediction sweep
     int ncu = 256;
     bool xcd_order = true;          // XCD-aware task order (speed only)
-    int tail_split = 4, tail_rounds = 1;
+    int tail_split = DSMGP_TAIL_SPLIT_DEFAULT, tail_rounds = DSMGP_TAIL_ROUNDS_DEFAULT;          // plans with one lane
+    int tail_split_lanes = DSMGP_TAIL_SPLIT_LANES, tail_rounds_lanes = DSMGP_TAIL_ROUNDS_LANES;  // plans with two or more
     int ragged_rounds = 2, ragged_div = 4;   // UpdateSplitter::add_step_ragged (launches of the gradient pass)
     std::vector<int> fwd_off, bwd_off;
     DevBuf<SolveTask> fwd, bwd;
@@ -980,8 +1002,8 @@ int build_factor_steps(dsmgp_ctx* c, int lane, bool with_test, StepLists (&phase
         UpdateSplitter& U = split[ph];
         U.ncu = c->ncu;
         U.xcd = c->xcd_order;
-        U.tail_split = c->tail_split;
-        U.tail_rounds = c->tail_rounds;
+        U.tail_split = c->nlanes > 1 ? c->tail_split_lanes : c->tail_split;
+        U.tail_rounds = c->nlanes > 1 ? c->tail_rounds_lanes : c->tail_rounds;
         auto in_phase = [&](const LeafHost& lf) {
             const size_t l = (size_t)(&lf - c->leaves.data());
             return c->leaf_group[l] == ph && c->leaf_lane[l] == lane;
@@ -1965,8 +1987,8 @@ int dsmgp_create(int32_t device_id, dsmgp_ctx** out) {
     }
 #ifdef DSMGP_DIAG   // scheduling knobs of the diagnostic build (DSMGP_XCD, DSMGP_TAIL_SPLIT, DSMGP_TAIL_ROUNDS); the product build reads no tuning variables
     if (const char* s = std::getenv("DSMGP_XCD")) c->xcd_order = std::atoi(s) != 0;
-    if (const char* s = std::getenv("DSMGP_TAIL_SPLIT")) c->tail_split = std::max(1, std::atoi(s));
-    if (const char* s = std::getenv("DSMGP_TAIL_ROUNDS")) c->tail_rounds = std::max(0, std::atoi(s));
+    if (const char* s = std::getenv("DSMGP_TAIL_SPLIT")) c->tail_split = c->tail_split_lanes = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("DSMGP_TAIL_ROUNDS")) c->tail_rounds = c->tail_rounds_lanes = std::max(0, std::atoi(s));
     if (const char* s = std::getenv("DSMGP_RAGGED_ROUNDS")) c->ragged_rounds = std::max(1, std::atoi(s));
     if (const char* s = std::getenv("DSMGP_RAGGED_DIV")) c->ragged_div = std::max(1, std::atoi(s));
 #endif
@@ -2486,8 +2508,8 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
     for (UpdateSplitter& u : U) {
         u.ncu = c->ncu;
         u.xcd = c->xcd_order;
-        u.tail_split = c->tail_split;
-        u.tail_rounds = c->tail_rounds;
+        u.tail_split = c->nlanes > 1 ? c->tail_split_lanes : c->tail_split;
+        u.tail_rounds = c->nlanes > 1 ? c->tail_rounds_lanes : c->tail_rounds;
     }
     std::vector<std::vector<TileTask>> trsm_l((size_t)nl);
     std::vector<int> upd_loc((size_t)nv + 1, 0), red_loc((size_t)nv + 1, 0), trsm_loc((size_t)nv + 1, 0);   // offsets inside the lane's own lists
