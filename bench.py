@@ -562,8 +562,10 @@ def main():
                      "diagonal block from the accumulators, one write; algorithmic flops = update + c_k^2 per solved row)")
         else:
             t_cat, n_l, fl_step = cats["chol_update"], upd_launches, alg_flops
-            kname = ("tile_gemm_kernel_v2<false, 0, false> (update launches of the factorisation, test rows riding along, each task "
-                     "evaluating the kernel function of its own tile; <false, 0, true> in launches with >= 10 % short tiles; "
+            kname = ("tile_gemm_kernel_v2<false, 0, *> (update launches of the factorisation, test rows riding along, each task "
+                     "evaluating the kernel function of its own tile; the same kernel under two symbol names: <false, 0, true> "
+                     "in launches of at least two rounds that carry short tiles -- a leaf's last row tile -- and <false, 0, false> "
+                     "in the others; a profiler's average of `that kernel` is the call-weighted mean of the two rows; "
                      "panel solves run as tile_trsm_kernel, split-K reduces as tile_reduce_kernel, the shallow block steps "
                      "(K <= 512) as diag_fused_reg_kernel + tile_fused8_kernel: all timed apart, device_seconds_per_step; the diagonal blocks of the other steps ride in these launches as DiagFinishTasks)")
         # With two leaf lanes the launches of the kernel overlap in time: `achieved` = their flops over the time during which ANY of

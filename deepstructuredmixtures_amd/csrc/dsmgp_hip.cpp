@@ -1260,7 +1260,10 @@ int build_factor_steps(dsmgp_ctx* c, int lane, bool with_test, StepLists (&phase
                     for (size_t q = (size_t)S.trsm_off[k]; q < trsm.size(); ++q) npad += (trsm[q].mrows != 0 && trsm[q].mrows <= 64) ? 1 : 0;
                 }
                 const bool share = DSMGP_PAD_SHARE == 0 || npad * (size_t)DSMGP_PAD_SHARE >= ntot;
-                S.pad[k] = (npad > 0 && share && ntot >= (size_t)(2 * c->ncu)) ? 1 : 0;   // big launches only
+                // big launches only: the PAD instantiation in EVERY launch leaves the headline, its shards and depth 4 where
+                // they are, costs a single GP of 32 blocks 2 % (2.28 -> 2.33 ms) and gives the PoE of 128 experts 2.4 % (4.50 ->
+                // 4.39 ms): profiles/r05_sym_pad_ab.log
+                S.pad[k] = (npad > 0 && share && ntot >= (size_t)(2 * c->ncu)) ? 1 : 0;
             }
             // (The shorter tasks stay with the tiles of their leaf, whose B panel they share through L2: moved behind the whole
             // tiles of the launch the headline step measures 0.3853 -> 0.3883 s, four alternating runs: profiles/r05_sym_pad_ab.log.)
