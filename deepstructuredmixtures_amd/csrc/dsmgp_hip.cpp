@@ -541,7 +541,8 @@ struct dsmgp_ctx {
     double* slabG = nullptr;
     size_t slabG_count = 0;
     DevBuf<TransTask> gtrans;
-    std::vector<int> gupd_off, gred_off, gtrsm_off;
+    std::vector<int> gupd_off, gred_off, gtrsm_off;   // entry q * gsteps + k: block step k of lane q
+    int glanes = 1;                                    // lanes of the gradient plan (= nlanes of the plan it was built on)
     DevBuf<TileTask> gupd, gtrsm;
     DevBuf<ReduceTask> gred;
     int gsteps = 0;
@@ -3195,68 +3196,99 @@ int build_grad_plan(dsmgp_ctx* c) {
         }
     }
     c->gsteps = nsteps;
-    UpdateSplitter U;
-    U.ncu = c->ncu;
-    U.xcd = c->xcd_order;
-    U.tail_split = c->tail_split;
-    U.tail_rounds = c->tail_rounds;
-    U.ragged_rounds = c->ragged_rounds;
-    U.ragged_div = c->ragged_div;
-    std::vector<TileTask> trsm;
-    c->gupd_off.assign(nsteps + 1, 0);
-    c->gred_off.assign(nsteps + 1, 0);
-    c->gtrsm_off.assign(nsteps + 1, 0);
-    for (int k = 1; k < nsteps; ++k) {
-        c->gupd_off[k] = (int)U.upd.size();
-        c->gred_off[k] = (int)U.red.size();
-        c->gtrsm_off[k] = (int)trsm.size();
-        std::vector<TileTask> tiles;
-        double depth = 0.0;
-        for (int l = 0; l < L; ++l) {
-            const LeafHost& lf = c->leaves[l];
-            if (lf.owner != l || lf.nb <= k || !needX[l]) continue;
-            const LeafDev& d = c->h_leaves[l];
-            for (int t = 0; t < k; ++t) {
-                double* tile = Xt(l) + (size_t)t * TB + (size_t)k * TB * lf.npad;
-                TileTask u{};
-                u.A = Xt(l) + (size_t)t * TB;
-                u.B = d.F + (size_t)k * TB;
-                u.C = tile;
-                u.lda = u.ldb = u.ldc = lf.npad;
-                u.k0 = t * TB;
-                u.k1 = k * TB;
-                u.update = 2;            // the block is defined here: -product, nothing to read (Xt needs no zero fill:
-                u.rev = 1;               //   every later task reads row tile t from column 128 t on only)
-                tiles.push_back(u);
-                depth += u.k1 - u.k0;
-                TileTask s{};
-                s.A = tile;
-                s.B = d.Dinv + (size_t)k * TB * TB;
-                s.C = tile;
-                s.lda = lf.npad;
-                s.ldb = TB;
-                s.ldc = lf.npad;
-                s.k0 = 0;
-                s.k1 = TB;
-                s.update = 0;
-                trsm.push_back(s);
+    // The inversion runs lane by lane like the factorisation (dsmgp_ctx::nlanes; a leaf inverts in the lane that factorised it):
+    // the lists of lane q's block step k are entry q * nsteps + k of the offset tables, one lane's panel solves and reduces run
+    // under the other's update launches.
+    const int nl = std::max(1, c->nlanes);
+    c->glanes = nl;
+    const int nv = nl * nsteps;
+    std::vector<UpdateSplitter> U((size_t)nl);
+    for (UpdateSplitter& u : U) {
+        u.ncu = c->ncu;
+        u.xcd = c->xcd_order;
+        u.tail_split = nl > 1 ? c->tail_split_lanes : c->tail_split;
+        u.tail_rounds = nl > 1 ? c->tail_rounds_lanes : c->tail_rounds;
+        u.ragged_rounds = c->ragged_rounds;      // (0 / 1 / 2 rounds cut under lanes: no difference, profiles/r05_grad_lanes_ab.log)
+        u.ragged_div = c->ragged_div;
+    }
+    std::vector<std::vector<TileTask>> trsm_l((size_t)nl);
+    std::vector<int> upd_loc((size_t)nv + 1, 0), red_loc((size_t)nv + 1, 0), trsm_loc((size_t)nv + 1, 0);   // inside the lane's own lists
+    for (int q = 0; q < nl; ++q) {
+        std::vector<TileTask>& trsm = trsm_l[q];
+        for (int k = 1; k < nsteps; ++k) {
+            const int v = q * nsteps + k;
+            upd_loc[v] = (int)U[q].upd.size();
+            red_loc[v] = (int)U[q].red.size();
+            trsm_loc[v] = (int)trsm.size();
+            std::vector<TileTask> tiles;
+            double depth = 0.0;
+            for (int l = 0; l < L; ++l) {
+                const LeafHost& lf = c->leaves[l];
+                if (lf.owner != l || lf.nb <= k || !needX[l] || (nl > 1 && c->leaf_lane[l] != q)) continue;
+                const LeafDev& d = c->h_leaves[l];
+                for (int t = 0; t < k; ++t) {
+                    double* tile = Xt(l) + (size_t)t * TB + (size_t)k * TB * lf.npad;
+                    TileTask u{};
+                    u.A = Xt(l) + (size_t)t * TB;
+                    u.B = d.F + (size_t)k * TB;
+                    u.C = tile;
+                    u.lda = u.ldb = u.ldc = lf.npad;
+                    u.k0 = t * TB;
+                    u.k1 = k * TB;
+                    u.update = 2;            // the block is defined here: -product, nothing to read (Xt needs no zero fill:
+                    u.rev = 1;               //   every later task reads row tile t from column 128 t on only)
+                    tiles.push_back(u);
+                    depth += u.k1 - u.k0;
+                    TileTask s{};
+                    s.A = tile;
+                    s.B = d.Dinv + (size_t)k * TB * TB;
+                    s.C = tile;
+                    s.lda = lf.npad;
+                    s.ldb = TB;
+                    s.ldc = lf.npad;
+                    s.k0 = 0;
+                    s.k1 = TB;
+                    s.update = 0;
+                    trsm.push_back(s);
+                }
             }
+            const int Kavg = tiles.empty() ? 0 : (int)(depth / tiles.size()) / TB * TB;
+            U[q].add_step_ragged(tiles, std::max(TB, Kavg), k);
         }
-        const int Kavg = tiles.empty() ? 0 : (int)(depth / tiles.size()) / TB * TB;
-        U.add_step_ragged(tiles, std::max(TB, Kavg), k);
     }
-    c->gupd_off[0] = c->gred_off[0] = c->gtrsm_off[0] = 0;
-    if (nsteps > 0) {
-        c->gupd_off[nsteps] = (int)U.upd.size();
-        c->gred_off[nsteps] = (int)U.red.size();
-        c->gtrsm_off[nsteps] = (int)trsm.size();
+    // one list of each kind for all lanes: lane q's tasks behind those of the lanes before it, its slabs behind theirs
+    c->gupd_off.assign((size_t)nv + 1, 0);
+    c->gred_off.assign((size_t)nv + 1, 0);
+    c->gtrsm_off.assign((size_t)nv + 1, 0);
+    std::vector<TileTask> upd_all, trsm_all;
+    std::vector<ReduceTask> red_all;
+    size_t slabs_total = 0;
+    std::vector<size_t> slab_base((size_t)nl, 0);
+    for (int q = 0; q < nl; ++q) {
+        slab_base[q] = slabs_total;
+        slabs_total += U[q].max_slabs;
     }
-    if (U.max_slabs * TB * TB > c->slabG_count) {
+    if (slabs_total * TB * TB > c->slabG_count) {
         arena_put(c, c->slabG);
-        if (int rc = arena_get(c, c->slabG, U.max_slabs * TB * TB)) return rc;
-        c->slabG_count = U.max_slabs * TB * TB;
+        if (int rc = arena_get(c, c->slabG, slabs_total * TB * TB)) return rc;
+        c->slabG_count = slabs_total * TB * TB;
     }
-    U.bind(c->slabG);
+    for (int q = 0; q < nl; ++q) {
+        U[q].bind(c->slabG + slab_base[q] * TB * TB);
+        const int ub = (int)upd_all.size(), rb = (int)red_all.size(), tb = (int)trsm_all.size();
+        for (int k = 0; k < nsteps; ++k) {
+            const int v = q * nsteps + k;
+            c->gupd_off[v] = ub + (k >= 1 ? upd_loc[v] : 0);
+            c->gred_off[v] = rb + (k >= 1 ? red_loc[v] : 0);
+            c->gtrsm_off[v] = tb + (k >= 1 ? trsm_loc[v] : 0);
+        }
+        upd_all.insert(upd_all.end(), U[q].upd.begin(), U[q].upd.end());
+        red_all.insert(red_all.end(), U[q].red.begin(), U[q].red.end());
+        trsm_all.insert(trsm_all.end(), trsm_l[q].begin(), trsm_l[q].end());
+    }
+    c->gupd_off[nv] = (int)upd_all.size();
+    c->gred_off[nv] = (int)red_all.size();
+    c->gtrsm_off[nv] = (int)trsm_all.size();
 
     // contraction tiles: every IsoSE leaf (COPY leaves too: their alpha is their own)
     // Order.  A 128x128 tile task moves 2 x 128 x K operand doubles for 2 x 128^2 x K flops: 8 flop/B, below the
@@ -3317,9 +3349,9 @@ int build_grad_plan(dsmgp_ctx* c) {
     }
     if (int rc = dev_upload(c, c->gtrans, trans)) return rc;
     if (int rc = dev_upload(c, c->gfrob, frob)) return rc;
-    if (int rc = dev_upload(c, c->gupd, U.upd)) return rc;
-    if (int rc = dev_upload(c, c->gred, U.red)) return rc;
-    if (int rc = dev_upload(c, c->gtrsm, trsm)) return rc;
+    if (int rc = dev_upload(c, c->gupd, upd_all)) return rc;
+    if (int rc = dev_upload(c, c->gred, red_all)) return rc;
+    if (int rc = dev_upload(c, c->gtrsm, trsm_all)) return rc;
     if (int rc = dev_upload(c, c->gdot, gd)) return rc;
     if (any_ard && c->D > GRADDOT_STAGE_D)
         return fail(c, DSMGP_E_ARG, "ArdSE length-scale gradients need D <= " + std::to_string(GRADDOT_STAGE_D));
@@ -3378,15 +3410,27 @@ int dsmgp_gradients(dsmgp_ctx* c, double* grad_out, int32_t stride) {
     HIPCHK(c, e_dot.init());
     // Xt = L^-T (blocks left of the diagonal are never written and never read)
     if (c->gtrans.count) transpose_tile_kernel<<<(int)c->gtrans.count * 16, 256, 0, c->stream>>>(c->gtrans.p);
-    for (int k = 1; k < c->gsteps; ++k) {
-        const int nu = c->gupd_off[k + 1] - c->gupd_off[k];
-        if (nu > 0) {
-            launch_tiles(c, c->gupd.p + c->gupd_off[k], nu);
-            const int nr = c->gred_off[k + 1] - c->gred_off[k];
-            if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, c->stream>>>(c->gred.p + c->gred_off[k]);
+    const int gl = c->glanes;
+    if (gl > 1) {       // fork: the lanes' streams wait for the transposes
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int q = 1; q < gl; ++q) HIPCHK(c, hipStreamWaitEvent(c->lane_stream[q], c->ev_fork, 0));
+    }
+    for (int k = 1; k < c->gsteps; ++k)
+        for (int q = 0; q < gl; ++q) {
+            const int v = q * c->gsteps + k;
+            const hipStream_t st = gl > 1 ? c->lane_stream[q] : c->stream;
+            const int nu = c->gupd_off[v + 1] - c->gupd_off[v];
+            if (nu > 0) {
+                launch_tiles(c, c->gupd.p + c->gupd_off[v], nu, 0, false, 0, nullptr, 0, st);
+                const int nr = c->gred_off[v + 1] - c->gred_off[v];
+                if (nr > 0) tile_reduce_kernel<<<nr * REDUCE_WGS, 256, 0, st>>>(c->gred.p + c->gred_off[v]);
+            }
+            const int ns = c->gtrsm_off[v + 1] - c->gtrsm_off[v];
+            if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[v], ns, 1, false, 0, nullptr, 0, st);
         }
-        const int ns = c->gtrsm_off[k + 1] - c->gtrsm_off[k];
-        if (ns > 0) launch_tiles(c, c->gtrsm.p + c->gtrsm_off[k], ns, 1);
+    for (int q = 1; q < gl; ++q) {      // join
+        HIPCHK(c, hipEventRecord(c->ev_join[q], c->lane_stream[q]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[q], 0));
     }
     HIPCHK(c, hipEventRecord(e_inv.a, c->stream));
     double* pfrob = c->d_gpart;
