@@ -1506,6 +1506,10 @@ int build_plan(dsmgp_ctx* c) {
             for (int l = 0; l < L; ++l)
                 if (unit[l] == l) order.push_back(l);
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+            // (Weighing in the chain of a lane's largest leaf -- in the shard of an 8-rank job the lane that holds it ends at 52.3 ms,
+            // the other, of equal flops and 77 steps instead of 103, at 47.5 -- by a cost per block step moves no end time that
+            // matters: shards 0.0520 / 0.0513 / 0.0975 s without, 0.0519 / 0.0514 / 0.0971 with 0.13 ms a step, slower beyond;
+            // tools/lane_timeline.py, profiles/r05_tail_ab.log.  What the early lane leaves behind runs on the whole chip.)
             double load[MAX_LANES] = {};
             std::vector<char> of_unit(L, 0);
             for (int u : order) {
@@ -1811,13 +1815,11 @@ struct PhaseTimer {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, c->event_pool[s.e0], c->event_pool[s.e1]);
             c->timings[s.slot] += ms * 1e-3;
-            if (ref && (s.slot == 1 || s.slot == 18)) {
-                float a = 0.f;
-                (void)hipEventElapsedTime(&a, ref, c->event_pool[s.e0]);
-                iv[s.slot == 1 ? 0 : 1].push_back({a, a + ms});
-            }
+            float a = -1.f;
+            if (ref && (log || s.slot == 1 || s.slot == 18)) (void)hipEventElapsedTime(&a, ref, c->event_pool[s.e0]);
+            if (ref && (s.slot == 1 || s.slot == 18)) iv[s.slot == 1 ? 0 : 1].push_back({a, a + ms});
             if (log && s.step >= 0)
-                std::fprintf(stderr, "steplog slot %d step %d tasks %d tiles %d ms %.4f\n", s.slot, s.step, s.tasks, s.red, ms);
+                std::fprintf(stderr, "steplog slot %d step %d tasks %d tiles %d ms %.4f at %.4f\n", s.slot, s.step, s.tasks, s.red, ms, a);
         }
         for (int q = 0; q < 2; ++q) {
             std::sort(iv[q].begin(), iv[q].end());
