@@ -673,12 +673,14 @@ def test_sparse_overlap_and_level_order_tree_passes_match_the_recursions():
         m = dsm.buildDSMGP(X, y, 3, 4, M=c["M"], D=c["depth"], kernel=c["kernel"], fit_now=False, seed=3 + i)
         if not isinstance(c["kernel"], list):
             ov = ptree.LeafOverlap(m.leaves)
-            assert np.array_equal(ov.todense(), m.D)
+            dense = ptree.get_overlap(m.root, m.L, sparse_from=10 ** 9)       # the dense evaluation, whatever the model keeps
+            assert isinstance(dense, np.ndarray) and np.array_equal(ov.todense(), dense)
+            assert isinstance(m.D, ptree.LeafOverlap) == (m.L > 1024)
             # the library's inverted-index routine (dsmgp_overlap_main) == the sparse-product evaluation, bit for bit
             nat, ref = ov.main_pairs(native=True), ptree.LeafOverlap(m.leaves).main_pairs(native=False)
             assert all(np.array_equal(u, v) for u, v in zip(nat, ref))
             for tau in (0.05, 0.0):
-                a = ptree.share_schedule(m.leaves, m.D, tau)
+                a = ptree.share_schedule(m.leaves, dense, tau)
                 b = ptree.share_schedule(m.leaves, ov, tau)
                 assert all(np.array_equal(u, v) for u, v in zip(a, b))
         m.leaf_mll = -50.0 * rng.random(m.L) - 5.0
