@@ -1535,6 +1535,9 @@ int build_plan(dsmgp_ctx* c) {
                 const LeafHost& lf = c->leaves[l];
                 if (c->leaf_group[l] == ph && lf.owner == l && lf.nb > k && k >= lf.kb) ++nd;
             }
+            // (a depth limit on the first rule -- classic steps from block step 6 / 10 / 14 on even where the diagonal blocks fill
+            // the chip -- gives the depth-3 model, whose fused steps reach K = 2304, 1.2 % at every limit and leaves depth 4
+            // where it is: profiles/r05_tail_ab.log)
             // fused: the diagonal blocks alone fill the chip -- or the step is shallow (K <= 512: the one workgroup that
             // updates a diagonal tile before factorising it is done in a few microseconds; deeper, that update belongs in
             // the many-workgroup update launch, split along K)
