@@ -11,6 +11,11 @@ scalar Julia code (routing, log-domain mixture aggregation, weights), plus leaf 
 """
 import numpy as np
 
+try:
+    import xxhash as _xxhash
+except ImportError:          # pragma: no cover
+    _xxhash = None
+
 from . import hipabi
 from .kernels import IsoSE, ConstMean, KIND_ISO_SE, KIND_ARD_SE, KIND_ISO_LINEAR
 from .tree import (DSMGPConfig, GPSumNode, build_tree, get_leaves, get_overlap, obs_table, share_schedule, share_decisions,
@@ -819,11 +824,20 @@ def finetune(model, optim=None, *, iterations=1000, lam=0.5, tau=0.05, verbose=F
 
 # ------------------------------------------------------------------------------------ predict
 
+def _content_hash(a):
+    """64-bit hash of an array's contents: what tells `predict` that it is handed the test set it has registered.  xxh3 over the
+    buffer where the array is contiguous (20 us for the 640 KB of 10k x 8 rows; hash(a.tobytes()) is a copy and a SipHash: 0.28 ms,
+    a third of predict's host time on a resident test set at depth 4)."""
+    if _xxhash is not None and a.flags.c_contiguous:
+        return _xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
+    return hash(a.tobytes())
+
+
 def _routing(model, xt, host_routes=True):
     """Routes of one test set, cached on the model: which rows each leaf predicts (CSR over all leaves and over
     this rank's leaves) and, filled lazily by the aggregation, the child masks of every split node.  With
     host_routes=False only the cache entry is made: the context routes the rows itself (`set_test_routed`)."""
-    key = (xt.shape, hash(xt.tobytes()))
+    key = (xt.shape, _content_hash(xt))
     rc = model._route_cache
     if rc is None or rc["key"] != key:
         rc = model._route_cache = dict(key=key, ptr=None, idx=None, lptr=None, lidx=None, masks={}, uploaded=False)
