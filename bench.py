@@ -29,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_FILE = "r05_update_kernel_traffic.json"
+TRAFFIC_FILE = "r06_update_kernel_traffic.json"
 
 
 def source_stamp():
@@ -153,11 +153,7 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
     est = float(np.sum(cost / rate(nobs)))
     t_held = lean(held)
     pred_held = float(cost[held] / rate(nobs[held]))
-    try:
-        import threadpoolctl
-        threads = max([p["num_threads"] for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    threads = blas_threads() or os.cpu_count() or 1
     # "as written" (SURVEY 8(d)): the reference factorises every leaf twice per fit! (F3), forms the full K_tt and
     # V^T V in prediction and predicts in two passes (F10).  Timed on up to eight sampled leaves SPREAD OVER THE SIZE RANGE
     # (quantiles of the sample by n, the smallest and the largest included: LAPACK runs the small leaves at a tenth of its
@@ -178,6 +174,9 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
         written8 += time.perf_counter() - t0
     by_size = sorted(sample, key=lambda j: nobs[j])
     return {"value": est, "unit": "s", "cores": int(threads), "kind": "port",
+            "blas_threads": blas_threads(), "host_cpus": os.cpu_count(),
+            "dpotrf_probe": dpotrf_probe(),      # how strong this baseline's own engine is on this host (a weakly threaded
+                                                 # OpenBLAS makes the GPU/CPU ratio large: the ratio is no credit, the roofline is)
             "sample": f"{len(sample)} of {model.L} leaves (n={int(nobs[sample].min())}..{int(nobs[sample].max())}, the largest leaf "
                       f"included) timed {spent:.1f} s with the NumPy/LAPACK oracle, one potrf per leaf + alpha + diag-only predict; "
                       f"every other leaf priced at n^3/3 + n^2(n_t+2) flops over the measured rate interpolated at its size",
@@ -190,6 +189,133 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
                                f"{written8 / lean8:.2f}x the lean form on {len(eight)} sampled leaves spread over n = "
                                f"{int(nobs[eight[0]])}..{int(nobs[eight[-1]])} "
                                f"({lean8:.1f} s vs {written8:.1f} s)"}
+
+
+def dpotrf_probe(n=8192):
+    """GFLOP/s of ONE LAPACK dpotrf of order n on this host with the BLAS threads the oracle runs on: how strong the CPU baseline's
+    own engine is (SciPy's OpenBLAS reaches a few hundred GFLOP/s on a well-threaded 64-core box, tens when it is not)."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n, 256))
+    S = A @ A.T
+    S[np.diag_indices(n)] += float(n)
+    sl.lapack.dpotrf(S[:512, :512].copy(order="F"), lower=1)       # thread pool start-up
+    F = np.asfortranarray(S)
+    t0 = time.perf_counter()
+    _, info = sl.lapack.dpotrf(F, lower=1, overwrite_a=1)
+    dt = time.perf_counter() - t0
+    return {"n": n, "seconds": dt, "gflops": n ** 3 / 3 / dt / 1e9, "info": int(info)}
+
+
+def blas_threads():
+    try:
+        import threadpoolctl
+        return max([p["num_threads"] for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        return None
+
+
+def short_series(ctx, step, flops_step, steps, warmup, torch):
+    """A short timed series of one of the other single-GPU BASELINE configs (run by the default bench after the headline series,
+    outside its timed region): `steps` calls of step() on wall clock with totals-only timing, then the same number with HIP events
+    around the launches of the dominant kernel -> {step_s, roofline}.  flops_step = sum n^3/3 + n^2 n_t over the leaves."""
+    ctx.set_profile(0)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    walls = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        step()
+        walls.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    ctx.set_profile(3)      # events around the dominant launches, under the kernel names of untimed launches: a profiler's
+    step()                  # average of the headline's timed instantiation (<false, 0, *>) stays the headline's
+    cats, walls_p, n_upd, n_fus = {}, [], 0, 0
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        step()
+        walls_p.append(time.perf_counter() - t0)
+        for k, v in ctx.timings().items():
+            cats[k] = cats.get(k, 0.0) + v
+        n_upd += ctx.work()[1]
+        n_fus += ctx.work_fused()[1]
+    ctx.set_profile(0)
+    fused = cats.get("chol_fused", 0.0) > cats.get("chol_update", 0.0)
+    fl, n_l = (ctx.work_fused()[0], n_fus) if fused else (ctx.work()[0], n_upd)
+    t_sum = cats.get("chol_fused" if fused else "chol_update", 0.0)
+    t_union = cats.get("chol_fused_union" if fused else "chol_update_union", 0.0) or t_sum
+    med = float(np.median(walls))
+    out = {"step_s": spread(walls), "step_s_with_launch_events": spread(walls_p), "steps": steps,
+           "matrix_flops_per_step": flops_step, "whole_step_tflops": flops_step / med / 1e12,
+           "whole_step_frac": flops_step / med / 1e12 / F64_MATRIX_PEAK_TFLOPS,
+           "device_seconds_per_step": {k: v / steps for k, v in cats.items() if v > 0}}
+    if t_union > 0 and n_l > 0:
+        ach = fl * steps / t_union / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "tile_fused8_kernel<0> (fused block steps: update + solve)" if fused
+                           else "tile_gemm_kernel_v2<false, 0, *> (update launches)",
+                           "alg_flops": fl, "achieved": ach, "peak": F64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / F64_MATRIX_PEAK_TFLOPS, "launches_per_step": n_l // steps,
+                           "avg_launch_ms": t_sum / n_l * 1e3, "launch_seconds_per_step": {"sum": t_sum / steps, "union": t_union / steps},
+                           "traffic": None}
+    return out
+
+
+def other_configs(device, torch):
+    """BASELINE configs 2, 3 and 4'' (depth 4) on this GPU, each with its own model and context, after the headline series:
+    {name: {step_s, roofline{kernel, alg_flops, achieved, frac}, ...}} (VERDICT r5 #1b: every single-GPU config driver-observed)."""
+    import deepstructuredmixtures_amd as dsm
+    from deepstructuredmixtures_amd import tree as ptree
+    h = HYPER["survey"]
+    out = {}
+    # config 2: one exact GP, N = 4096, D = 4, IsoSE: update_cholesky! + prediction on N/10 rows (src/gaussianprocess.jl:82-137)
+    X, y, Xt = dsm.regression_data(4096, 4, seed=20202)
+    gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(h["logl"], h["logs"]), logNoise=h["lognoise"], device=device)
+
+    def step2():
+        dsm.update_cholesky(gp)
+        return dsm.prediction(gp, Xt)
+    r = short_series(gp.model.ctx, step2, 4096.0 ** 3 / 3 + 4096.0 ** 2 * Xt.shape[0], 30, 3, torch)
+    r["workload"] = f"single GaussianProcess N=4096 D=4 IsoSE: update_cholesky! + prediction(gp, x) on {Xt.shape[0]} rows; 32 dependent block steps"
+    out["single_gp_n4096"] = r
+    gp.model.ctx.close()
+    # config 3: buildPoE K = 8, M = 200, N = 50k, D = 8, ArdSE (additive): 128 independent experts n ~ 391
+    X, y, Xt = dsm.regression_data(50_000, 8, seed=20203)
+    m = dsm.buildPoE(X, y, 8, M=200, kernel=dsm.ArdSE(np.full(8, h["logl"]), h["logs"]), logNoise=h["lognoise"],
+                     meanFun=dsm.ConstMean(float(np.mean(y))), seed=20203, fit_now=False, device=device)
+    nobs = np.array([lf.nobs for lf in m.leaves], dtype=np.float64)
+
+    def step3():
+        dsm.fit(m)
+        return dsm.predict(m, Xt)
+    r = short_series(m.ctx, step3, float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2) * Xt.shape[0]), 30, 3, torch)
+    r["workload"] = (f"buildPoE K=8 M=200 N=50000 D=8 ArdSE: {m.L} experts n={int(nobs.min())}..{int(nobs.max())}, every expert predicts all "
+                     f"{Xt.shape[0]} rows; fit! + predict; the kernel function (8 exp per entry) shares the f64 pipe with the MFMAs")
+    out["poe_ardse_n50k"] = r
+    m.ctx.close()
+    # config 4'': the headline data at tree depth 4 (18,461 leaves, n = 103..2,668: the small-leaf regime)
+    c = CONFIGS["dsmgp_n100k_d8_depth4"]
+    X, y, Xt = dsm.regression_data(c["N"], c["D"], seed=20204)
+    t0 = time.perf_counter()
+    m = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=dsm.IsoSE(h["logl"], h["logs"]), logNoise=h["lognoise"],
+                       seed=20204, fit_now=False, device=device)
+    t_build = time.perf_counter() - t0
+    nobs = np.array([lf.nobs for lf in m.leaves], dtype=np.float64)
+    ptr, _ = ptree.route(m.root, Xt)
+    dsm.resident_test(m, Xt)
+
+    def step4():
+        dsm.fit(m)
+        dsm.update(m)
+        return dsm.predict(m, Xt)
+    r = short_series(m.ctx, step4, float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2 * np.diff(ptr))), 10, 2, torch)
+    r["workload"] = (f"buildDSMGP K=4 splits V=3 sum children M=200 N=100000 D=8 IsoSE depth 4: {m.L} leaf GPs n={int(nobs.min())}.."
+                     f"{int(nobs.max())}, {Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; fit! + update! + predict")
+    r["model_build_s"] = t_build
+    r["lanes"] = m.ctx.lanes()
+    out["dsmgp_depth4"] = r
+    m.ctx.close()
+    return out
 
 
 def bench_train(args, model, X, y, rank, world, td, torch):
@@ -366,6 +492,8 @@ def main():
                     help="hyper-parameters of the run: survey (default: IsoSE(log 0.3, 0), logNoise log 0.1) or the "
                          "reference's own defaults IsoSE(1, 1), logNoise 1 (src/treeStructure.jl:332-334), SURVEY 8(d)'s secondary point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short series of BASELINE configs 2, 3 and depth 4 that follow the headline series (N = 1, default config)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel categories with hipEvents")
     ap.add_argument("--unfused-gram", action="store_true",
                     help="diagnostic: every Gram tile through memory first (DSMGP_OPT_FUSED_GRAM = 0), for A/B runs")
@@ -451,6 +579,12 @@ def main():
             n_sub = 1
             model._n_sub, model._ctx = 1, None
             ctx = model.ctx
+    # N > 1 over RCCL: the library's own communicator (dsmgp_fit_exchange / dsmgp_aggregate_exchange: payload in HBM, collective
+    # on the context's stream) is built and PROVEN now, before the first series, and left on standby: the timed series below
+    # travels over torch.distributed (the path every world-2 test covers), a second series of the same steps then over the
+    # communicator -- so the first hardware run with more than one rank shows both paths in one line
+    if td is not None and exchange_backend == "nccl" and n_sub == 1 and isinstance(ctx, dsm.hipabi.Context) and not args.simulate_shard:
+        model.shard.device_comm(ctx, force=True, standby=True)
     if args.unfused_gram:
         ctx.set_option(dsm.hipabi.OPT_FUSED_GRAM, 0)
     if args.no_fused_steps:
@@ -547,6 +681,36 @@ def main():
                 "exchange_s_per_step": (xs1 - xs0) / args.steps, "exchanges_per_step": (xn1 - xn0) / args.steps}
         ranks_info = [None] * world
         td.all_gather_object(ranks_info, mine)
+
+    # The same steps once more with the exchanges inside the library (RCCL on the context's stream, payload in HBM): every rank
+    # holds the standby communicator or none does (its set-up MIN-reduces every verdict), so every rank enters this block or none
+    device_series = None
+    if td is not None and model.shard.standby_ctx is not None:
+        mu_t, var_t = mu.copy(), var.copy()
+        model.shard.activate_device_exchange()
+        step()                                   # its fit_exchange is cross-checked against torch.distributed (dist.Shard.fit_exchange)
+        sync_all()
+        xd0, xdn0 = model.shard.exchange_seconds, model.shard.exchanges
+        td0 = time.perf_counter()
+        walls_d = []
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            mu, var = step()
+            walls_d.append(time.perf_counter() - ts)
+        sync_all()
+        el_d = time.perf_counter() - td0
+        tmax = torch.tensor([el_d], dtype=torch.float64, device="cpu")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        mine_d = {"rank": rank, "step_s": spread(walls_d), "exchange_s_per_step": (model.shard.exchange_seconds - xd0) / args.steps,
+                  "exchanges_per_step": (model.shard.exchanges - xdn0) / args.steps, "exchange_in_use": model.shard.exchange,
+                  "rccl_ranks_seen": model.shard.rccl_ranks_seen,
+                  "max_abs_diff_vs_torch_series": [float(np.max(np.abs(mu - mu_t))), float(np.max(np.abs(var - var_t)))]}
+        ranks_d = [None] * world
+        td.all_gather_object(ranks_d, mine_d)
+        device_series = {"value": float(tmax.item()) / args.steps, "unit": "s", "steps": args.steps, "ranks": ranks_d,
+                         "note": "the same steps with the (mll, info) all-gather and the aggregation's partial sums exchanged inside the "
+                                 "library (dsmgp_fit_exchange / dsmgp_aggregate_exchange over RCCL, device to device); the first exchange "
+                                 "cross-checked against torch.distributed; `value` of the line is the torch.distributed series"}
 
     # roofline of the dominant kernel on this rank: the f64-MFMA update launches (tile_gemm_kernel_v2) -- or, where the fused
     # block steps dominate (many small leaves), the fused tile launches (tile_fused8_kernel: update + solve)
@@ -712,6 +876,7 @@ def main():
         if world > 1:
             out["exchange_backend"] = exchange_backend      # "nccl" (= RCCL); "gloo" only if RCCL did not come up on this node
             out["ranks"] = ranks_info
+            out["device_exchange_series"] = device_series   # None: no RCCL group, or the library's communicator did not come up
         if standalone is not None:
             out["drop_in_s"] = standalone["step_s"]
             out["standalone_fit_s"] = standalone["fit_s"]["median"]
@@ -720,6 +885,10 @@ def main():
             out["drop_in"] = standalone
         if roof is not None:
             out["roofline"] = roof
+        if (world == 1 and args.config == "dsmgp_n100k_d8" and not args.simulate_shard and not args.no_other_configs
+                and args.hyper == "survey"):
+            # BASELINE configs 2, 3 and depth 4 on the same GPU, each a short series of its own (after every headline series)
+            out["configs"] = other_configs(local_rank, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, X, y, Xt, ptr, idx)
             out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / per_step

@@ -9,6 +9,7 @@
 #include "kernels_fused.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2630,18 +2631,30 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
       }
     };
     {
+        // nothing may throw across the ABI, and nothing may leave a worker thread (std::terminate) or unwind past a joinable one:
+        // every lane's build runs inside a catch that records the failure (bad_alloc from the 90k-task vectors of a large
+        // registration), the workers are joined first, then the call returns DSMGP_E_NOMEM
+        std::atomic<bool> lane_failed{false};
+        auto build_lane_safe = [&](int q) {
+            try {
+                build_lane(q);
+            } catch (...) {
+                lane_failed.store(true);
+            }
+        };
         std::vector<std::thread> th;
         int started = 1;                    // lanes [1, started) have a thread of their own
         try {
             for (int q = 1; q < nl; ++q) {
-                th.emplace_back(build_lane, q);
+                th.emplace_back(build_lane_safe, q);
                 started = q + 1;
             }
-        } catch (...) {                     // no thread to be had: the remaining lanes are built here (nothing may throw across the ABI)
+        } catch (...) {                     // no thread to be had: the remaining lanes are built here
         }
-        build_lane(0);
+        build_lane_safe(0);
         for (std::thread& t : th) t.join();
-        for (int q = started; q < nl; ++q) build_lane(q);
+        for (int q = started; q < nl; ++q) build_lane_safe(q);
+        if (lane_failed.load()) return fail(c, DSMGP_E_NOMEM, "set_test: out of host memory while building the sweep's task lists");
     }
     // one split-K workspace per lane, one list of each kind for all lanes (lane after lane)
     size_t slab_tot = 0;
@@ -2719,10 +2732,11 @@ int register_test(dsmgp_ctx* c, HostLog& hl) {
 
 extern "C" {
 
-int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* route_ptr, const int64_t* route_idx) {
+int dsmgp_set_test(dsmgp_ctx* c, const double* Xt, int64_t n_t, int32_t D, const int64_t* route_ptr, const int64_t* route_idx) {
     if (!c) return DSMGP_E_ARG;
     if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_test before set_leaves");
     if (!Xt || n_t <= 0 || !route_ptr) return fail(c, DSMGP_E_ARG, "set_test: bad arguments");
+    if (D != c->D) return fail(c, DSMGP_E_ARG, "set_test: the test matrix has " + std::to_string(D) + " columns, the training data " + std::to_string(c->D));
     HIPCHK(c, hipSetDevice(c->device));
     HostLog hl_total("set_test");
     if (!c->plan_ready)
@@ -2826,11 +2840,12 @@ int dsmgp_set_tree(dsmgp_ctx* c, int64_t n_nodes, const int8_t* kind, const int6
     return 0;
 }
 
-int dsmgp_set_test_routed(dsmgp_ctx* c, const double* Xt, int64_t n_t) {
+int dsmgp_set_test_routed(dsmgp_ctx* c, const double* Xt, int64_t n_t, int32_t D) {
     if (!c) return DSMGP_E_ARG;
     if (c->L == 0) return fail(c, DSMGP_E_STATE, "set_test before set_leaves");
     if (!c->rtree_ready) return fail(c, DSMGP_E_STATE, "set_test_routed before set_tree");
     if (!Xt || n_t <= 0) return fail(c, DSMGP_E_ARG, "set_test_routed: bad arguments");
+    if (D != c->D) return fail(c, DSMGP_E_ARG, "set_test_routed: the test matrix has " + std::to_string(D) + " columns, the training data " + std::to_string(c->D));
     HIPCHK(c, hipSetDevice(c->device));
     HostLog hl_total("set_test_routed");
     if (!c->plan_ready)
@@ -2878,7 +2893,7 @@ int dsmgp_set_test_routed(dsmgp_ctx* c, const double* Xt, int64_t n_t) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (flag != 0) {
         free_test(c);
-        return fail(c, DSMGP_E_ARG, "set_test_routed: a test row lies outside the region of a split node (the reference loops forever there)");
+        return fail(c, DSMGP_E_DOMAIN, "set_test_routed: a test row lies outside the region of a split node (the reference loops forever there)");
     }
     const int64_t total = c->route_ptr[(size_t)L];
     if (total > (int64_t)INT32_MAX) {
@@ -3006,9 +3021,9 @@ int dsmgp_predict_fetch(dsmgp_ctx* c, double* mu_out, double* var_out) {
     return 0;
 }
 
-int dsmgp_predict_leaves(dsmgp_ctx* c, const double* Xt, int64_t n_t, const int64_t* route_ptr,
+int dsmgp_predict_leaves(dsmgp_ctx* c, const double* Xt, int64_t n_t, int32_t D, const int64_t* route_ptr,
                          const int64_t* route_idx, double* mu_out, double* var_out) {
-    if (int rc = dsmgp_set_test(c, Xt, n_t, route_ptr, route_idx)) return rc;
+    if (int rc = dsmgp_set_test(c, Xt, n_t, D, route_ptr, route_idx)) return rc;
     if (int rc = dsmgp_predict_run(c, nullptr)) return rc;
     return dsmgp_predict_fetch(c, mu_out, var_out);
 }

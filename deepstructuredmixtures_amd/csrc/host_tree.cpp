@@ -169,9 +169,9 @@ extern "C" int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64
 namespace {
 #pragma clang fp contract(off)
 
-// NumPy's pairwise summation (add.reduce of a contiguous float64 vector; numpy/_core/src/umath/loops_utils.h.src):
-// plain loop below 8 elements, eight running sums up to 128, halves (the first a multiple of 8 long) above.
-static double np_sum(const double* a, int64_t n) {
+// NumPy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src): plain loop below 8 elements, eight running sums up to
+// 128, halves (the first a multiple of 8 long) above.
+static double np_pairwise(const double* a, int64_t n) {
     if (n < 8) {
         double r = -0.0;
         for (int64_t i = 0; i < n; ++i) r += a[i];
@@ -189,7 +189,18 @@ static double np_sum(const double* a, int64_t n) {
     }
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
-    return np_sum(a, n2) + np_sum(a + n2, n - n2);
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+
+// add.reduce of a contiguous float64 vector as NumPy evaluates it: the reduction walks the vector in chunks of the ufunc buffer
+// size (8192 elements, np.getbufsize()), each chunk pairwise, the chunk sums added in order.  Until round 6 this was ONE pairwise
+// sum over the whole vector -- equal to NumPy's up to 8192 elements, an ulp off above (found by oracle/tree.py on the headline
+// model: the ConstMean of 15 of its 144 leaves, n > 8192).
+static double np_sum(const double* a, int64_t n) {
+    constexpr int64_t NP_BUFSIZE = 8192;
+    double out = 0.0;
+    for (int64_t i = 0; i < n; i += NP_BUFSIZE) out += np_pairwise(a + i, std::min(NP_BUFSIZE, n - i));
+    return out;
 }
 
 struct TreeBuild {
@@ -637,17 +648,20 @@ extern "C" int dsmgp_tree_route(int64_t n_nodes, const int8_t* kind, const int64
         sdim[(size_t)i] = (int32_t)split_dim[i];
         leaf[(size_t)i] = kind[i] == 0 ? (int32_t)leaf_id[i] : -1;
     }
-    if (dsmgp::route_stack_need(n_nodes, kind, first.data(), nch.data(), need.data()) > dsmgp::ROUTE_STACK) return -1;
+    // the walk's pending-node stack on the heap, sized by THIS tree: the host routine takes any tree (the device walk has the
+    // fixed ROUTE_STACK and dsmgp_set_tree refuses a tree beyond it -- the caller then routes here)
+    std::vector<int32_t> stack((size_t)dsmgp::route_stack_need(n_nodes, kind, first.data(), nch.data(), need.data()));
     const dsmgp::RouteTree t{kind, first.data(), nch.data(), sdim.data(), leaf.data(), thr, (int)thr_ld};
     std::vector<int64_t> cnt((size_t)n_leaves, 0);
     for (int64_t r = 0; r < n_t; ++r)
-        if (dsmgp::route_walk_row(t, x, row_stride, col_stride, r, [&](int l, int) { ++cnt[(size_t)l]; }) < 0) return -1;   // outside
+        if (dsmgp::route_walk_row_on(stack.data(), t, x, row_stride, col_stride, r, [&](int l, int) { ++cnt[(size_t)l]; }) < 0)
+            return -6;  // DSMGP_E_DOMAIN: a row outside the region of a split node (NaN included), not a malformed call
     route_ptr[0] = 0;
     for (int64_t l = 0; l < n_leaves; ++l) route_ptr[l + 1] = route_ptr[l] + cnt[(size_t)l];
     if (n_routes_out) *n_routes_out = route_ptr[n_leaves];
     if (capacity < route_ptr[n_leaves]) return -4;  // DSMGP_E_NOMEM: *n_routes_out says how much
     std::vector<int64_t> fill(route_ptr, route_ptr + n_leaves);
     for (int64_t r = 0; r < n_t; ++r)
-        (void)dsmgp::route_walk_row(t, x, row_stride, col_stride, r, [&](int l, int) { route_idx[fill[(size_t)l]++] = r; });
+        (void)dsmgp::route_walk_row_on(stack.data(), t, x, row_stride, col_stride, r, [&](int l, int) { route_idx[fill[(size_t)l]++] = r; });
     return 0;
 }

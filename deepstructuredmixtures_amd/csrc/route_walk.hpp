@@ -27,9 +27,11 @@ constexpr int ROUTE_STACK = 96;       // pending nodes of one row's walk (route_
 // Depth-first, children in order: leaves are numbered depth-first, so the row meets its leaves in ascending leaf order.
 // visit(leaf, i) for the i-th leaf reached; returns their number, or -1 when the row lies outside the region of a split node
 // (beyond its last threshold -- the reference loops forever there; a NaN coordinate is beyond every threshold).
+// `stack` holds at least route_stack_need(tree) entries: the device walk's fixed ROUTE_STACK (route_walk_row below), the host
+// routine's heap buffer sized by the tree (dsmgp_tree_route: any tree).
 template <class Visit>
-DSMGP_HD inline int route_walk_row(const RouteTree& t, const double* x, int64_t row_stride, int64_t col_stride, int64_t r, Visit&& visit) {
-    int32_t stack[ROUTE_STACK];
+DSMGP_HD inline int route_walk_row_on(int32_t* stack, const RouteTree& t, const double* x, int64_t row_stride, int64_t col_stride, int64_t r,
+                                      Visit&& visit) {
     int sp = 0, cnt = 0;
     stack[sp++] = 0;
     while (sp > 0) {
@@ -55,6 +57,12 @@ DSMGP_HD inline int route_walk_row(const RouteTree& t, const double* x, int64_t 
         }
     }
     return cnt;
+}
+
+template <class Visit>
+DSMGP_HD inline int route_walk_row(const RouteTree& t, const double* x, int64_t row_stride, int64_t col_stride, int64_t r, Visit&& visit) {
+    int32_t stack[ROUTE_STACK];
+    return route_walk_row_on(stack, t, x, row_stride, col_stride, r, visit);
 }
 
 // Most pending nodes any row's walk can hold: need[i] over the subtree of node i, children after their parents (one backward

@@ -41,6 +41,8 @@ class Shard:
         self.exchange_seconds = 0.0   # wall time this rank has spent inside the exchange collectives (waiting for the slowest
         self.exchanges = 0            # rank included): bench.py prints it per rank, so an N-GPU line explains its own efficiency
         self.exchange = "none" if self.world == 1 else "torch"
+        self.standby_ctx = None       # a proven communicator not (yet) carrying the exchanges: device_comm(standby=True)
+        self.rccl_ranks_seen = 0      # ranks whose value came back in the proof all-gather of the communicator
 
     # ---- exchange through the library (RCCL on the context's stream) ----------------------------
     @staticmethod
@@ -60,7 +62,7 @@ class Shard:
         td.all_reduce(flag, op=td.ReduceOp.MIN, group=GROUP)
         return int(flag.item())
 
-    def device_comm(self, ctx, force=False):
+    def device_comm(self, ctx, force=False, standby=False):
         """Set up the library's own RCCL communicator on `ctx` (one per rank): rank 0 draws the 128-byte id,
         torch.distributed carries it to the others, every rank calls dsmgp_comm_init and proves the communicator with one
         tiny all-gather.  Taken when asked for (`device_exchange_requested`) under the `nccl` process group, or with
@@ -70,14 +72,18 @@ class Shard:
         probes that it can reach RCCL at all (draws an id of its own and drops it) and the verdicts are MIN-reduced --
         nobody enters the blocking dsmgp_comm_init unless everybody can; (2) rank 0's id is broadcast; (3) init, verdicts
         MIN-reduced; (4) the proof all-gather, verdicts MIN-reduced: all ranks take the device path or none does, and on any
-        failure the exchanges stay on torch.distributed.  Returns the path in use."""
+        failure the exchanges stay on torch.distributed.  Returns the path in use.
+
+        standby: build and prove the communicator but leave the exchanges on torch.distributed until
+        `activate_device_exchange` (bench.py --gpus N: the communicator exists before the first timed series, which runs over
+        torch.distributed; a second series of the same steps then runs over it -- one run, both paths)."""
         td = _pg()
         if self.world == 1 and force:          # one-rank communicator: the GPU box's test of this path
             uid = ctx.comm_unique_id()
             ctx.comm_init(0, 1, uid)
             self.comm_ctx, self.exchange = ctx, "rccl-device"
             return self.exchange
-        if self.world == 1 or td is None or self.comm_ctx is not None:
+        if self.world == 1 or td is None or self.comm_ctx is not None or self.standby_ctx is not None:
             return self.exchange
         if not force and not (_backend(td) == "nccl" and self.device_exchange_requested()):
             return self.exchange
@@ -98,12 +104,15 @@ class Shard:
         ok = self._all_min(ok)                 # nobody enters the proof collective unless every rank holds a communicator
         if ok == 1:
             try:
-                got = ctx.allgather(np.array([float(self.rank)]))
-                ok = int(np.array_equal(np.asarray(got).ravel(), np.arange(self.world, dtype=np.float64)))
+                got = np.asarray(ctx.allgather(np.array([float(self.rank)]))).ravel()
+                self.rccl_ranks_seen = int(np.unique(got[(got >= 0) & (got < self.world)]).size)
+                ok = int(np.array_equal(got, np.arange(self.world, dtype=np.float64)))
             except Exception:
                 ok = 0
             ok = self._all_min(ok)
-        if ok == 1:
+        if ok == 1 and standby:
+            self.standby_ctx = ctx
+        elif ok == 1:
             self.comm_ctx, self.exchange = ctx, "rccl-device"
             self.verified = False
         else:
@@ -112,6 +121,16 @@ class Shard:
             except Exception:
                 pass
         return self.exchange
+
+    def activate_device_exchange(self):
+        """The exchanges move onto the communicator `device_comm(standby=True)` left proven (every rank calls this at the same
+        point of its program, or none: it is local, the collectives that follow are not).  The first exchange is cross-checked
+        against torch.distributed as after a direct set-up (`fit_exchange`).  False: there is no standby communicator."""
+        if self.standby_ctx is None:
+            return False
+        self.comm_ctx, self.standby_ctx, self.exchange = self.standby_ctx, None, "rccl-device"
+        self.verified = False
+        return True
 
     def drop_device_comm(self):
         """Back to torch.distributed for good (a cross-check of the device exchange failed)."""

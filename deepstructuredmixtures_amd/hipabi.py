@@ -44,13 +44,13 @@ SIGNATURES = {
     "dsmgp_set_sharing": (C.c_int, [_ctx, _ip, _ip, _lp]),
     "dsmgp_set_hyper": (C.c_int, [_ctx, C.c_int32, C.c_int32, _dp, C.c_int32]),
     "dsmgp_fit": (C.c_int, [_ctx, _dp, _ip, _dp]),
-    "dsmgp_set_test": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp]),
+    "dsmgp_set_test": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int32, _lp, _lp]),
     "dsmgp_set_tree": (C.c_int, [_ctx, C.c_int64, C.POINTER(C.c_int8), _lp, _lp, _lp, _dp, C.c_int64, _lp]),
-    "dsmgp_set_test_routed": (C.c_int, [_ctx, _dp, C.c_int64]),
+    "dsmgp_set_test_routed": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int32]),
     "dsmgp_routes": (C.c_int, [_ctx, _lp, _lp]),
     "dsmgp_predict_run": (C.c_int, [_ctx, _dp]),
     "dsmgp_predict_fetch": (C.c_int, [_ctx, _dp, _dp]),
-    "dsmgp_predict_leaves": (C.c_int, [_ctx, _dp, C.c_int64, _lp, _lp, _dp, _dp]),
+    "dsmgp_predict_leaves": (C.c_int, [_ctx, _dp, C.c_int64, C.c_int32, _lp, _lp, _dp, _dp]),
     "dsmgp_gradients": (C.c_int, [_ctx, _dp, C.c_int32]),
     "dsmgp_set_gradient_leaves": (C.c_int, [_ctx, _ip]),
     "dsmgp_set_option": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
@@ -106,10 +106,18 @@ _lib = None
 _diag_lib = None
 
 
+# include/dsmgp_hip.h DSMGP_E_*
+E_ARG, E_STATE, E_HIP, E_NOMEM, E_NODEVICE, E_DOMAIN = -1, -2, -3, -4, -5, -6
+
+
 class DsmgpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"dsmgp error {code}: {msg}")
         self.code = code
+
+
+class DsmgpDomainError(DsmgpError, ValueError):
+    """DSMGP_E_DOMAIN: a test row outside the region of a split node -- the ValueError the host routing raises for the same row."""
 
 
 def load_diag_library():
@@ -182,7 +190,7 @@ class Context:
 
     def _chk(self, rc):
         if rc != 0:
-            raise DsmgpError(rc, self.lib.dsmgp_last_error(self.h).decode())
+            raise (DsmgpDomainError if rc == E_DOMAIN else DsmgpError)(rc, self.lib.dsmgp_last_error(self.h).decode())
 
     def close(self):
         if self.h is not None:
@@ -237,11 +245,19 @@ class Context:
         self._chk(self.lib.dsmgp_fit(self.h, mll.ctypes.data_as(_dp), info.ctypes.data_as(_ip), C.byref(sec)))
         return mll, info, sec.value
 
-    def set_test(self, Xt, route_ptr, route_idx):
+    def _test_matrix(self, Xt):
+        """The test rows as the ABI reads them (n_t x D doubles, column-major); a matrix of another width is refused HERE,
+        before any pointer is handed over (the library checks D once more: DSMGP_E_ARG)."""
         Xt, px = _f64_fortran(Xt)
+        if Xt.ndim != 2 or Xt.shape[1] != self.D:
+            raise ValueError(f"test matrix of shape {Xt.shape}: the model was trained on D = {self.D} columns")
+        return Xt, px
+
+    def set_test(self, Xt, route_ptr, route_idx):
+        Xt, px = self._test_matrix(Xt)
         route_ptr, p0 = _i64(route_ptr)
         route_idx, p1 = _i64(route_idx)
-        self._chk(self.lib.dsmgp_set_test(self.h, px, Xt.shape[0], p0, p1))
+        self._chk(self.lib.dsmgp_set_test(self.h, px, Xt.shape[0], Xt.shape[1], p0, p1))
         self.route_total = int(route_ptr[-1])
         self.n_t = int(Xt.shape[0])
 
@@ -259,8 +275,8 @@ class Context:
 
     def set_test_routed(self, Xt):
         """`set_test` with the routing of predict done on the device (needs `set_tree`)."""
-        Xt, px = _f64_fortran(Xt)
-        self._chk(self.lib.dsmgp_set_test_routed(self.h, px, Xt.shape[0]))
+        Xt, px = self._test_matrix(Xt)
+        self._chk(self.lib.dsmgp_set_test_routed(self.h, px, Xt.shape[0], Xt.shape[1]))
         self.n_t = int(Xt.shape[0])
         ptr = np.zeros(self.L + 1, dtype=np.int64)
         self._chk(self.lib.dsmgp_routes(self.h, ptr.ctypes.data_as(_lp), None))
@@ -766,8 +782,8 @@ def tree_route(kind, first_child, n_child, split_dim, thr, leaf_id, n_leaves, xt
     if rc != 0:
         if rc == -1 and split_dim.size and x.shape[1] <= int(split_dim.max()):
             raise IndexError(f"test rows have {x.shape[1]} columns, the tree splits on dimension {int(split_dim.max())}")
-        raise ValueError("test point outside the region of a split node (reference loops forever here)" if rc == -1
-                         else f"dsmgp_tree_route failed ({rc})")
+        raise ValueError("test point outside the region of a split node (reference loops forever here)" if rc == E_DOMAIN
+                         else f"dsmgp_tree_route failed ({rc}): malformed tree arrays")
     return ptr, idx[:nr.value].copy() if nr.value < idx.size else idx
 
 

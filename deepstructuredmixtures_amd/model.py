@@ -375,9 +375,7 @@ def update_cholesky(gp):
 def prediction(gp, xtest):
     """`prediction(gp, xtest)` -> (mu, diag of Sigma) (`src/gaussianprocess.jl:110-137`; only the
     diagonal of Sigma is ever consumed, `src/common.jl:136,147`)."""
-    xt = np.asfortranarray(xtest, dtype=np.float64)
-    if xt.ndim == 1:
-        xt = xt.reshape(-1, 1)
+    xt = _test_matrix(gp.model, xtest)
     # registered like the test set of a tree model (cached by content): a loop of update_cholesky! + prediction on the same
     # rows carries them through the factorisation launches from its second pass on, and prediction only finishes the moments
     rc = _routing(gp.model, xt)
@@ -825,12 +823,24 @@ def finetune(model, optim=None, *, iterations=1000, lam=0.5, tau=0.05, verbose=F
 # ------------------------------------------------------------------------------------ predict
 
 def _content_hash(a):
-    """64-bit hash of an array's contents: what tells `predict` that it is handed the test set it has registered.  xxh3 over the
-    buffer where the array is contiguous (20 us for the 640 KB of 10k x 8 rows; hash(a.tobytes()) is a copy and a SipHash: 0.28 ms,
-    a third of predict's host time on a resident test set at depth 4)."""
-    if _xxhash is not None and a.flags.c_contiguous:
-        return _xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
-    return hash(a.tobytes())
+    """64-bit hash of an array's contents: what tells `predict` that it is handed the test set it has registered (the cache key
+    is (shape, this hash): a 64-bit content hash decides whether the rows are registered again -- a collision between two test
+    matrices of one shape would reuse the first one's routes, at odds of 2^-64 per pair).  xxh3 over the array's own buffer in
+    whichever contiguous layout it has -- `predict` hands over Fortran-ordered matrices (the layout of the C ABI), whose buffer
+    is the C-ordered buffer of the transpose; anything else (a strided slice) is hashed through one contiguous copy.  xxhash is
+    an optional dependency: without it the bytes go through Python's own hash (a copy and a SipHash: 0.65 ms for 10k x 8 rows
+    against 0.03 ms)."""
+    if a.flags.c_contiguous:
+        buf = a
+    elif a.flags.f_contiguous:
+        buf = a.T
+    else:
+        buf = np.ascontiguousarray(a)
+    if a.size == 0:
+        return 0
+    if _xxhash is not None:
+        return _xxhash.xxh3_64_intdigest(memoryview(buf).cast("B"))
+    return hash(buf.tobytes())
 
 
 def _routing(model, xt, host_routes=True):
@@ -860,11 +870,18 @@ def _register_rows(model, xt, rc):
     if rc["uploaded"]:
         return
     if model._device_routing:
-        model.ctx.set_test_routed(xt)
-    else:
-        if rc["ptr"] is None:
-            _routing(model, xt)
-        model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
+        try:
+            model.ctx.set_test_routed(xt)
+            rc["uploaded"] = True
+            return
+        except hipabi.DsmgpError as e:
+            # the routing workspace (bitmap + prefixes: 8 L ceil(n_t / 32) bytes) did not fit: the host lists need none of it.
+            # Anything else (a row outside a split region: DsmgpDomainError, a ValueError like the host routing's) is the caller's
+            if e.code != hipabi.E_NOMEM:
+                raise
+    if rc["ptr"] is None:
+        _routing(model, xt)
+    model.ctx.set_test(xt, rc["lptr"], rc["lidx"])
     rc["uploaded"] = True
 
 
@@ -881,15 +898,24 @@ def _leaf_moments(model, xt, rc):
     return model.shard.gather_ragged_pair(mu_l, var_l, counts)
 
 
+def _test_matrix(model, xtest):
+    """`xtest` as the n_t x D Fortran-ordered matrix the C ABI reads; a matrix of another width than the training data is
+    refused here, on every path (device routing reads n_t * D doubles from the caller's buffer)."""
+    xt = np.asfortranarray(xtest, dtype=np.float64)
+    if xt.ndim == 1:
+        xt = xt.reshape(-1, 1)
+    if xt.ndim != 2 or xt.shape[1] != model.x.shape[1]:
+        raise ValueError(f"test matrix of shape {xt.shape}: the model was trained on D = {model.x.shape[1]} columns")
+    return xt
+
+
 def resident_test(model, xtest, tau=0.05):
     """Register `xtest` as the resident test set BEFORE the next fit (no reference counterpart): that fit then
     carries the test rows through its factorisation launches and the following `predict(model, xtest)` only
     finishes the moments.  `predict` registers its argument by itself, which pays off from the second fit on;
     this call is for evaluation loops that know their test set up front and for the streaming context, where a
     prediction after an unprepared fit costs a second pass over all leaf groups."""
-    xt = np.asfortranarray(xtest, dtype=np.float64)
-    if xt.ndim == 1:
-        xt = xt.reshape(-1, 1)
+    xt = _test_matrix(model, xtest)
     model._upload(tau)
     rc = _routing(model, xt, host_routes=not model._device_routing)
     if len(model.shard.local):
@@ -897,16 +923,15 @@ def resident_test(model, xtest, tau=0.05):
 
 
 def predict(model, xtest):
-    """`predict(model, x)` -> (mu, var) of length n_t (`src/common.jl:294-307`).  The per-(leaf, row) moments stay on
+    """`predict(model, x)` -> (mu, var) of length n_t (`src/common.jl:294-307`).  The rows are registered with the context once per
+    test matrix: whether `x` is the registered one is decided by (shape, 64-bit content hash) -- `_content_hash`.  The per-(leaf, row) moments stay on
     the device and are aggregated there (`dsmgp_aggregate*`); contexts without that entry (the streaming context, whose
     moments are on the host anyway) use the host rules below."""
     if isinstance(model, GaussianProcess):
         mu, var = prediction(model, xtest)
         var = np.where(var <= 0, EPS, var)
         return mu, var
-    xt = np.asfortranarray(xtest, dtype=np.float64)
-    if xt.ndim == 1:
-        xt = xt.reshape(-1, 1)
+    xt = _test_matrix(model, xtest)
     model._scores_on_device = False
     if hasattr(_ctx_type(model), "aggregate_partial"):       # decided by the model's construction: the same on every rank
         # (a rank that holds leaves and whose context holds the tree routes its rows on the device: no host lists at all)

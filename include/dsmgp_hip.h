@@ -45,6 +45,7 @@ typedef struct dsmgp_ctx dsmgp_ctx;
 #define DSMGP_E_HIP        -3
 #define DSMGP_E_NOMEM      -4
 #define DSMGP_E_NODEVICE   -5
+#define DSMGP_E_DOMAIN     -6   /* a test row outside the region of a split node (NaN included): the reference loops forever there */
 
 /* number of doubles dsmgp_timings() fills: gram, chol_update (the update launches of the tile kernel alone),
  * chol_diag, chol_trsm, solve (forward substitution of COPY / PREFIX leaves), mll, predict_gram, predict_update,
@@ -101,23 +102,24 @@ int dsmgp_fit(dsmgp_ctx* ctx, double* mll_out /* L */, int32_t* info_out /* L */
  * launches (V^T = K_tn L^-T rides along as extra row tiles), and dsmgp_predict_run only finishes mu and var.
  * dsmgp_set_joint(ctx, 0) switches that off (e.g. inside train!, where fit is not followed by predict). */
 int dsmgp_set_joint(dsmgp_ctx* ctx, int32_t on);
-int dsmgp_set_test(dsmgp_ctx* ctx, const double* Xt /* n_t x D */, int64_t n_t,
+/* D = number of columns of Xt as the caller holds it: DSMGP_E_ARG unless it is the D of dsmgp_set_train (n_t * D doubles are read). */
+int dsmgp_set_test(dsmgp_ctx* ctx, const double* Xt /* n_t x D column-major */, int64_t n_t, int32_t D,
                    const int64_t* route_ptr /* L+1 */, const int64_t* route_idx);
 /* predict(model, x) on rows the model has not seen (the reference's normal call, src/common.jl:304-307, src/plot.jl:40): the routing
  * of src/common.jl:101-122,181-196,275-292 on the device.  dsmgp_set_tree registers the model's tree once per leaf table (flat
  * arrays as dsmgp_tree_route takes them; leaf_id = index in THIS context's leaf table, -1 = a region another rank holds; a new
- * leaf table or new training data drop it).  dsmgp_set_test_routed(Xt, n_t) then is dsmgp_set_test with the routes made on the
+ * leaf table or new training data drop it).  dsmgp_set_test_routed(Xt, n_t, D) then is dsmgp_set_test with the routes made on the
  * device: one thread per row walks the tree, a bitmap per leaf turns the visits into the same CSR (rows ascending per leaf) and the
  * same per-row entry index the host path builds -- entry by entry -- and only the L + 1 per-leaf offsets come back to the host
- * (they size the K_tn arena and the sweep's task lists).  DSMGP_E_ARG: a row outside the region of a split node (NaN included).
+ * (they size the K_tn arena and the sweep's task lists).  DSMGP_E_DOMAIN: a row outside the region of a split node (NaN included).
  * dsmgp_routes fetches the CSR of the registered test set (route_ptr: L + 1; route_idx: route_ptr[L] entries, may be NULL). */
 int dsmgp_set_tree(dsmgp_ctx* ctx, int64_t n_nodes, const int8_t* kind, const int64_t* first_child, const int64_t* n_child,
                    const int64_t* split_dim, const double* thr, int64_t thr_ld, const int64_t* leaf_id);
-int dsmgp_set_test_routed(dsmgp_ctx* ctx, const double* Xt /* n_t x D */, int64_t n_t);
+int dsmgp_set_test_routed(dsmgp_ctx* ctx, const double* Xt /* n_t x D column-major */, int64_t n_t, int32_t D);
 int dsmgp_routes(dsmgp_ctx* ctx, int64_t* route_ptr /* L+1 */, int64_t* route_idx /* or NULL */);
 int dsmgp_predict_run(dsmgp_ctx* ctx, double* seconds);   /* device work only, inputs resident */
 int dsmgp_predict_fetch(dsmgp_ctx* ctx, double* mu_out, double* var_out);
-int dsmgp_predict_leaves(dsmgp_ctx* ctx, const double* Xt, int64_t n_t, const int64_t* route_ptr,
+int dsmgp_predict_leaves(dsmgp_ctx* ctx, const double* Xt, int64_t n_t, int32_t D, const int64_t* route_ptr,
                          const int64_t* route_idx, double* mu_out, double* var_out);
 
 /* ---- predict(model, x): sum/product aggregation of the leaf moments over the leaves every test row visits, on the
@@ -272,7 +274,8 @@ int dsmgp_overlap_main(int32_t L, const int64_t* obs_ptr, const int64_t* obs_idx
  * thr[i * thr_ld + 0 .. n_child[i] - 1]), 2 = sum node.
  * x: n_t rows of D columns, element (row r, dimension d) at x[r * row_stride + d * col_stride].  route_ptr: n_leaves + 1 entries; route_idx: `capacity`
  * entries for the rows of every leaf, ascending (a row reaches at most as many leaves as the tree has below sum nodes along one
- * path: n_t times that bound always suffices).  DSMGP_E_ARG: malformed tree, a split dimension >= D, or a row
+ * path: n_t times that bound always suffices).  DSMGP_E_ARG: malformed tree or a split dimension >= D (a tree of any width and depth is taken: the
+ * walk's stack is sized by the tree); DSMGP_E_DOMAIN: a row
  * beyond the last threshold of a split node (the reference loops forever there; a NaN coordinate is beyond every threshold); DSMGP_E_NOMEM: capacity too small -- route_ptr and *n_routes_out are valid, route_idx
  * is not.  At depth 4 (18k leaves, 10k rows to 81 leaves each) the recursion over node objects took 0.09 s on the host, four
  * times the prediction sweep it feeds. */

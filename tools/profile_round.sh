@@ -10,7 +10,7 @@ rm -rf $out && mkdir -p $out
 PMC1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
 PMC2="FETCH_SIZE"
 PMC3="WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 run() {   # run <name> <bench args...>: the three PMC passes FIRST; for the headline run the traffic figure they give is written
           # to profiles/ (on this box) before the stats pass, so that the bench line of the stats pass -- the line that gets
           # committed -- quotes the traffic measured beside it (tools/summarize_profiles.py --traffic-only)
@@ -24,7 +24,7 @@ run() {   # run <name> <bench args...>: the three PMC passes FIRST; for the head
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_stats -- python3 bench.py "$@" > $out/${name}_stats/bench.log 2>&1
   echo "$name stats done"
 }
-run n100k --steps 2 --warmup 2 --no-cpu-baseline
+run n100k --steps 2 --warmup 2 --no-cpu-baseline --no-other-configs
 run depth4 --config dsmgp_n100k_d8_depth4 --steps 2 --warmup 2 --no-cpu-baseline
 run train --mode train --steps 2 --warmup 1
 echo profiled
