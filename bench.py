@@ -104,7 +104,37 @@ def default_sub(world):
     return 1
 
 
+def best_blas_threads():
+    """The BLAS thread count at which this host's LAPACK runs a dpotrf of order 4096 fastest, among 8 .. the count the library
+    picked by itself (OpenBLAS starts 64 threads on the 256-CPU hosts of the GPU boxes, whose share of one GPU job is smaller:
+    oversubscribed, it factorises at a few tens of GFLOP/s) -> (threads, {threads: GFLOP/s}).  The baseline then runs at its best."""
+    try:
+        import threadpoolctl
+    except Exception:
+        return None, {}
+    top = blas_threads() or 1
+    try:
+        top = min(top, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    cand = sorted({t for t in (8, 16, 32, 64, top) if 1 <= t <= max(top, 1)} | {top})
+    sweep = {}
+    for t in cand:
+        with threadpoolctl.threadpool_limits(limits=t, user_api="blas"):
+            sweep[t] = round(dpotrf_probe(4096)["gflops"], 1)
+    return max(sweep, key=sweep.get), sweep
+
+
 def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
+    best_t, sweep = best_blas_threads()
+    if best_t is None:
+        return _cpu_baseline(model, X, y, Xt, ptr, idx, budget_s, None, sweep)
+    import threadpoolctl
+    with threadpoolctl.threadpool_limits(limits=best_t, user_api="blas"):
+        return _cpu_baseline(model, X, y, Xt, ptr, idx, budget_s, best_t, sweep)
+
+
+def _cpu_baseline(model, X, y, Xt, ptr, idx, budget_s, best_t, sweep):
     """Oracle ("port" of the reference's per-leaf arithmetic, LAPACK via SciPy) on a bounded sample of
     the same workload: whole leaves, lean form (one potrf per leaf, diag-only variance), timed on the
     host cores; every other leaf is priced with the cost model n^3/3 + n^2 (n_t + 2) at the measured rate interpolated
@@ -153,7 +183,7 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
     est = float(np.sum(cost / rate(nobs)))
     t_held = lean(held)
     pred_held = float(cost[held] / rate(nobs[held]))
-    threads = blas_threads() or os.cpu_count() or 1
+    threads = best_t or blas_threads() or os.cpu_count() or 1
     # "as written" (SURVEY 8(d)): the reference factorises every leaf twice per fit! (F3), forms the full K_tt and
     # V^T V in prediction and predicts in two passes (F10).  Timed on up to eight sampled leaves SPREAD OVER THE SIZE RANGE
     # (quantiles of the sample by n, the smallest and the largest included: LAPACK runs the small leaves at a tenth of its
@@ -174,7 +204,7 @@ def cpu_baseline(model, X, y, Xt, ptr, idx, budget_s=20.0):
         written8 += time.perf_counter() - t0
     by_size = sorted(sample, key=lambda j: nobs[j])
     return {"value": est, "unit": "s", "cores": int(threads), "kind": "port",
-            "blas_threads": blas_threads(), "host_cpus": os.cpu_count(),
+            "blas_threads": int(threads), "blas_thread_sweep_dpotrf4096_gflops": sweep, "host_cpus": os.cpu_count(),
             "dpotrf_probe": dpotrf_probe(),      # how strong this baseline's own engine is on this host (a weakly threaded
                                                  # OpenBLAS makes the GPU/CPU ratio large: the ratio is no credit, the roofline is)
             "sample": f"{len(sample)} of {model.L} leaves (n={int(nobs[sample].min())}..{int(nobs[sample].max())}, the largest leaf "
@@ -502,7 +532,7 @@ def main():
     ap.add_argument("--no-diag-ahead", action="store_true",
                     help="diagnostic: DSMGP_OPT_DIAG_IN_UPDATE = 0 (a diagonal-block launch per classic step), for A/B runs")
     ap.add_argument("--lanes", type=int, default=None, choices=[0, 1, 2, 3, 4],
-                    help="leaf lanes inside the context (DSMGP_OPT_LANES): default 0 = automatic (two from 8 independent sharing groups on; one in streaming mode)")
+                    help="leaf lanes inside the context (DSMGP_OPT_LANES): default 0 = automatic (two from 8 independent sharing groups on)")
     ap.add_argument("--sub", type=int, default=None,
                     help="concurrent contexts per GPU (hipabi.MultiContext); default 1")
     ap.add_argument("--simulate-shard", default=None, metavar="R/W",
@@ -521,7 +551,17 @@ def main():
     td = None
     exchange_backend = None
     if world > 1:
-        td, exchange_backend, local_rank = init_distributed(rank, world, local_rank, torch)
+        # gloo announces its connections on the process's stdout ("[Gloo] Rank 0 is connected to 1 peer ranks ..."): while the
+        # groups come up, file descriptor 1 points at stderr, so that rank 0's stdout carries the ONE JSON line and nothing else
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            td, exchange_backend, local_rank = init_distributed(rank, world, local_rank, torch)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import deepstructuredmixtures_amd as dsm
     if args.simulate_shard:

@@ -1473,8 +1473,26 @@ int build_plan(dsmgp_ctx* c) {
         }
         if (int rc = dev_upload(c, zrows, zr)) return rc;
         if (!zr.empty()) zero_pad_rows_kernel<<<(int)zr.size(), 256, 0, c->stream>>>(zrows.p);
+    }
+    // the upper 16x16 blocks of every diagonal tile: zero once per plan, written by nobody afterwards (zero_upper_blocks_kernel)
+    DevBuf<ZeroUpperTask> zupper;
+    {
+        std::vector<ZeroUpperTask> zu;
+        int maxnb = 1;
+        for (int l = 0; l < L; ++l) {
+            const LeafHost& lf = c->leaves[l];
+            if (lf.owner != l) continue;
+            zu.push_back(ZeroUpperTask{c->h_leaves[l].F, lf.npad, lf.nb});
+            maxnb = std::max(maxnb, lf.nb);
+        }
+        if (int rc = dev_upload(c, zupper, zu)) return rc;
+        for (size_t b0 = 0; b0 < zu.size(); b0 += 32768) {
+            const size_t cnt = std::min<size_t>(32768, zu.size() - b0);
+            zero_upper_blocks_kernel<<<dim3((unsigned)cnt, (unsigned)std::min(maxnb, 64)), 256, 0, c->stream>>>(zupper.p + b0);
+        }
         const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
         dev_free(zrows);          // before anything below can return
+        dev_free(zupper);
         HIPCHK(c, e1);
         HIPCHK(c, e2);
     }
@@ -1498,8 +1516,9 @@ int build_plan(dsmgp_ctx* c) {
         }
         int nunits = 0;
         for (int l = 0; l < L; ++l) nunits += unit[l] == l ? 1 : 0;
-        c->nlanes = c->lanes_opt > 0 ? c->lanes_opt : ((nunits >= LANES_AUTO_MIN_LEAVES && !c->pool_base) ? 2 : 1);
-        if (c->pool_base) c->nlanes = 1;                    // (the pool is a stack: one split-K workspace per table)
+        // (also under a reserved pool -- the streaming context -- since round 6: every lane's split-K workspace is one more
+        // arena_get on the pool's stack, lane after lane; config 5 at full size 111.4 -> 110.3 s with two lanes in every group)
+        c->nlanes = c->lanes_opt > 0 ? c->lanes_opt : (nunits >= LANES_AUTO_MIN_LEAVES ? 2 : 1);
         c->nlanes = std::max(1, std::min(c->nlanes, nunits));
         c->leaf_lane.assign(L, 0);
         if (c->nlanes > 1) {
@@ -1855,6 +1874,12 @@ void run_step(dsmgp_ctx* c, StepLists& S, int k, PhaseTimer& pt, hipStream_t st,
     if (nfd > 0 || nft8 > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
         if (nfd > 0) {
             pt.begin(2, st);
+#if DSMGP_DIAGR_K0_WGS > 0
+            if (k == 0) {
+                constexpr int K0_LDS = (DIAGR_LDS_DOUBLES > GRAM_FUSE_MAX_D * TB ? DIAGR_LDS_DOUBLES : GRAM_FUSE_MAX_D * TB) * (int)sizeof(double) + 128;
+                diag_fused_reg_k0_kernel<<<nfd, 256, K0_LDS, st>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
+            } else
+#endif
             diag_fused_reg_kernel<<<nfd, 256, DIAGR_LDS_BYTES, st>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
             pt.note(k, nfd, 0);
             pt.end(st);
@@ -4118,6 +4143,97 @@ int dsmgp_probe_diag(dsmgp_ctx* c, int32_t ntiles, int32_t ld, int32_t reps, dou
     (void)hipEventDestroy(e1);
     (void)hipFree(T0); (void)hipFree(T); (void)hipFree(Dinv); (void)hipFree(wz);
     (void)hipFree(info); (void)hipFree(stamps); (void)hipFree(dt);
+    if (bad != 0) return fail(c, DSMGP_E_STATE, "probe block was not positive definite");
+    return 0;
+}
+
+// diagnostic: the diagonal-block task of a FUSED step (diag_fused_reg_kernel) alone on ntiles synthetic blocks of depth K: IsoSE
+// values of random points in [0, 1)^8 (l = 0.3, noise 0.01) minus a small product -- what a depth-4 fit launches 18k of per step.
+// ntiles = 256 / 512 / 768 puts one / two / three tasks on every CU: the latency of a task alone and what co-residents cost it.
+int dsmgp_probe_diag_fused(dsmgp_ctx* c, int32_t ntiles, int32_t K, int32_t reps, double* kernel_us) {
+    if (!c || ntiles <= 0 || K < 0 || K % TB != 0 || reps <= 0 || !kernel_us) return DSMGP_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int D = 8;
+    const size_t leaf = (size_t)TB * (size_t)(K + TB);          // block row: 128 rows x (K + 128) columns, ld = 128
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        return (double)(st >> 11) * (1.0 / 9007199254740992.0);
+    };
+    std::vector<double> hx((size_t)TB * D), ha((size_t)TB * std::max(K, 1));
+    for (double& v : hx) v = rnd();
+    for (double& v : ha) v = (rnd() - 0.5) * 2e-3;
+    double *F = nullptr, *X = nullptr, *Dinv = nullptr, *wz = nullptr, *nh = nullptr;
+    int* info = nullptr;
+    DiagFusedTask* dt = nullptr;
+    KParam* kp = nullptr;
+    HIPCHK(c, hipMalloc(&F, (size_t)ntiles * leaf * sizeof(double)));
+    HIPCHK(c, hipMalloc(&X, (size_t)TB * D * sizeof(double)));
+    HIPCHK(c, hipMalloc(&Dinv, (size_t)ntiles * TB * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&wz, (size_t)ntiles * 2 * TB * sizeof(double)));
+    HIPCHK(c, hipMalloc(&info, ntiles * sizeof(int)));
+    HIPCHK(c, hipMalloc(&dt, ntiles * sizeof(DiagFusedTask)));
+    HIPCHK(c, hipMalloc(&kp, sizeof(KParam)));
+    HIPCHK(c, hipMalloc(&nh, 2 * sizeof(double)));
+    HIPCHK(c, hipMemset(F, 0, (size_t)ntiles * leaf * sizeof(double)));
+    HIPCHK(c, hipMemset(Dinv, 0, (size_t)ntiles * TB * TB * sizeof(double)));
+    HIPCHK(c, hipMemset(wz, 0, (size_t)ntiles * 2 * TB * sizeof(double)));
+    HIPCHK(c, hipMemset(info, 0, ntiles * sizeof(int)));
+    HIPCHK(c, hipMemcpy(X, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (K > 0)
+        for (int i = 0; i < ntiles; ++i)
+            HIPCHK(c, hipMemcpyAsync(F + (size_t)i * leaf, ha.data(), (size_t)TB * K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const double l2 = 0.09, hnh[2] = {-0.5 / l2, l2};
+    HIPCHK(c, hipMemcpy(nh, hnh, sizeof(hnh), hipMemcpyHostToDevice));
+    KParam p{};
+    p.kind = DSMGP_KIND_ISO_SE;
+    p.nl = 1;
+    p.sigma2 = p.sigma = 1.0;
+    p.noise = 0.01;
+    p.l2 = nh + 1;
+    p.nh = nh;
+    p.nh0 = hnh[0];
+    p.il2 = 1.0 / l2;
+    HIPCHK(c, hipMemcpy(kp, &p, sizeof(p), hipMemcpyHostToDevice));
+    std::vector<DiagFusedTask> tasks(ntiles);
+    for (int i = 0; i < ntiles; ++i) {
+        DiagFusedTask f{};
+        f.d.T = F + (size_t)i * leaf + (size_t)K * TB;
+        f.d.Dinv = Dinv + (size_t)i * TB * TB;
+        f.d.wk = wz + (size_t)i * 2 * TB;
+        f.d.zk = wz + (size_t)i * 2 * TB + TB;
+        f.d.info = info + i;
+        f.d.ld = TB;
+        f.d.nvalid = TB;
+        f.d.row0 = 0;
+        f.A = F + (size_t)i * leaf;
+        f.gx = X;
+        f.k1 = K;
+        f.glda = TB;
+        f.kid = 0;
+        tasks[i] = f;
+    }
+    HIPCHK(c, hipMemcpy(dt, tasks.data(), ntiles * sizeof(DiagFusedTask), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    double total = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        diag_fused_reg_kernel<<<ntiles, 256, DIAGR_LDS_BYTES, c->stream>>>(dt, kp, D);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+    }
+    *kernel_us = total / reps * 1e3;
+    int bad = 0;
+    HIPCHK(c, hipMemcpy(&bad, info, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(F); (void)hipFree(X); (void)hipFree(Dinv); (void)hipFree(wz); (void)hipFree(nh);
+    (void)hipFree(info); (void)hipFree(dt); (void)hipFree(kp);
     if (bad != 0) return fail(c, DSMGP_E_STATE, "probe block was not positive definite");
     return 0;
 }

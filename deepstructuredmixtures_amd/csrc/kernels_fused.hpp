@@ -31,6 +31,12 @@ namespace dsmgp {
 #ifndef DSMGP_DIAGR_WGS
 #define DSMGP_DIAGR_WGS 3                 // workgroups per CU the register-resident diagonal-block task is compiled for
 #endif
+#ifndef DSMGP_DIAG_PRIO
+#define DSMGP_DIAG_PRIO 0                 // s_setprio of the wave that factorises a 16x16 diagonal block (its chain of ~400 dependent
+#endif                                    // f64 vector instructions shares the SIMD's f64 pipe with the other waves' MFMAs)
+#ifndef DSMGP_DIAGR_K0_WGS
+#define DSMGP_DIAGR_K0_WGS 0              // > 0: the K = 0 launches of the diagonal-block task (no tile update in front: the tasks
+#endif                                    // start at the kernel function) run as an instantiation of their own, compiled for that many workgroups per CU
 
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
@@ -491,6 +497,24 @@ __global__ __launch_bounds__(256) void zero_pad_rows_kernel(const ZeroRowsTask* 
     for (int col = threadIdx.x >> 7; col < tk.ncols; col += 2) tk.p[r + (size_t)col * tk.ld] = 0.0;
 }
 
+// The 28 upper 16x16 blocks of a factor's diagonal tiles <- 0, once per plan (build_plan).  No kernel reads them -- every consumer of
+// a diagonal tile takes its 36 lower blocks (tile_fused8_body, dinv_complete, the packed image) or its diagonal entries (mll), the
+// inverse comes from Dinv -- and until round 6 every diagonal-block task of a fused step wrote them again in every fit: 56 of the
+// 128 KB a task stores (2.4 GB in the first launch of a depth-4 fit).  Now they are written here and by nobody afterwards.
+struct ZeroUpperTask {
+    double* p;            // origin of the leaf's first diagonal tile
+    int ld, nb;           // leading dimension, number of diagonal tiles (tile k at p + k 128 (ld + 1))
+};
+__global__ __launch_bounds__(256) void zero_upper_blocks_kernel(const ZeroUpperTask* __restrict__ tasks) {
+    const ZeroUpperTask tk = tasks[blockIdx.x];
+    const int r = threadIdx.x & (TB - 1);
+    for (int k = blockIdx.y; k < tk.nb; k += gridDim.y) {
+        double* t = tk.p + (size_t)k * TB * ((size_t)tk.ld + 1);
+        for (int col = 16 + (threadIdx.x >> 7); col < TB; col += 2)
+            if (r < (col & ~15)) t[r + (size_t)col * tk.ld] = 0.0;
+    }
+}
+
 // Gram values of a wave's 9 lower blocks of the diagonal tile, S = k - product in place (syrk_gram_epilogue without the
 // store), then the blocks go into the packed image of chol_diag_packed_body
 #ifndef DSMGP_SYRK_GRAM_GROUP
@@ -632,8 +656,15 @@ __device__ __forceinline__ void diag_finish_front(const TileTask& tt, double* S,
 //       the registers; w_I -= L(I,J) z_J
 // 20 KB of LDS beside the update's 36 KB ring (they alias), registers for nine blocks: three workgroups per CU.
 // No inverse phase (the fused steps' tile tasks substitute against L_kk: tile_fused8_body).
-constexpr int DIAGR_PANEL = 8 * 256;                         // doubles: solved panel, block row I at 256 I (column-major, ld 16)
-constexpr int DIAGR_LDS_DOUBLES = DIAGR_PANEL + 256 + 2 * TB + 2;   // + L_JJ^-1 + rhs block + z + first bad pivot
+// LDS strides chosen against bank conflicts (round 6; the counters had read SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.094 for this
+// kernel since round 4): a block row of the panel is 256 doubles but sits DIAGR_PB = 272 apart -- the rows-below update of the
+// right-hand side reads one row per thread, 16 consecutive rows per block, so a half wave spans two block rows, which 256 apart
+// fall on the same banks (272 = 16 mod 32 doubles: the second block row takes the other half of the banks); L_JJ^-1 is written
+// transposed out of the accumulator layout, 16 lanes a row apart: rows DIAGR_SLD = 17 doubles apart instead of 16 (8-way -> none).
+constexpr int DIAGR_PB = 272;                                // doubles between block rows of the solved panel (column-major, ld 16)
+constexpr int DIAGR_SLD = 17;                                // leading dimension of L_JJ^-1 in LDS
+constexpr int DIAGR_PANEL = 8 * DIAGR_PB;
+constexpr int DIAGR_LDS_DOUBLES = DIAGR_PANEL + 16 * DIAGR_SLD + 2 * TB + 2;   // + L_JJ^-1 + rhs block + z + first bad pivot
 constexpr int DIAGR_LDS_BYTES = ((NRING * KC2 * LDP > DIAGR_LDS_DOUBLES ? NRING * KC2 * LDP : DIAGR_LDS_DOUBLES) + 16) * (int)sizeof(double);
 
 // Which block an accumulator of wave W holds (the layout syrk_mainloop leaves): waves 0..2 a 3x3 square of blocks, wave 3 the
@@ -656,7 +687,7 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
     const int l15 = lane & 15, l4 = lane >> 4;
     double* panel = S;
     double* sLinv = S + DIAGR_PANEL;
-    double* wl = sLinv + 256;
+    double* wl = sLinv + 16 * DIAGR_SLD;
     double* zl = wl + TB;
     int* sbad = reinterpret_cast<int*>(zl + TB);
     const bool fuse = tk.wk != nullptr;
@@ -666,13 +697,14 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
     }
     if (t == 0) sbad[0] = 0;
     const int JN = (tk.nvalid + 15) >> 4;
-    {   // what is known to be zero in the tile goes out now (chol_diag_packed_body does the same)
+    if (JN < 8) {   // the lower blocks of the block columns without data go out now, as zeros (the upper blocks are zeroed once per
+                    // plan: zero_upper_blocks_kernel)
         const int mc = lane >> 3, mr = 2 * (lane & 7);
         const d2 zero = {0.0, 0.0};
 #pragma unroll 4
         for (int q = 0; q < 16; ++q) {
             const int b = W + 4 * q, I = b >> 3, K = b & 7;
-            if (I < K || (I > K && K >= JN)) {
+            if (I > K && K >= JN) {
                 double* gT = tk.T + (size_t)(16 * I + mr) + (size_t)(16 * K + mc) * tk.ld;
                 *reinterpret_cast<d2*>(gT) = zero;
                 *reinterpret_cast<d2*>(gT + (size_t)8 * tk.ld) = zero;
@@ -687,7 +719,9 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
             constexpr int i = decltype(ic)::value;
             if constexpr (diagr_rb(W, i) == J && diagr_cb(W, i) == J) {
                 d4 lt, xi;
+                if (DSMGP_DIAG_PRIO) __builtin_amdgcn_s_setprio(DSMGP_DIAG_PRIO);
                 const int bj = potrf_inv16_mfma(acc[i], lt, xi, lane);
+                if (DSMGP_DIAG_PRIO) __builtin_amdgcn_s_setprio(0);
                 if (bj != 0 && lane == 0 && sbad[0] == 0) sbad[0] = J * 16 + bj;
                 // lt register g = L(l15, 4g + l4), xi register g = L^-1(4g + l4, l15)
                 const gf64_ptr gT = AS_GLOBAL_F64(tk.T + (size_t)(16 * J + l15) + (size_t)(16 * J + l4) * tk.ld);
@@ -698,7 +732,7 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
                     gT[(size_t)(4 * g) * tk.ld] = (l15 >= q) ? lt[g] : 0.0;
                     const double x = (q >= l15) ? xi[g] : 0.0;
                     gD[4 * g] = x;
-                    sLinv[l15 * 16 + q] = x;
+                    sLinv[l15 * DIAGR_SLD + q] = x;
                 }
             }
         });
@@ -713,7 +747,7 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
             {
                 double la[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) la[q] = sLinv[(4 * q + l4) * 16 + l15];
+                for (int q = 0; q < 4; ++q) la[q] = sLinv[(4 * q + l4) * DIAGR_SLD + l15];
                 static_for<9>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     constexpr int rb = diagr_rb(W, i), cb = diagr_cb(W, i);
@@ -724,7 +758,7 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
                         v = __builtin_amdgcn_mfma_f64_16x16x4f64(la[3], acc[i][3], v, 0, 0, 0);
                         const d4 x = u + v;
                         acc[i] = x;
-                        double* ps = panel + rb * 256 + l15;
+                        double* ps = panel + rb * DIAGR_PB + l15;
                         const gf64_ptr g0 = AS_GLOBAL_F64(tk.T + (size_t)(16 * rb + l15) + (size_t)(16 * J + l4) * tk.ld);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -737,7 +771,7 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
                     const double* linv = sLinv + lane;
                     double sum = 0.0;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) sum = fma(linv[c * 16], wl[16 * J + c], sum);
+                    for (int c = 0; c < 16; ++c) sum = fma(linv[c * DIAGR_SLD], wl[16 * J + c], sum);
                     zl[16 * J + lane] = sum;
                 }
             }
@@ -748,8 +782,8 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
             auto trailing = [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int rb = diagr_rb(W, i), cb = diagr_cb(W, i);
-                const double* pk = panel + cb * 256 + l15;
-                const double* pi = panel + rb * 256 + l15;
+                const double* pk = panel + cb * DIAGR_PB + l15;
+                const double* pi = panel + rb * DIAGR_PB + l15;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pk[(4 * q + l4) * 16], pi[(4 * q + l4) * 16], acc[i], 0, 0, 0);
@@ -766,7 +800,7 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
                 if constexpr (diagr_cb(W, i) > J && !(diagr_rb(W, i) == J + 1 && diagr_cb(W, i) == J + 1)) trailing(ic);
             });
             if (fuse && t < TB && t >= 16 * (J + 1)) {      // w_I -= L(I,J) z_J for the rows below block J
-                const double* lrow = panel + (t >> 4) * 256 + (t & 15);
+                const double* lrow = panel + (t >> 4) * DIAGR_PB + (t & 15);
                 double sum = 0.0;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) sum = fma(lrow[c * 16], zl[16 * J + c], sum);
@@ -797,7 +831,7 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
     }
 }
 
-template <int W>
+template <int W, bool K0 = false>
 __device__ __forceinline__ void diag_fused_reg(const TileTask& tt, const DiagTask& d, const KParam* __restrict__ kp, int D, double* S) {
     constexpr int SHAPE = W == 3 ? 1 : 0;
     constexpr int rbase = (W == 2) ? 2 : 5, cbase = (W == 1) ? 3 : 0;
@@ -805,7 +839,12 @@ __device__ __forceinline__ void diag_fused_reg(const TileTask& tt, const DiagTas
                         W == 3 ? 4 : cbase, W == 3 ? 6 : cbase + 1, W == 3 ? 7 : cbase + 2};
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
     d4 acc[9];
-    syrk_mainloop<SHAPE>(tt, acc, sA, blk);                 // ends on a barrier: the ring is free
+    if constexpr (K0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    } else {
+        syrk_mainloop<SHAPE>(tt, acc, sA, blk);             // ends on a barrier: the ring is free
+    }
     const KParam p = kp[tt.kid];
     gram_stage_coords(tt, D, S, nullptr, false);            // coordinates over the ring (barrier inside)
     if (p.kind == 0) syrk_gram_inplace<SHAPE, 0>(tt, p, D, acc, blk, S);
@@ -840,6 +879,27 @@ __global__ __launch_bounds__(256, DSMGP_DIAGR_WGS) void diag_fused_reg_kernel(co
     else if (w == 2) diag_fused_reg<2>(tt, ft.d, kp, D, S);
     else diag_fused_reg<3>(tt, ft.d, kp, D, S);
 }
+
+#if DSMGP_DIAGR_K0_WGS > 0
+// The first block step of a fused phase (K = 0): no tile update in front, so no operand ring and none of its registers
+__global__ __launch_bounds__(256, DSMGP_DIAGR_K0_WGS) void diag_fused_reg_k0_kernel(const DiagFusedTask* __restrict__ tasks,
+                                                                                     const KParam* __restrict__ kp, int D) {
+    extern __shared__ __attribute__((aligned(16))) double S[];
+    const DiagFusedTask ft = tasks[blockIdx.x];
+    TileTask tt{};
+    tt.kid = ft.kid;
+    tt.gxa = ft.gx;
+    tt.glda = ft.glda;
+    tt.gna = tt.gnb = ft.d.nvalid;
+    tt.C = ft.d.T;
+    tt.ldc = ft.d.ld;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w == 0) diag_fused_reg<0, true>(tt, ft.d, kp, D, S);
+    else if (w == 1) diag_fused_reg<1, true>(tt, ft.d, kp, D, S);
+    else if (w == 2) diag_fused_reg<2, true>(tt, ft.d, kp, D, S);
+    else diag_fused_reg<3, true>(tt, ft.d, kp, D, S);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // The diagonal block INSIDE the update launch (round 4).  In a classic block step the chain update -> (reduce) -> diagonal

@@ -99,6 +99,7 @@ DIAG_SIGNATURES = {
     "dsmgp_bench_tile": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "dsmgp_probe_diag": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
     "dsmgp_bench_fused8": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "dsmgp_probe_diag_fused": (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _dp]),
 }
 DIAG_LIB_PATH = os.path.join(_HERE, "libdsmgp_hip_diag.so")
 
@@ -512,6 +513,12 @@ class Context:
         ph = np.zeros(23)
         self._chk(self.lib.dsmgp_probe_diag(self.h, int(ntiles), int(ld), int(reps), C.byref(us), ph.ctypes.data_as(_dp)))
         return us.value, ph
+
+    def probe_diag_fused(self, ntiles, K=0, reps=10):
+        """(diagnostic library) microseconds per launch of the fused steps' diagonal-block task on ntiles synthetic blocks"""
+        us = C.c_double(0.0)
+        self._chk(self.lib.dsmgp_probe_diag_fused(self.h, int(ntiles), int(K), int(reps), C.byref(us)))
+        return us.value
 
     def bench_tile(self, ntiles, K, mode=0, group=16, reps=3):
         """TFLOP/s of the tile GEMM on a uniform batch (diagnostic)."""

@@ -196,7 +196,7 @@ int dsmgp_set_gradient_leaves(dsmgp_ctx* ctx, const int32_t* active /* L flags, 
  * in the same process. */
 #define DSMGP_OPT_FIT_GRAPH 5
 /* DSMGP_OPT_LANES: leaf lanes of a fit (src/fit.jl:88-119: the leaves are independent): 0 (default) = automatic -- two lanes from 8
- * sharing groups on (a source leaf with its COPY / PREFIX leaves is one group), one below (a single GP) and with a reserved device pool -- 1 = one lane, 2 = two.
+ * sharing groups on (a source leaf with its COPY / PREFIX leaves is one group), one below (a single GP) -- 1 = one lane, 2 = two.
  * With two lanes the leaves are dealt longest-processing-time first into two halves with step lists, split-K workspace and HIP
  * stream of their own, joined at the end of the factorisation: one half's latency-bound launches (diagonal blocks, panel solves,
  * reduces) run under the other's update launches.  Per-leaf results agree to rounding with the one-lane schedule (a launch of half

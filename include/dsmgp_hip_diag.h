@@ -27,6 +27,10 @@ int dsmgp_bench_fused8(dsmgp_ctx* ctx, int32_t ntasks, int32_t K, int32_t group,
  * wave 0 the trailing product and the potrf + inverse of the next 16x16 diagonal block (us, then shader cycles) */
 int dsmgp_probe_diag(dsmgp_ctx* ctx, int32_t ntiles, int32_t ld, int32_t reps, double* kernel_us, double* phases_us);
 
+/* diagnostic: the diagonal-block task of a fused step (diag_fused_reg_kernel) alone on ntiles synthetic blocks whose tile update has
+ * depth K (a multiple of 128; 0 = the first block step): us per launch.  256 / 512 / 768 blocks = one / two / three tasks per CU */
+int dsmgp_probe_diag_fused(dsmgp_ctx* ctx, int32_t ntiles, int32_t K, int32_t reps, double* kernel_us);
+
 #ifdef __cplusplus
 }
 #endif

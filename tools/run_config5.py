@@ -22,6 +22,7 @@ ap.add_argument("--iterations", type=int, default=1, help="train! iterations to 
 ap.add_argument("--host-only", action="store_true", help="build the tree and schedule only (no GPU)")
 ap.add_argument("--load-hyper", default=None, help=".npy hyper-vector to start train! from (instead of the random initialisation)")
 ap.add_argument("--save-hyper", default=None, help=".npy file that receives the hyper-vector after every optimiser step")
+ap.add_argument("--lanes", type=int, default=None, help="DSMGP_OPT_LANES inside every leaf group (default: automatic = one under the pool)")
 args = ap.parse_args()
 
 t0 = time.perf_counter()
@@ -64,6 +65,8 @@ if args.train:                        # train! iterations (src/optimisers.jl:40-
     out["root_mll"] = dsm.update(model)
     print(json.dumps(out))
     sys.exit(0)
+if args.lanes is not None:
+    model.ctx.set_option(dsm.hipabi.OPT_LANES, args.lanes)
 dsm.resident_test(model, Xt)          # the test rows ride through the factorisation of every leaf group
 model.ctx.set_profile(1)
 t0 = time.perf_counter(); dsm.fit(model); out["fit_s"] = time.perf_counter() - t0
@@ -79,4 +82,11 @@ out["root_mll"] = z
 out["rmse"] = float(np.sqrt(np.mean((mu - np.mean(y)) ** 2)))
 out["finite"] = bool(np.all(np.isfinite(mu)) and np.all(var > 0))
 out["cholesky_tflops"] = float(np.sum(n ** 3) / 3 / out["fit_s"] / 1e12)
+# the algorithmic flops of the whole step: n^3/3 per factorisation + n^2 n_t per leaf for the prediction solves
+from deepstructuredmixtures_amd import tree as ptree
+nt = np.diff(ptree.route(model.root, Xt)[0]).astype(np.float64)
+out["flops_cholesky"], out["flops_predict_solves"] = float(np.sum(n ** 3) / 3), float(np.sum(n * n * nt))
+out["matrix_tflops_fit_predict"] = (out["flops_cholesky"] + out["flops_predict_solves"]) / (out["fit_s"] + out["update_predict_s"]) / 1e12
+out["whole_run_frac_of_78.6"] = out["matrix_tflops_fit_predict"] / 78.6
+out["lanes"] = args.lanes
 print(json.dumps(out))
