@@ -27,4 +27,12 @@ run() {   # run <name> <bench args...>: the three PMC passes FIRST; for the head
 run n100k --steps 2 --warmup 2 --no-cpu-baseline --no-other-configs
 run depth4 --config dsmgp_n100k_d8_depth4 --steps 2 --warmup 2 --no-cpu-baseline
 run train --mode train --steps 2 --warmup 1
+# BASELINE configs 2 and 3 (tools/run_config3.py: single GP n = 4096, then the PoE of 128 ArdSE experts): kernel stats, the SQ / GRBM
+# pass, and the vector-instruction counters that say whether the ArdSE kernel function (8 exp per entry) is what its launches do
+mkdir -p $out/c23_stats $out/c23_pmc1 $out/c23_pmc4
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c23_stats -- python3 tools/run_config3.py > $out/c23_stats/run.log 2>&1
+rocprofv3 --kernel-trace --pmc $PMC1 --output-format csv -d $out/c23_pmc1 -- python3 tools/run_config3.py > $out/c23_pmc1/run.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $out/c23_pmc4 -- python3 tools/run_config3.py > $out/c23_pmc4/run.log 2>&1 || echo "c23 pmc4 pass failed (counter names?)"
+echo "c23 done"
+python3 tools/fit_timeline.py $out/depth4_stats $TAG > $out/fit_timeline.log 2>&1 || echo "fit_timeline failed"
 echo profiled

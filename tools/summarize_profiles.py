@@ -205,3 +205,49 @@ for run in ("n100k", "depth4", "train"):
             write_union(run, line, "tile_fused8_kernel<0>", "tile_fused8_kernel<0>")
         elif run == "n100k":
             write_union(run, line, "tile_gemm_kernel_v2<false, 0,", "tile_gemm_kernel_v2<false, 0, *>")
+
+
+# BASELINE configs 2 and 3 (tools/run_config3.py under the profiler): kernel stats + per-kernel counters -> <tag>_configs23_pmc_summary.json
+if os.path.isdir(f"{base}/c23_stats"):
+    shutil.copy(newest(f"{base}/c23_stats/**/*_kernel_stats.csv"), f"profiles/{tag}_configs23_kernel_stats.csv")
+    shutil.copy(f"{base}/c23_stats/run.log", f"profiles/{tag}_configs23_rocprof_run.log")
+    res = {}
+    for d in ("c23_pmc1", "c23_pmc4"):
+        try:
+            rows = rows_of(d)
+        except FileNotFoundError:
+            continue
+        agg, dur, seen = collections.defaultdict(float), collections.defaultdict(float), set()
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+            if (d, r["Dispatch_Id"]) not in seen:
+                seen.add((d, r["Dispatch_Id"]))
+                dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e9
+        for (k, cname), v in agg.items():
+            res.setdefault(k, {"seconds": {}})[cname] = v
+            res[k]["seconds"][d] = dur[k]
+    out23 = {}
+    for k, c in res.items():
+        sec = max(c["seconds"].values()) if c["seconds"] else 0.0
+        if sec < 2e-4:
+            continue
+        e = {"seconds_in_run": sec}
+        if c.get("GRBM_GUI_ACTIVE"):
+            gui = c["GRBM_GUI_ACTIVE"] / 8.0
+            e["clock_ghz"] = gui / c["seconds"].get("c23_pmc1", sec) / 1e9
+            e["mfma_busy_fraction"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / gui
+            if c.get("SQ_WAVE_CYCLES"):
+                e["wait_inst_over_wave_cycles"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        if c.get("SQ_INSTS_VALU") is not None and c.get("SQ_INSTS_MFMA") is not None:
+            # wave instructions: a vector instruction holds its SIMD's lane pipe for 4 cycles, an f64 MFMA for 64
+            e["valu_wave_instructions"] = c["SQ_INSTS_VALU"]
+            e["mfma_wave_instructions"] = c["SQ_INSTS_MFMA"]
+            e["valu_over_mfma_pipe_cycles"] = (c["SQ_INSTS_VALU"] * 4.0) / max(1.0, c["SQ_INSTS_MFMA"] * 64.0)
+        out23[k] = e
+    json.dump(out23, open(f"profiles/{tag}_configs23_pmc_summary.json", "w"), indent=1)
+    print("== configs 2 / 3:")
+    for k, v in sorted(out23.items(), key=lambda kv: -kv[1]["seconds_in_run"])[:8]:
+        print("  ", k[:60], {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()})
+if os.path.exists(f"{base}/fit_timeline.log"):
+    shutil.copy(f"{base}/fit_timeline.log", f"profiles/{tag}_bench_depth4_fit_timeline.log")
