@@ -38,6 +38,9 @@ namespace dsmgp {
 #define DSMGP_DIAGR_BALANCED 0            // 1 = the 36 lower blocks dealt so that every wave factorises two of the eight 16x16 diagonal
 #endif                                    // blocks (kernels.hpp SYRK_BAL); 0 = the deal of the update tiles (wave 3: six of them).
                                           // Measured equal (profiles/r06_diag_balanced_ab.log): the deal is not what the task waits for
+#ifndef DSMGP_DIAGR_FULL_FORM
+#define DSMGP_DIAGR_FULL_FORM 0           // 1 = tiles whose 128 rows all hold data evaluate the kernel function without validity masks (12.0k -> 11.4k vector instructions per task, same time: r06_probe_diag_fused_counters.log)
+#endif
 #ifndef DSMGP_DIAGR_SKIP
 #define DSMGP_DIAGR_SKIP 0                // DIAGNOSTIC builds only (tools/probe_diag_fused.py): leave parts of the task out to see what its
 #endif                                    // time is made of -- 1 kernel function, 2 the 16x16 factorisations, 4 trailing products, 8 panel solves
@@ -527,7 +530,11 @@ __global__ __launch_bounds__(256) void zero_upper_blocks_kernel(const ZeroUpperT
 #ifndef DSMGP_SYRK_GRAM_GROUP
 #define DSMGP_SYRK_GRAM_GROUP 2         // blocks whose kernel-function sums are in flight at once (round 4: 3 -- with 68 B of scratch)
 #endif
-template <int SHAPE, int KIND, int W = 0>
+// FULL (round 6): all 128 rows of the tile hold data -- no validity masks; the noise term goes on the entries with row == col of
+// the DIAGONAL blocks only (which accumulators those are is known at compile time): 12.0k -> 11.0k vector instructions per task,
+// where the counters put the task at 58 % of what its vector + matrix instructions occupy the f64 pipe (profiles/r06_probe_diag_fused_counters.log).
+// Same values as the masked form: valid ? kv : 0 and valid ? kv + (noise + 1e-8) : 1 with everything valid.
+template <int SHAPE, int KIND, int W = 0, bool FULL = false>
 __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KParam& p, int D, d4 (&acc)[9], const int (&blk)[6],
                                                   const double* sa) {
     const int lane = threadIdx.x & 63;
@@ -560,7 +567,13 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int row = 16 * rbk[i] + l15, col = 16 * cbk[i] + l4 + 4 * (r0 + r);
-                    const double kv = gram_finish<KIND>(z[0][r], p, row, col, tk.gna, tk.gnb, true);
+                    double kv;
+                    if constexpr (FULL) {
+                        kv = gram_finish<KIND, false>(z[0][r], p, row, col, tk.gna, tk.gnb, true);
+                        if (rbk[i] == cbk[i] && l15 == l4 + 4 * (r0 + r)) kv += p.noise + 1e-8;
+                    } else {
+                        kv = gram_finish<KIND>(z[0][r], p, row, col, tk.gna, tk.gnb, true);
+                    }
                     acc[i][r0 + r] = kv - acc[i][r0 + r];
                 }
             }
@@ -594,7 +607,13 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * rbk[i] + l15, col = 16 * cbk[i] + l4 + 4 * r;
-                        const double kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
+                        double kv;
+                        if constexpr (FULL) {
+                            kv = gram_finish<KIND, false>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
+                            if (rbk[i] == cbk[i] && l15 == l4 + 4 * r) kv += p.noise + 1e-8;
+                        } else {
+                            kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
+                        }
                         acc[i][r] = kv - acc[i][r];
                     }
                 }
@@ -877,7 +896,9 @@ __device__ __forceinline__ void diag_fused_reg(const TileTask& tt, const DiagTas
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[i][r] = (diagr_rb(W, i) == diagr_cb(W, i) && (int)(threadIdx.x & 15) == (int)((threadIdx.x & 63) >> 4) + 4 * r) ? 4.0 : 0.0;
-    } else if (p.kind == 0) syrk_gram_inplace<SHAPE, 0, W>(tt, p, D, acc, blk, S);
+    } else if (DSMGP_DIAGR_FULL_FORM && tt.gna == TB && p.kind == 0) syrk_gram_inplace<SHAPE, 0, W, true>(tt, p, D, acc, blk, S);
+    else if (DSMGP_DIAGR_FULL_FORM && tt.gna == TB && p.kind == 1) syrk_gram_inplace<SHAPE, 1, W, true>(tt, p, D, acc, blk, S);
+    else if (p.kind == 0) syrk_gram_inplace<SHAPE, 0, W>(tt, p, D, acc, blk, S);
     else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1, W>(tt, p, D, acc, blk, S);
     else syrk_gram_inplace<SHAPE, 2, W>(tt, p, D, acc, blk, S);
     __syncthreads();                                        // the coordinates are no longer read: panel and rhs take their place
