@@ -124,6 +124,16 @@ class TreeIndex:
                 self.lw[sl] = np.where(self.edge_is_sum[sl], post, 0.0)
         return val
 
+    def weights_normalised(self, tol=1e-12):
+        """Do the weights of every sum node add up to one?  Every path of the reference keeps them so (-log V at build,
+        `src/treeStructure.jl:226`; log Dirichlet draws, `:260-286`; the posterior of `update!` / `infer!`,
+        `src/common.jl:326-353`) -- but `logweights` is a plain field a caller may assign."""
+        if not self.lw.size or not np.any(self.edge_is_sum):
+            return True
+        tot = np.bincount(self.edge_parent[self.edge_is_sum], weights=np.exp(self.lw[self.edge_is_sum]), minlength=self.n)
+        par = np.unique(self.edge_parent[self.edge_is_sum])
+        return bool(np.all(np.abs(tot[par] - 1.0) <= tol))
+
     def leaf_path_logweights(self):
         """log of the product of sum-node weights on every leaf's path, indexed by leaf id."""
         acc = np.zeros(self.n)
@@ -933,6 +943,14 @@ def predict(model, xtest):
         return mu, var
     xt = _test_matrix(model, xtest)
     model._scores_on_device = False
+    if model.family == "dsmgp" and model.root.kind != "gp" and not model.tindex.weights_normalised():
+        # `_predict` shifts the means by c = mu_min - 1 before it weighs them (`src/common.jl:134-143,275-302`): with weights
+        # that add up to one the shift cancels and the recursion IS the flat mixture the device aggregates; with weights a
+        # caller assigned by hand it leaves c (1 - sum of weights) per sum node behind.  Then: the literal recursion on the
+        # host, from the per-(leaf, row) moments of the device (the same on every rank: it depends on the weights alone)
+        rc = _routing(model, xt)
+        mu, var = _leaf_moments(model, xt, rc)
+        return _aggregate_dsmgp(model, xt, rc["ptr"], mu, var)
     if hasattr(_ctx_type(model), "aggregate_partial"):       # decided by the model's construction: the same on every rank
         # (a rank that holds leaves and whose context holds the tree routes its rows on the device: no host lists at all)
         return _predict_device(model, xt, _routing(model, xt, host_routes=not model._device_routing))

@@ -410,8 +410,17 @@ function aggregate(s::Session, family::Int32, coef, group, G::Integer, plain::Bo
     return μ, σ²
 end
 
+"Do the weights of every sum node add up to one?  (Every path of the reference keeps them so; `logweights` is a plain field.)"
+weightsnormalised(node::GPNode) = true
+weightsnormalised(node::GPSplitNode) = all(weightsnormalised, children(node))
+weightsnormalised(node::GPSumNode) = abs(sum(exp.(logweights(node))) - 1) <= 1e-12 && all(weightsnormalised, children(node))
+
 "predict(model::DSMGP, x) (src/common.jl:294-304): (μ, σ²) of the mixture; σ² ≤ 0 of a leaf → ϵ inside the aggregation (:137)."
 function predict(model::DSMGP, x::AbstractMatrix)
+    # `_predict` shifts the means by μmin - 1 before it weighs them (src/common.jl:134-143,275-302): with weights that add up to
+    # one the recursion IS the flat mixture the device aggregates; with hand-assigned ones it is not, and the reference's own
+    # recursion runs (its leaf predictions come from the device through prediction(gp, x) above)
+    weightsnormalised(model.root) || return predict(model.root, x)
     s = session(model.root)
     xt = Matrix{Float64}(x)
     settestrouted!(s, xt)          # (route! + settest! above are the host form of the same lists: rows in ascending order per leaf)

@@ -2111,3 +2111,22 @@ def test_native_tree_builder_equals_the_oracle_restatement_at_bench_sizes():
         nodes, regions = _native_table_equals_oracle(X, y, M, K, V, depth, eps, sr, nk, seed)
         if N == 100_000:
             assert regions == 144                                      # the 144 leaves of the headline bench line
+
+
+def test_predict_with_unnormalised_weights_on_the_device_moments():
+    """src/common.jl:134-143,275-302: hand-assigned sum-node weights that do not add up to one leave (mu_min - 1)(1 - sum w) in
+    the mean; the product then runs the literal recursion on the per-(leaf, row) moments of the device (model.predict)."""
+    X, y, Xt = regression_data(1200, 2, n_test=80, seed=64)
+    m = dsm.buildDSMGP(X, y, 3, 3, M=50, kernel=dsm.IsoSE(np.log(0.4), 0.0), logNoise=np.log(0.2), seed=9)
+    dsm.update(m)
+    gps = ospn.make_leaf_gps(m.root, X, y, exact_dist=True)
+    ospn.fit(m.root, gps, ospn.get_overlap(m.root, m.L))
+    mu_n, var_n = dsm.predict(m, Xt)
+    m.root.logweights = np.log(np.array([0.6, 0.3, 0.3]))
+    mu_u, var_u = dsm.predict(m, Xt)
+    mo, vo = ospn.predict(m.root, gps, Xt)
+    assert np.allclose(mu_u, mo, rtol=RTOL, atol=1e-10) and np.allclose(var_u, vo, rtol=RTOL, atol=1e-10)
+    assert np.max(np.abs(mu_u - mu_n)) > 1e-3
+    dsm.update(m)                                                       # back to the posterior weights: the device aggregation again
+    mu_b, var_b = dsm.predict(m, Xt)
+    assert np.array_equal(mu_b, mu_n) and np.array_equal(var_b, var_n)

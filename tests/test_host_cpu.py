@@ -1176,3 +1176,30 @@ def test_host_routing_takes_a_tree_wider_than_the_device_walks_stack():
     with pytest.raises(ValueError, match="outside"):
         hipabi.tree_route(kind2, np.array([1, 0, 0]), np.array([2, 0, 0]), np.zeros(3, dtype=np.int64),
                           np.array([[0.5, 0.9], [0, 0], [0, 0]], dtype=np.float64), np.array([-1, 0, 1]), 2, np.array([[0.95]]), 1)
+
+
+def test_predict_with_hand_assigned_unnormalised_weights_follows_the_reference_recursion():
+    """`_predict` shifts the leaf means by c = mu_min - 1 BEFORE it weighs them (src/common.jl:134-143,275-302).  With weights
+    that add up to one the shift cancels and the recursion is the flat mixture the device aggregates; `logweights` is a plain
+    field, though, and with hand-assigned weights the reference's answer carries c (1 - sum w) per sum node.  The product then
+    runs the literal recursion (host) on the device's per-(leaf, row) moments -- both context kinds, against the oracle."""
+    X, y = _small_problem(700, 2, seed=5)
+    Xt = uniform(77, 0, 60 * 2).reshape((60, 2), order="F")
+    for ctx_cls in (OracleContext, OraclePartialContext):
+        m = dsm.buildDSMGP(X, y, 3, 3, M=40, kernel=dsm.IsoSE(np.log(0.4), 0.0), logNoise=np.log(0.2), seed=8, ctx=ctx_cls())
+        dsm.update(m)
+        assert m.tindex.weights_normalised()
+        gps = ospn.make_leaf_gps(m.root, X, y)
+        ospn.fit_naive(m.root, gps)
+        mu_n, var_n = dsm.predict(m, Xt)
+        mo, vo = ospn.predict(m.root, gps, Xt)
+        assert np.allclose(mu_n, mo, rtol=1e-9, atol=1e-11) and np.allclose(var_n, vo, rtol=1e-8, atol=1e-11)
+        m.root.logweights = np.log(np.array([0.5, 0.2, 0.1]))            # adds up to 0.8
+        inner = next(c for sp in m.root.children for c in sp.children if c.kind == "sum")
+        inner.logweights = np.log(np.array([0.9, 0.4, 0.3]))             # adds up to 1.6
+        assert not m.tindex.weights_normalised()
+        mu_u, var_u = dsm.predict(m, Xt)
+        mo, vo = ospn.predict(m.root, gps, Xt)
+        assert np.allclose(mu_u, mo, rtol=1e-9, atol=1e-11) and np.allclose(var_u, vo, rtol=1e-8, atol=1e-11)
+        flat = np.exp(m.tindex.leaf_path_logweights())                   # ... and the flat mixture would NOT have been it
+        assert np.max(np.abs(mu_u - mu_n)) > 1e-3 and flat.sum() > 0
