@@ -386,6 +386,8 @@ def prediction(gp, xtest):
     """`prediction(gp, xtest)` -> (mu, diag of Sigma) (`src/gaussianprocess.jl:110-137`; only the
     diagonal of Sigma is ever consumed, `src/common.jl:136,147`)."""
     xt = _test_matrix(gp.model, xtest)
+    if xt.shape[0] == 0:
+        return np.zeros(0), np.zeros(0)
     # registered like the test set of a tree model (cached by content): a loop of update_cholesky! + prediction on the same
     # rows carries them through the factorisation launches from its second pass on, and prediction only finishes the moments
     rc = _routing(gp.model, xt)
@@ -926,6 +928,8 @@ def resident_test(model, xtest, tau=0.05):
     this call is for evaluation loops that know their test set up front and for the streaming context, where a
     prediction after an unprepared fit costs a second pass over all leaf groups."""
     xt = _test_matrix(model, xtest)
+    if xt.shape[0] == 0:
+        return                      # nothing to carry along
     model._upload(tau)
     rc = _routing(model, xt, host_routes=not model._device_routing)
     if len(model.shard.local):
@@ -943,6 +947,8 @@ def predict(model, xtest):
         return mu, var
     xt = _test_matrix(model, xtest)
     model._scores_on_device = False
+    if xt.shape[0] == 0:            # no rows: (Float64[], Float64[]) as in the reference; no device call, no collective (every rank sees the same x)
+        return np.zeros(0), np.zeros(0)
     if model.family == "dsmgp" and model.root.kind != "gp" and not model.tindex.weights_normalised():
         # `_predict` shifts the means by c = mu_min - 1 before it weighs them (`src/common.jl:134-143,275-302`): with weights
         # that add up to one the shift cancels and the recursion IS the flat mixture the device aggregates; with weights a

@@ -1203,3 +1203,21 @@ def test_predict_with_hand_assigned_unnormalised_weights_follows_the_reference_r
         assert np.allclose(mu_u, mo, rtol=1e-9, atol=1e-11) and np.allclose(var_u, vo, rtol=1e-8, atol=1e-11)
         flat = np.exp(m.tindex.leaf_path_logweights())                   # ... and the flat mixture would NOT have been it
         assert np.max(np.abs(mu_u - mu_n)) > 1e-3 and flat.sum() > 0
+
+
+def test_predict_of_no_rows_is_empty_on_every_path():
+    """Empty input: predict(model, x) with zero rows returns (Float64[], Float64[]) as the reference's loops do -- before any
+    device call (dsmgp_set_test refuses n_t = 0) and on every model family."""
+    X, y = _small_problem(300, 2, seed=6)
+    m = dsm.buildDSMGP(X, y, 2, 3, M=40, kernel=dsm.IsoSE(0.0, 0.0), fit_now=False, seed=3, device=None)
+    p = dsm.buildPoE(X, y, 3, M=60, kernel=dsm.IsoSE(0.0, 0.0), meanFun=dsm.ConstMean(0.0), fit_now=False, seed=3, device=None)
+    g = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(0.0, 0.0), ctx=OracleContext())
+    for model in (m, p):
+        mu, var = dsm.predict(model, X[:0])
+        assert mu.shape == var.shape == (0,) and mu.dtype == var.dtype == np.float64 and model._ctx is None
+        dsm.resident_test(model, X[:0])
+        assert model._ctx is None
+    mu, var = dsm.prediction(g, X[:0])
+    assert mu.shape == var.shape == (0,)
+    with pytest.raises(ValueError):                                   # ... while zero rows of the WRONG width are still refused
+        dsm.predict(m, np.zeros((0, 3)))
