@@ -420,6 +420,7 @@ function predict(model::DSMGP, x::AbstractMatrix)
     # `_predict` shifts the means by μmin - 1 before it weighs them (src/common.jl:134-143,275-302): with weights that add up to
     # one the recursion IS the flat mixture the device aggregates; with hand-assigned ones it is not, and the reference's own
     # recursion runs (its leaf predictions come from the device through prediction(gp, x) above)
+    size(x, 1) == 0 && return Float64[], Float64[]            # (dsmgp_set_test* refuse n_t = 0)
     weightsnormalised(model.root) || return predict(model.root, x)
     s = session(model.root)
     xt = Matrix{Float64}(x)
@@ -431,6 +432,7 @@ function predict(model::DSMGP, x::AbstractMatrix)
 end
 
 function predictfamily(model, x::AbstractMatrix, family::Int32)
+    size(x, 1) == 0 && return Float64[], Float64[]
     s = session(model.root)
     xt = Matrix{Float64}(x)
     rows = Dict{Symbol,Vector{Int}}()
