@@ -293,60 +293,78 @@ def short_series(ctx, step, flops_step, steps, warmup, torch):
 
 def other_configs(device, torch):
     """BASELINE configs 2, 3 and 4'' (depth 4) on this GPU, each with its own model and context, after the headline series:
-    {name: {step_s, roofline{kernel, alg_flops, achieved, frac}, ...}} (VERDICT r5 #1b: every single-GPU config driver-observed)."""
+    {name: {step_s, roofline{kernel, alg_flops, achieved, frac}, ...}} (VERDICT r5 #1b: every single-GPU config driver-observed).
+    One config failing (memory, a HIP error) leaves the others in the line."""
     import deepstructuredmixtures_amd as dsm
     from deepstructuredmixtures_amd import tree as ptree
     h = HYPER["survey"]
+
+    def single_gp():
+        # config 2: one exact GP, N = 4096, D = 4, IsoSE: update_cholesky! + prediction on N/10 rows (src/gaussianprocess.jl:82-137)
+        X, y, Xt = dsm.regression_data(4096, 4, seed=20202)
+        gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(h["logl"], h["logs"]), logNoise=h["lognoise"], device=device)
+        try:
+            def step():
+                dsm.update_cholesky(gp)
+                return dsm.prediction(gp, Xt)
+            r = short_series(gp.model.ctx, step, 4096.0 ** 3 / 3 + 4096.0 ** 2 * Xt.shape[0], 30, 3, torch)
+        finally:
+            gp.model.ctx.close()
+        r["workload"] = (f"single GaussianProcess N=4096 D=4 IsoSE: update_cholesky! + prediction(gp, x) on {Xt.shape[0]} rows; "
+                         "32 dependent block steps")
+        return r
+
+    def poe_ardse():
+        # config 3: buildPoE K = 8, M = 200, N = 50k, D = 8, ArdSE (additive, SURVEY F6): 128 independent experts n ~ 391
+        X, y, Xt = dsm.regression_data(50_000, 8, seed=20203)
+        m = dsm.buildPoE(X, y, 8, M=200, kernel=dsm.ArdSE(np.full(8, h["logl"]), h["logs"]), logNoise=h["lognoise"],
+                         meanFun=dsm.ConstMean(float(np.mean(y))), seed=20203, fit_now=False, device=device)
+        nobs = np.array([lf.nobs for lf in m.leaves], dtype=np.float64)
+        try:
+            def step():
+                dsm.fit(m)
+                return dsm.predict(m, Xt)
+            r = short_series(m.ctx, step, float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2) * Xt.shape[0]), 30, 3, torch)
+        finally:
+            m.ctx.close()
+        r["workload"] = (f"buildPoE K=8 M=200 N=50000 D=8 ArdSE: {m.L} experts n={int(nobs.min())}..{int(nobs.max())}, every expert "
+                         f"predicts all {Xt.shape[0]} rows; fit! + predict; the kernel function (8 exp per entry) shares the f64 pipe "
+                         "with the MFMAs")
+        return r
+
+    def depth4():
+        # config 4'': the headline data at tree depth 4 (18,461 leaves, n = 103..2,668: the small-leaf regime)
+        c = CONFIGS["dsmgp_n100k_d8_depth4"]
+        X, y, Xt = dsm.regression_data(c["N"], c["D"], seed=20204)
+        t0 = time.perf_counter()
+        m = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=dsm.IsoSE(h["logl"], h["logs"]),
+                           logNoise=h["lognoise"], seed=20204, fit_now=False, device=device)
+        t_build = time.perf_counter() - t0
+        nobs = np.array([lf.nobs for lf in m.leaves], dtype=np.float64)
+        ptr, _ = ptree.route(m.root, Xt)
+        try:
+            dsm.resident_test(m, Xt)
+
+            def step():
+                dsm.fit(m)
+                dsm.update(m)
+                return dsm.predict(m, Xt)
+            r = short_series(m.ctx, step, float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2 * np.diff(ptr))), 10, 2, torch)
+            r["lanes"] = m.ctx.lanes()
+        finally:
+            m.ctx.close()
+        r["workload"] = (f"buildDSMGP K=4 splits V=3 sum children M=200 N=100000 D=8 IsoSE depth 4: {m.L} leaf GPs n={int(nobs.min())}.."
+                         f"{int(nobs.max())}, {Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; fit! + update! + predict")
+        r["model_build_s"] = t_build
+        return r
+
     out = {}
-    # config 2: one exact GP, N = 4096, D = 4, IsoSE: update_cholesky! + prediction on N/10 rows (src/gaussianprocess.jl:82-137)
-    X, y, Xt = dsm.regression_data(4096, 4, seed=20202)
-    gp = dsm.GaussianProcess(X, y, kernel=dsm.IsoSE(h["logl"], h["logs"]), logNoise=h["lognoise"], device=device)
-
-    def step2():
-        dsm.update_cholesky(gp)
-        return dsm.prediction(gp, Xt)
-    r = short_series(gp.model.ctx, step2, 4096.0 ** 3 / 3 + 4096.0 ** 2 * Xt.shape[0], 30, 3, torch)
-    r["workload"] = f"single GaussianProcess N=4096 D=4 IsoSE: update_cholesky! + prediction(gp, x) on {Xt.shape[0]} rows; 32 dependent block steps"
-    out["single_gp_n4096"] = r
-    gp.model.ctx.close()
-    # config 3: buildPoE K = 8, M = 200, N = 50k, D = 8, ArdSE (additive): 128 independent experts n ~ 391
-    X, y, Xt = dsm.regression_data(50_000, 8, seed=20203)
-    m = dsm.buildPoE(X, y, 8, M=200, kernel=dsm.ArdSE(np.full(8, h["logl"]), h["logs"]), logNoise=h["lognoise"],
-                     meanFun=dsm.ConstMean(float(np.mean(y))), seed=20203, fit_now=False, device=device)
-    nobs = np.array([lf.nobs for lf in m.leaves], dtype=np.float64)
-
-    def step3():
-        dsm.fit(m)
-        return dsm.predict(m, Xt)
-    r = short_series(m.ctx, step3, float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2) * Xt.shape[0]), 30, 3, torch)
-    r["workload"] = (f"buildPoE K=8 M=200 N=50000 D=8 ArdSE: {m.L} experts n={int(nobs.min())}..{int(nobs.max())}, every expert predicts all "
-                     f"{Xt.shape[0]} rows; fit! + predict; the kernel function (8 exp per entry) shares the f64 pipe with the MFMAs")
-    out["poe_ardse_n50k"] = r
-    m.ctx.close()
-    # config 4'': the headline data at tree depth 4 (18,461 leaves, n = 103..2,668: the small-leaf regime)
-    c = CONFIGS["dsmgp_n100k_d8_depth4"]
-    X, y, Xt = dsm.regression_data(c["N"], c["D"], seed=20204)
-    t0 = time.perf_counter()
-    m = dsm.buildDSMGP(X, y, c["K"], c["V"], M=c["M"], D=c["depth"], kernel=dsm.IsoSE(h["logl"], h["logs"]), logNoise=h["lognoise"],
-                       seed=20204, fit_now=False, device=device)
-    t_build = time.perf_counter() - t0
-    nobs = np.array([lf.nobs for lf in m.leaves], dtype=np.float64)
-    ptr, _ = ptree.route(m.root, Xt)
-    dsm.resident_test(m, Xt)
-
-    def step4():
-        dsm.fit(m)
-        dsm.update(m)
-        return dsm.predict(m, Xt)
-    r = short_series(m.ctx, step4, float(np.sum(nobs ** 3) / 3 + np.sum(nobs ** 2 * np.diff(ptr))), 10, 2, torch)
-    r["workload"] = (f"buildDSMGP K=4 splits V=3 sum children M=200 N=100000 D=8 IsoSE depth 4: {m.L} leaf GPs n={int(nobs.min())}.."
-                     f"{int(nobs.max())}, {Xt.shape[0]} test rows x {int(ptr[-1] // Xt.shape[0])} leaves each; fit! + update! + predict")
-    r["model_build_s"] = t_build
-    r["lanes"] = m.ctx.lanes()
-    out["dsmgp_depth4"] = r
-    m.ctx.close()
+    for name, fn in (("single_gp_n4096", single_gp), ("poe_ardse_n50k", poe_ardse), ("dsmgp_depth4", depth4)):
+        try:
+            out[name] = fn()
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
     return out
-
 
 def bench_train(args, model, X, y, rank, world, td, torch):
     """One train! iteration per step (src/optimisers.jl:40-80) on the bench config: setparams!, fit!, tree mll,
