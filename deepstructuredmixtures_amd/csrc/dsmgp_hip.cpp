@@ -1874,12 +1874,6 @@ void run_step(dsmgp_ctx* c, StepLists& S, int k, PhaseTimer& pt, hipStream_t st,
     if (nfd > 0 || nft8 > 0) {     // fused step: diagonal blocks (their tile's update included), then the tiles below them
         if (nfd > 0) {
             pt.begin(2, st);
-#if DSMGP_DIAGR_K0_WGS > 0
-            if (k == 0) {
-                constexpr int K0_LDS = (DIAGR_LDS_DOUBLES > GRAM_FUSE_MAX_D * TB ? DIAGR_LDS_DOUBLES : GRAM_FUSE_MAX_D * TB) * (int)sizeof(double) + 128;
-                diag_fused_reg_k0_kernel<<<nfd, 256, K0_LDS, st>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
-            } else
-#endif
             diag_fused_reg_kernel<<<nfd, 256, DIAGR_LDS_BYTES, st>>>(S.fdiag.p + S.fdiag_off[k], c->d_kp, c->D);
             pt.note(k, nfd, 0);
             pt.end(st);

@@ -633,49 +633,7 @@ __device__ __forceinline__ void gemm_mainloop_v2(const TileTask& tk, d4 (&acc)[4
 //   wave 2: block rows 2..4 x block columns 0..2      wave 3: the three 2x2 lower triangles at blocks 0, 3 and 6
 // Every wave reads 6 operand fragments per 4-column group (one LDS image: B == A) for its 9 MFMAs: 9/16 of the matrix
 // work, half the global and LDS staging traffic of a full tile.  Same ring / prefetch protocol as gemm_mainloop_v2.
-// SHAPE 0: 3x3 square (F[0..2] rows, F[3..5] columns), 1: three 2x2 lower triangles (F[2q], F[2q+1])
-// SHAPE 2 (round 6, the diagonal-block task of the fused steps): the BALANCED deal of the 36 lower blocks -- every wave a 2x2 lower
-// triangle on the diagonal (two diagonal blocks each) and six blocks below:
-//   wave 0: (6,6) (7,6) (7,7) + rows 6-7 x columns 0-2        wave 1: (4,4) (5,4) (5,5) + rows 6-7 x columns 3-5
-//   wave 2: (0,0) (1,0) (1,1) + rows 4-5 x columns 0-2        wave 3: (2,2) (3,2) (3,3) + rows 2-3 x columns 0-1 + rows 4-5 x column 3
-// nine blocks and at most six operand fragments per wave, as in shapes 0 / 1 (three 3x3 squares + the three diagonal triangles on
-// wave 3) -- but there wave 3 factorises six of the eight 16x16 diagonal blocks, ~1,600 cycles of its SIMD's f64 pipe each: with
-// three tasks on a CU that SIMD carries 23k cycles per task, the others 14k, and the launch runs at the pace of the fullest
-// (tools/probe_diag_fused.py: +10.5 us per co-resident task at K = 0 against 7.0 us of pipe work per task when dealt evenly).
-struct SyrkBalanced {
-    signed char rb[4][9], cb[4][9], frag[4][6];
-};
-constexpr SyrkBalanced SYRK_BAL = {
-    {{6, 7, 7, 6, 6, 6, 7, 7, 7}, {4, 5, 5, 6, 6, 6, 7, 7, 7}, {0, 1, 1, 4, 4, 4, 5, 5, 5}, {2, 3, 3, 2, 2, 3, 3, 4, 5}},
-    {{6, 6, 7, 0, 1, 2, 0, 1, 2}, {4, 4, 5, 3, 4, 5, 3, 4, 5}, {0, 0, 1, 0, 1, 2, 0, 1, 2}, {2, 2, 3, 0, 1, 0, 1, 3, 3}},
-    {{0, 1, 2, 6, 7, 7}, {3, 4, 5, 6, 7, 7}, {0, 1, 2, 4, 5, 5}, {0, 1, 2, 3, 4, 5}}};
-__host__ __device__ constexpr int bal_rb(int w, int i) { return SYRK_BAL.rb[w][i]; }
-__host__ __device__ constexpr int bal_cb(int w, int i) { return SYRK_BAL.cb[w][i]; }
-__host__ __device__ constexpr int bal_fpos(int w, int b) {       // position of block b's fragment in the wave's list
-    for (int q = 0; q < 6; ++q)
-        if (SYRK_BAL.frag[w][q] == b) return q;
-    return 0;
-}
-constexpr bool syrk_bal_covers() {       // every lower block exactly once, two diagonal blocks a wave, every operand in the wave's list
-    int seen[8][8] = {};
-    for (int w = 0; w < 4; ++w) {
-        int nd = 0;
-        for (int i = 0; i < 9; ++i) {
-            const int r = SYRK_BAL.rb[w][i], c = SYRK_BAL.cb[w][i];
-            if (r < c || seen[r][c]++) return false;
-            nd += r == c;
-            if (SYRK_BAL.frag[w][bal_fpos(w, r)] != r || SYRK_BAL.frag[w][bal_fpos(w, c)] != c) return false;
-        }
-        if (nd != 2) return false;
-    }
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c <= r; ++c)
-            if (seen[r][c] != 1) return false;
-    return true;
-}
-static_assert(syrk_bal_covers(), "balanced deal of the lower blocks");
-
-template <int SHAPE, int W = 0>
+template <int SHAPE>   // 0: 3x3 square (F[0..2] rows, F[3..5] columns), 1: three 2x2 lower triangles (F[2q], F[2q+1])
 __device__ __forceinline__ void syrk_mainloop(const TileTask& tk, d4 (&acc)[9], double (*sA)[KC2 * LDP], const int (&blk)[6]) {
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -704,10 +662,7 @@ __device__ __forceinline__ void syrk_mainloop(const TileTask& tk, d4 (&acc)[9], 
     } while (0)
 #define SMFMA9(F)                                                                                \
     do {                                                                                         \
-        if (SHAPE == 2) {                                                                        \
-            _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_)                                     \
-                acc[i_] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[bal_fpos(W, bal_cb(W, i_))], F[bal_fpos(W, bal_rb(W, i_))], acc[i_], 0, 0, 0); \
-        } else if (SHAPE == 0) {                                                                 \
+        if (SHAPE == 0) {                                                                        \
             _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                     \
                 _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                 \
                     acc[3 * i_ + j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[3 + j_], F[i_], acc[3 * i_ + j_], 0, 0, 0); \

@@ -34,19 +34,9 @@ namespace dsmgp {
 #ifndef DSMGP_DIAG_PRIO
 #define DSMGP_DIAG_PRIO 0                 // s_setprio of the wave that factorises a 16x16 diagonal block (its chain of ~400 dependent
 #endif                                    // f64 vector instructions shares the SIMD's f64 pipe with the other waves' MFMAs)
-#ifndef DSMGP_DIAGR_BALANCED
-#define DSMGP_DIAGR_BALANCED 0            // 1 = the 36 lower blocks dealt so that every wave factorises two of the eight 16x16 diagonal
-#endif                                    // blocks (kernels.hpp SYRK_BAL); 0 = the deal of the update tiles (wave 3: six of them).
-                                          // Measured equal (profiles/r06_diag_balanced_ab.log): the deal is not what the task waits for
-#ifndef DSMGP_DIAGR_FULL_FORM
-#define DSMGP_DIAGR_FULL_FORM 0           // 1 = tiles whose 128 rows all hold data evaluate the kernel function without validity masks (12.0k -> 11.4k vector instructions per task, same time: r06_probe_diag_fused_counters.log)
-#endif
 #ifndef DSMGP_DIAGR_SKIP
 #define DSMGP_DIAGR_SKIP 0                // DIAGNOSTIC builds only (tools/probe_diag_fused.py): leave parts of the task out to see what its
 #endif                                    // time is made of -- 1 kernel function, 2 the 16x16 factorisations, 4 trailing products, 8 panel solves
-#ifndef DSMGP_DIAGR_K0_WGS
-#define DSMGP_DIAGR_K0_WGS 0              // > 0: the K = 0 launches of the diagonal-block task (no tile update in front: the tasks
-#endif                                    // start at the kernel function) run as an instantiation of their own, compiled for that many workgroups per CU
 
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
@@ -530,11 +520,7 @@ __global__ __launch_bounds__(256) void zero_upper_blocks_kernel(const ZeroUpperT
 #ifndef DSMGP_SYRK_GRAM_GROUP
 #define DSMGP_SYRK_GRAM_GROUP 2         // blocks whose kernel-function sums are in flight at once (round 4: 3 -- with 68 B of scratch)
 #endif
-// FULL (round 6): all 128 rows of the tile hold data -- no validity masks; the noise term goes on the entries with row == col of
-// the DIAGONAL blocks only (which accumulators those are is known at compile time): 12.0k -> 11.0k vector instructions per task,
-// where the counters put the task at 58 % of what its vector + matrix instructions occupy the f64 pipe (profiles/r06_probe_diag_fused_counters.log).
-// Same values as the masked form: valid ? kv : 0 and valid ? kv + (noise + 1e-8) : 1 with everything valid.
-template <int SHAPE, int KIND, int W = 0, bool FULL = false>
+template <int SHAPE, int KIND>
 __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KParam& p, int D, d4 (&acc)[9], const int (&blk)[6],
                                                   const double* sa) {
     const int lane = threadIdx.x & 63;
@@ -544,8 +530,8 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int g3 = i / 3, j = i % 3;
-        rbk[i] = (SHAPE == 2) ? bal_rb(W, i) : (SHAPE == 0) ? blk[g3] : blk[2 * g3 + (j > 0 ? 1 : 0)];
-        cbk[i] = (SHAPE == 2) ? bal_cb(W, i) : (SHAPE == 0) ? blk[3 + j] : blk[2 * g3 + (j > 1 ? 1 : 0)];
+        rbk[i] = (SHAPE == 0) ? blk[g3] : blk[2 * g3 + (j > 0 ? 1 : 0)];
+        cbk[i] = (SHAPE == 0) ? blk[3 + j] : blk[2 * g3 + (j > 1 ? 1 : 0)];
     }
     if constexpr (KIND != 0) {
         // ArdSE / IsoLinear: one block, two of its entries at a time (the exp per dimension of the additive kernel and the
@@ -567,13 +553,7 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int row = 16 * rbk[i] + l15, col = 16 * cbk[i] + l4 + 4 * (r0 + r);
-                    double kv;
-                    if constexpr (FULL) {
-                        kv = gram_finish<KIND, false>(z[0][r], p, row, col, tk.gna, tk.gnb, true);
-                        if (rbk[i] == cbk[i] && l15 == l4 + 4 * (r0 + r)) kv += p.noise + 1e-8;
-                    } else {
-                        kv = gram_finish<KIND>(z[0][r], p, row, col, tk.gna, tk.gnb, true);
-                    }
+                    const double kv = gram_finish<KIND>(z[0][r], p, row, col, tk.gna, tk.gnb, true);
                     acc[i][r0 + r] = kv - acc[i][r0 + r];
                 }
             }
@@ -607,13 +587,7 @@ __device__ __forceinline__ void syrk_gram_inplace(const TileTask& tk, const KPar
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * rbk[i] + l15, col = 16 * cbk[i] + l4 + 4 * r;
-                        double kv;
-                        if constexpr (FULL) {
-                            kv = gram_finish<KIND, false>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
-                            if (rbk[i] == cbk[i] && l15 == l4 + 4 * r) kv += p.noise + 1e-8;
-                        } else {
-                            kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
-                        }
+                        const double kv = gram_finish<KIND>(z[j][0][r], p, row, col, tk.gna, tk.gnb, true);
                         acc[i][r] = kv - acc[i][r];
                     }
                 }
@@ -698,16 +672,13 @@ constexpr int DIAGR_LDS_BYTES = ((NRING * KC2 * LDP > DIAGR_LDS_DOUBLES ? NRING 
 // a block of column J" folds away and a step is straight-line code: the 16x16 factorisation of the NEXT diagonal block (a
 // latency-bound chain of vector instructions) and the wave's remaining trailing products (independent MFMAs) can interleave.
 __host__ __device__ constexpr int diagr_rb(int w, int i) {
-    if (DSMGP_DIAGR_BALANCED) return bal_rb(w, i);
     return w == 3 ? (i / 3) * 3 + (i % 3 > 0 ? 1 : 0) : (w == 2 ? 2 : 5) + i / 3;
 }
 __host__ __device__ constexpr int diagr_cb(int w, int i) {
-    if (DSMGP_DIAGR_BALANCED) return bal_cb(w, i);
     return w == 3 ? (i / 3) * 3 + (i % 3 > 1 ? 1 : 0) : (w == 1 ? 3 : 0) + i % 3;
 }
-static_assert(DSMGP_DIAGR_BALANCED ||
-                  (diagr_rb(3, 4) == 4 && diagr_cb(3, 4) == 3 && diagr_rb(3, 8) == 7 && diagr_cb(3, 8) == 7 && diagr_rb(0, 5) == 6 &&
-                   diagr_cb(0, 5) == 2 && diagr_rb(1, 4) == 6 && diagr_cb(1, 4) == 4 && diagr_rb(2, 8) == 4 && diagr_cb(2, 8) == 2),
+static_assert(diagr_rb(3, 4) == 4 && diagr_cb(3, 4) == 3 && diagr_rb(3, 8) == 7 && diagr_cb(3, 8) == 7 && diagr_rb(0, 5) == 6 &&
+                  diagr_cb(0, 5) == 2 && diagr_rb(1, 4) == 6 && diagr_cb(1, 4) == 4 && diagr_rb(2, 8) == 4 && diagr_cb(2, 8) == 2,
               "accumulator -> block map of syrk_mainloop");
 
 template <int W>
@@ -870,24 +841,15 @@ __device__ __forceinline__ void diag_reg_body(const DiagTask& tk, d4 (&acc)[9], 
     }
 }
 
-template <int W, bool K0 = false>
+template <int W>
 __device__ __forceinline__ void diag_fused_reg(const TileTask& tt, const DiagTask& d, const KParam* __restrict__ kp, int D, double* S) {
-    constexpr int SHAPE = DSMGP_DIAGR_BALANCED ? 2 : (W == 3 ? 1 : 0);
+    constexpr int SHAPE = W == 3 ? 1 : 0;
     constexpr int rbase = (W == 2) ? 2 : 5, cbase = (W == 1) ? 3 : 0;
-    const int blk[6] = {DSMGP_DIAGR_BALANCED ? SYRK_BAL.frag[W][0] : W == 3 ? 0 : rbase,
-                        DSMGP_DIAGR_BALANCED ? SYRK_BAL.frag[W][1] : W == 3 ? 1 : rbase + 1,
-                        DSMGP_DIAGR_BALANCED ? SYRK_BAL.frag[W][2] : W == 3 ? 3 : rbase + 2,
-                        DSMGP_DIAGR_BALANCED ? SYRK_BAL.frag[W][3] : W == 3 ? 4 : cbase,
-                        DSMGP_DIAGR_BALANCED ? SYRK_BAL.frag[W][4] : W == 3 ? 6 : cbase + 1,
-                        DSMGP_DIAGR_BALANCED ? SYRK_BAL.frag[W][5] : W == 3 ? 7 : cbase + 2};
+    const int blk[6] = {W == 3 ? 0 : rbase, W == 3 ? 1 : rbase + 1, W == 3 ? 3 : rbase + 2,
+                        W == 3 ? 4 : cbase, W == 3 ? 6 : cbase + 1, W == 3 ? 7 : cbase + 2};
     double (*sA)[KC2 * LDP] = reinterpret_cast<double (*)[KC2 * LDP]>(S);
     d4 acc[9];
-    if constexpr (K0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-    } else {
-        syrk_mainloop<SHAPE, W>(tt, acc, sA, blk);          // ends on a barrier: the ring is free
-    }
+    syrk_mainloop<SHAPE>(tt, acc, sA, blk);                 // ends on a barrier: the ring is free
     const KParam p = kp[tt.kid];
     gram_stage_coords(tt, D, S, nullptr, false);            // coordinates over the ring (barrier inside)
     if (DSMGP_DIAGR_SKIP & 1) {
@@ -896,11 +858,9 @@ __device__ __forceinline__ void diag_fused_reg(const TileTask& tt, const DiagTas
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[i][r] = (diagr_rb(W, i) == diagr_cb(W, i) && (int)(threadIdx.x & 15) == (int)((threadIdx.x & 63) >> 4) + 4 * r) ? 4.0 : 0.0;
-    } else if (DSMGP_DIAGR_FULL_FORM && tt.gna == TB && p.kind == 0) syrk_gram_inplace<SHAPE, 0, W, true>(tt, p, D, acc, blk, S);
-    else if (DSMGP_DIAGR_FULL_FORM && tt.gna == TB && p.kind == 1) syrk_gram_inplace<SHAPE, 1, W, true>(tt, p, D, acc, blk, S);
-    else if (p.kind == 0) syrk_gram_inplace<SHAPE, 0, W>(tt, p, D, acc, blk, S);
-    else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1, W>(tt, p, D, acc, blk, S);
-    else syrk_gram_inplace<SHAPE, 2, W>(tt, p, D, acc, blk, S);
+    } else if (p.kind == 0) syrk_gram_inplace<SHAPE, 0>(tt, p, D, acc, blk, S);
+    else if (p.kind == 1) syrk_gram_inplace<SHAPE, 1>(tt, p, D, acc, blk, S);
+    else syrk_gram_inplace<SHAPE, 2>(tt, p, D, acc, blk, S);
     __syncthreads();                                        // the coordinates are no longer read: panel and rhs take their place
     diag_reg_body<W>(d, acc, S);
 }
@@ -930,27 +890,6 @@ __global__ __launch_bounds__(256, DSMGP_DIAGR_WGS) void diag_fused_reg_kernel(co
     else if (w == 2) diag_fused_reg<2>(tt, ft.d, kp, D, S);
     else diag_fused_reg<3>(tt, ft.d, kp, D, S);
 }
-
-#if DSMGP_DIAGR_K0_WGS > 0
-// The first block step of a fused phase (K = 0): no tile update in front, so no operand ring and none of its registers
-__global__ __launch_bounds__(256, DSMGP_DIAGR_K0_WGS) void diag_fused_reg_k0_kernel(const DiagFusedTask* __restrict__ tasks,
-                                                                                     const KParam* __restrict__ kp, int D) {
-    extern __shared__ __attribute__((aligned(16))) double S[];
-    const DiagFusedTask ft = tasks[blockIdx.x];
-    TileTask tt{};
-    tt.kid = ft.kid;
-    tt.gxa = ft.gx;
-    tt.glda = ft.glda;
-    tt.gna = tt.gnb = ft.d.nvalid;
-    tt.C = ft.d.T;
-    tt.ldc = ft.d.ld;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (w == 0) diag_fused_reg<0, true>(tt, ft.d, kp, D, S);
-    else if (w == 1) diag_fused_reg<1, true>(tt, ft.d, kp, D, S);
-    else if (w == 2) diag_fused_reg<2, true>(tt, ft.d, kp, D, S);
-    else diag_fused_reg<3, true>(tt, ft.d, kp, D, S);
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // The diagonal block INSIDE the update launch (round 4).  In a classic block step the chain update -> (reduce) -> diagonal
