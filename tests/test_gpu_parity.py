@@ -2130,3 +2130,24 @@ def test_predict_with_unnormalised_weights_on_the_device_moments():
     dsm.update(m)                                                       # back to the posterior weights: the device aggregation again
     mu_b, var_b = dsm.predict(m, Xt)
     assert np.array_equal(mu_b, mu_n) and np.array_equal(var_b, var_n)
+
+
+def test_duplicate_training_points_and_test_points_on_training_points(ctx):
+    """Collisions as the domain has them: exact duplicates among the training rows (K singular, K + noise I not) and test rows that
+    ARE training rows (the smallest predictive variances the model can give), for the three kernel kinds, against the oracle."""
+    D = 3
+    base = uniform(70, 0, 150 * D).reshape((150, D), order="F")
+    X = np.asfortranarray(np.vstack([base, base[:90], base[:40]]))                  # 280 rows, 130 of them copies
+    y = np.sin(4 * X[:, 0]) + 0.05 * normal(71, 0, X.shape[0])
+    Xt = np.asfortranarray(np.vstack([base[:25], uniform(72, 0, 20 * D).reshape((20, D), order="F")]))
+    for kind, h in ((0, [np.log(0.4), 0.1]), (1, list(np.log([0.3, 0.6, 0.9])) + [0.0]), (2, [np.log(1.3), 0.0])):
+        logn = np.log(0.15)
+        mll, info, _ = _single(ctx, X, y, 0.1, kind, np.array(h), logn)
+        assert info[0] == 0
+        g = ogp.GaussianProcess(X, y, 0.1, ogp.make_kernel(kind, h), logn, exact_dist=True).update_cholesky()
+        assert abs(mll[0] - g.mll()) <= RTOL * abs(g.mll()), kind
+        n_t = Xt.shape[0]
+        mu, var = ctx.predict_leaves(Xt, np.array([0, n_t]), np.arange(n_t))
+        mo, vo = g.prediction(Xt)
+        assert np.allclose(mu, mo, rtol=RTOL, atol=1e-10), kind
+        assert np.allclose(var, vo, rtol=RTOL, atol=1e-12) and np.all(var > 0), kind
