@@ -1221,3 +1221,37 @@ def test_predict_of_no_rows_is_empty_on_every_path():
     assert mu.shape == var.shape == (0,)
     with pytest.raises(ValueError):                                   # ... while zero rows of the WRONG width are still refused
         dsm.predict(m, np.zeros((0, 3)))
+
+
+def test_tree_builders_reproduce_the_committed_tables(golden_dir):
+    """tests/golden/tree_tables.npz (made by oracle/tree.py, tests/golden/make_tree_golden.py): the native builder, the
+    interpreted builder and the oracle of TODAY all reproduce the committed node tables bit for bit."""
+    import importlib.util
+    from oracle import tree as otree
+    spec = importlib.util.spec_from_file_location("make_tree_golden", os.path.join(golden_dir, "make_tree_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    z = np.load(os.path.join(golden_dir, "tree_tables.npz"))
+    for name, (N, D, dseed, M, K, V, depth, eps, sr, nk, seed) in mk.CASES.items():
+        X, y, _ = regression_data(N, D, seed=dseed)
+        nat = hipabi.tree_build(X, M, K, V, depth, eps, sr, nk, seed, y=y)
+        orc = otree.table(otree.build_tree(X, y, M, K, V, depth, eps, sr, n_kernels=nk, seed=seed))
+        for k in ("kind", "parent", "split_dim", "lb", "ub", "thr_ptr", "obs_ptr"):
+            assert np.array_equal(nat[k], z[f"{name}/{k}"]) and np.array_equal(orc[k], z[f"{name}/{k}"]), (name, k)
+        nthr, nobs = z[f"{name}/thr"].size, z[f"{name}/obs"].size
+        assert np.array_equal(nat["thr"][:nthr], z[f"{name}/thr"]) and np.array_equal(nat["obs"][:nobs], z[f"{name}/obs"])
+        assert np.array_equal(np.asarray(nat["mean"]), z[f"{name}/mean"])
+        if nk:
+            R = z[f"{name}/mean"].size
+            e = -np.log(1.0 - nat["dir_u"][:R * nk].reshape(R, nk))
+            assert np.array_equal(e / e.sum(axis=1, keepdims=True), z[f"{name}/weights"])
+        # ... and the interpreted builder through the model: same regions, in order
+        kern = [dsm.IsoSE(0.0, 0.0), dsm.IsoLinear(0.0)] if nk else dsm.IsoSE(0.0, 0.0)
+        cfg = ptree.DSMGPConfig(None, kern, 1.0, M, K, V, depth, eps, sr)
+        root = ptree.build_tree(X, y, cfg, seed=seed, native=False)
+        reg = np.flatnonzero(z[f"{name}/kind"] == 0)
+        leaves = ptree.get_leaves(root)
+        assert len(leaves) == reg.size * max(1, nk)
+        for r, i in enumerate(reg):
+            o = z[f"{name}/obs"][z[f"{name}/obs_ptr"][i]:z[f"{name}/obs_ptr"][i + 1]]
+            assert np.array_equal(leaves[r * max(1, nk)].obs, o)
