@@ -2151,3 +2151,26 @@ def test_duplicate_training_points_and_test_points_on_training_points(ctx):
         mo, vo = g.prediction(Xt)
         assert np.allclose(mu, mo, rtol=RTOL, atol=1e-10), kind
         assert np.allclose(var, vo, rtol=RTOL, atol=1e-12) and np.all(var > 0), kind
+
+
+def test_bench_two_ranks_over_gloo_prints_one_json_line():
+    """bench.py --gpus 2 without a launcher (it starts its own two ranks under torch.distributed.run), exchange over gloo with both
+    ranks on this one GPU: the rehearsal of the N > 1 bench path the driver runs on a multi-GPU node.  Rank 0's stdout must carry
+    ONE JSON line and nothing else (gloo announces its connections on stdout: bench.py points fd 1 at stderr while the groups come
+    up), with both ranks' shares, the exchange seconds, and no device-exchange series (that needs RCCL)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSMGP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--config", "dsmgp_n20k_d8"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["exchange_backend"] == "gloo" and d["device_exchange_series"] is None
+    assert d["scaling"] == "strong" and d["unit"] == "s" and d["value"] > 0
+    ranks = d["ranks"]
+    assert [x["rank"] for x in ranks] == [0, 1] and sum(x["n_leaves"] for x in ranks) == 144
+    assert abs(sum(x["cholesky_flop_share"] for x in ranks) - 1.0) < 1e-12
+    assert all(x["exchanges_per_step"] == 2 and x["exchange_s_per_step"] > 0 for x in ranks)
